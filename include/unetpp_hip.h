@@ -1,0 +1,169 @@
+/*
+ * unetpp_hip.h -- C ABI of the MI355X (gfx950) UNet_Nested forward/backward path.
+ *
+ * The reference (unanan/UNet_Nested4Tiny_Objects_Keypoints) has no FFI of its own: its hot
+ * path is reached through the torch.nn.Module API of models/unet.py and executes inside
+ * torch.nn layers.  Each entry point below therefore cites the torch.nn call site in
+ * /root/reference/models/unet.py that it replaces.  All functions
+ *   - take plain device pointers, explicit sizes and a hipStream_t (passed as void*),
+ *   - never allocate, never synchronise, never own memory, keep no global state,
+ *   - return 0 on success or a negative UNETPP_E* code (nothing is thrown across the ABI),
+ *   - are asynchronous on `stream` and re-entrant per (device, stream).
+ *
+ * Tensor layout on the device is NHWC fp32 ("pixel-major": the channels of one pixel are
+ * contiguous).  A `unetpp_view` names a channel slice of such a tensor, optionally sampled
+ * on a strided pixel grid; the multi-view GEMM uses that to read a dense-skip concatenation
+ * (models/unet.py:198-202) without materialising it, and to express the 2x2/stride-2
+ * transposed convolution (models/unet.py:187) as a pointwise GEMM plus pixel shuffle.
+ */
+#ifndef UNETPP_HIP_H
+#define UNETPP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNETPP_ABI_VERSION 1
+#define UNETPP_MAX_VIEWS 8
+
+#define UNETPP_OK 0
+#define UNETPP_EINVAL (-1)   /* bad argument (null pointer, size <= 0, unsupported shape) */
+#define UNETPP_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
+
+/* A channel slice [c_off, c_off + c_len) of an NHWC fp32 tensor [N, Hs, Ws, C], sampled at
+ * tensor pixel (y*sy + oy, x*sx + ox) for logical pixel (y, x).  sy = sx = 1, oy = ox = 0
+ * is the plain case. */
+typedef struct unetpp_view {
+  float* ptr;
+  int32_t C, c_off, c_len;
+  int32_t Hs, Ws;
+  int32_t sy, sx, oy, ox;
+  /* on load : v = v * scale[c] + shift[c] (c counted inside the slice) when scale != NULL
+   * on store: unused */
+  const float* scale;
+  const float* shift;
+  /* ReLU-backward gate: an NHWC tensor with the same geometry as `ptr`; the value is
+   * multiplied by (gate > 0).  Applied on load for inputs, on store for outputs. */
+  const float* gate;
+  int32_t relu;        /* load: max(v, 0) after the affine; store: max(v, 0) after the bias */
+  int32_t accumulate;  /* store only: dst += v instead of dst = v */
+} unetpp_view;
+
+/* rows = N*H*W logical pixels;  out[p, n] = bias[n] + sum_{tap, k} in[p (+) tap, k] * weight[tap][k][n]
+ * K = sum of in[].c_len (virtual channel concatenation in view order), Ncols = sum of out[].c_len.
+ * taps = 9: 3x3 window, zero padding 1 (padding is applied AFTER the per-view load transform);
+ * taps = 1: pointwise.  Replaces nn.Conv2d(.,.,3,1,1) (models/unet.py:132,140), its input
+ * gradient, nn.ConvTranspose2d(.,.,2,2,0) (:187) forward and input gradient, nn.Conv2d(.,.,1) (:191). */
+typedef struct unetpp_gemm_desc {
+  int32_t N, H, W;
+  int32_t taps;
+  int32_t n_in;
+  int32_t n_out;
+  unetpp_view in[UNETPP_MAX_VIEWS];
+  unetpp_view out[UNETPP_MAX_VIEWS];
+  const float* weight; /* packed [taps][K][Ncols] (see unetpp_pack_weight) */
+  const float* bias;   /* [Ncols] or NULL */
+  /* optional BatchNorm statistics epilogue: per pixel-block partial (sum, sum of squares) of the
+   * stored values, [unetpp_gemm_pixel_blocks()][Ncols][2]; requires n_out == 1. */
+  float* stats_partial;
+} unetpp_gemm_desc;
+
+/* weight gradient:  dW[tap][k][n] = sum_p x[p (+) tap, k] * dy[p, n]  (+ db[n] = sum_p dy[p, n]).
+ * Replaces the weight/bias gradient of nn.Conv2d 3x3 / 1x1 and nn.ConvTranspose2d 2x2 s2
+ * (autograd of models/unet.py:132,140,187,191).  Split over pixel blocks: each of the
+ * `n_split` blocks per (k-tile, n-tile) writes one partial slab; unetpp_wgrad_finish sums them. */
+typedef struct unetpp_wgrad_desc {
+  int32_t N, H, W;
+  int32_t taps;
+  int32_t n_x;
+  int32_t n_dy;
+  unetpp_view x[UNETPP_MAX_VIEWS];  /* K = sum c_len */
+  unetpp_view dy[UNETPP_MAX_VIEWS]; /* Ncols = sum c_len (several views: the 4 pixel phases of a 2x2 deconv) */
+  int32_t n_split;                  /* partial slabs (<= unetpp_wgrad_max_split) */
+  float* slabs;                    /* [n_split][taps*K + 1][Ncols]; row taps*K holds db */
+} unetpp_wgrad_desc;
+
+int unetpp_abi_version(void);
+const char* unetpp_build_arch(void); /* "gfx950" */
+
+/* ---- multi-view pixel GEMM on MFMA (v_mfma_f32_32x32x2_f32) ------------------------------ */
+int64_t unetpp_gemm_pixel_blocks(int32_t N, int32_t H, int32_t W);
+int unetpp_gemm_fwd(const unetpp_gemm_desc* d, void* stream);
+
+int32_t unetpp_wgrad_max_split(int32_t N, int32_t H, int32_t W);
+int unetpp_wgrad(const unetpp_wgrad_desc* d, void* stream);
+/* column n = o*n_inner + i:  dw[t*d_t + k*d_k + i*d_n + o*d_o] = sum_s slabs[s][t*K + k][n];
+ * db[i] = sum_o sum_s slabs[s][taps*K][o*n_inner + i]   (n_inner = Ncols for a plain convolution) */
+int unetpp_wgrad_finish(const float* slabs, int32_t n_split, int32_t taps, int32_t K, int32_t Ncols, int32_t n_inner,
+                        float* dw, int64_t d_t, int64_t d_k, int64_t d_n, int64_t d_o, float* db, void* stream);
+
+/* dst[t*d_t + k*d_k + n*d_n] = src[tt*s_t + k*s_k + n*s_n], tt = flip ? T-1-t : t.
+ * Re-lays a torch-layout weight ([co,ci,3,3] / [ci,co,2,2], the state-dict contract of
+ * models/unet.py) into the packed [taps][K][Ncols] operand of the GEMM. */
+int unetpp_pack_weight(float* dst, const float* src, int32_t T, int32_t K, int32_t Ncols,
+                       int64_t d_t, int64_t d_k, int64_t d_n, int64_t s_t, int64_t s_k, int64_t s_n,
+                       int32_t flip, void* stream);
+
+/* ---- BatchNorm2d, training mode (models/unet.py:133) -------------------------------------- */
+/* partial [n_blocks][C][2] (sum, sumsq) -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale;
+ * running_mean/var updated with `momentum` (unbiased variance), all [C]. count = N*H*W. */
+int unetpp_bn_finalize(const float* partial, int64_t n_blocks, int32_t C, int64_t count,
+                       const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var,
+                       float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* eval mode: scale/shift from running statistics */
+int unetpp_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                          const float* running_var, float eps, int32_t C, float* scale, float* shift,
+                          void* stream);
+/* act = relu?(y*scale + shift) (scale may be NULL = identity);  optional fused nn.MaxPool2d(2)
+ * (models/unet.py:219): pooled [N,H/2,W/2,C] and pool_idx (uint8 window index 0..3, first max wins).
+ * act may be NULL when only the pooled output is wanted. */
+int unetpp_affine_relu_pool(const float* y, const float* scale, const float* shift, int32_t relu,
+                            int32_t N, int32_t H, int32_t W, int32_t C,
+                            float* act, float* pooled, uint8_t* pool_idx, void* stream);
+/* d_act[window argmax] += d_pooled */
+int unetpp_maxpool_bwd(const float* d_pooled, const uint8_t* pool_idx, int32_t N, int32_t H, int32_t W,
+                       int32_t C, float* d_act, void* stream);
+int64_t unetpp_bn_bwd_blocks(int64_t pixels, int32_t C);
+/* g = d_act * (y*scale+shift > 0); partial [blocks][C][2] = (sum g, sum g*xhat) */
+int unetpp_bn_bwd_reduce(const float* d_act, const float* y, const float* scale, const float* shift,
+                         const float* mean, const float* invstd, int64_t pixels, int32_t C,
+                         float* partial, void* stream);
+/* sums the partials -> dgamma, dbeta; then dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M) (dy may alias d_act) */
+int unetpp_bn_bwd_finalize(const float* partial, int64_t n_blocks, int32_t C, float* dgamma, float* dbeta,
+                           void* stream);
+int unetpp_bn_bwd_apply(const float* d_act, const float* y, const float* scale, const float* shift,
+                        const float* mean, const float* invstd, const float* gamma,
+                        const float* dgamma, const float* dbeta, int64_t pixels, int32_t C,
+                        float* dy, void* stream);
+
+/* ---- deep-supervision head: sigmoid(Conv1x1(Dropout(x))) (models/unet.py:242-244,254,283-286) ---- */
+/* x NHWC [P, C]; weight [n_cls, C]; out NCHW [N, n_cls, H, W].  Dropout: keep mask regenerated from
+ * (seed, element index) with keep probability 1-p_drop, or read from `mask` (uint8 NHWC) when not NULL;
+ * p_drop = 0 disables it. */
+int unetpp_head_fwd(const float* x, const float* weight, const float* bias, int32_t N, int32_t H, int32_t W,
+                    int32_t C, int32_t n_cls, float p_drop, uint64_t seed, const uint8_t* mask,
+                    float* out_nchw, void* stream);
+int64_t unetpp_head_bwd_blocks(int64_t pixels);
+/* d_out, out: NCHW.  dx (NHWC) is written (accumulate = 0) or added to; partial [blocks][n_cls*C + n_cls]. */
+int unetpp_head_bwd(const float* d_out_nchw, const float* out_nchw, const float* x, const float* weight,
+                    int32_t N, int32_t H, int32_t W, int32_t C, int32_t n_cls, float p_drop, uint64_t seed,
+                    const uint8_t* mask, float* dx, int32_t accumulate, float* partial, void* stream);
+/* out[i] = sum_b partial[b][i], i < len (used for head dW/db) */
+int unetpp_sum_partials(const float* partial, int64_t n_blocks, int64_t len, float* out, void* stream);
+
+/* ---- bilinear x2, align_corners=True (nn.UpsamplingBilinear2d, models/unet.py:190) ---------- */
+int unetpp_bilinear2x_fwd(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* y, void* stream);
+int unetpp_bilinear2x_bwd(const float* dy, int32_t N, int32_t H, int32_t W, int32_t C, float* dx, int32_t accumulate,
+                          void* stream);
+
+/* ---- layout converters at the network edge ------------------------------------------------ */
+int unetpp_nchw_to_nhwc(const float* src, int32_t N, int32_t C, int32_t H, int32_t W, float* dst, void* stream);
+int unetpp_nhwc_to_nchw(const float* src, int32_t N, int32_t C, int32_t H, int32_t W, float* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNETPP_HIP_H */

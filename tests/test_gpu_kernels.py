@@ -1,0 +1,269 @@
+"""Kernel-level parity: each C-ABI entry point against a CPU fp32/fp64 PyTorch statement of the same op.
+
+GPU only (pytest -m gpu).  Tolerance: 1e-4 relative to the largest reference magnitude (north_star),
+most ops land at ~1e-6.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def nhwc(t):  # NCHW cpu -> NHWC gpu
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):  # NHWC gpu -> NCHW cpu
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+@pytest.mark.parametrize("shape", [
+    # (B, H, W, [cin per source], cout)
+    (2, 16, 16, [8], 8),
+    (1, 24, 40, [3], 4),          # rgb first layer, ragged tiles
+    (2, 32, 32, [32], 32),
+    (1, 64, 64, [32, 32, 32, 32], 32),   # X_03.conv1-like virtual concat
+    (2, 8, 8, [16, 8, 8], 40),    # odd column tile
+    (1, 4, 4, [5, 3], 7),         # scalar-load path, tile much larger than the image
+    (1, 16, 48, [1], 33),
+])
+def test_conv3x3_fwd_multiview(dev, shape):
+    from unet_nested4tiny_objects_keypoints_amd import engine, ops
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    b, h, w, cins, co = shape
+    g = torch.Generator().manual_seed(1)
+    srcs = [torch.randn(b, c, h, w, generator=g) for c in cins]
+    wt = torch.randn(co, sum(cins), 3, 3, generator=g) * 0.2
+    bias = torch.randn(co, generator=g)
+    ref = F.conv2d(torch.cat(srcs, 1).double(), wt.double(), bias.double(), padding=1).float()
+    out = torch.full((b, h, w, co), float("nan"), device=dev)
+    ops.gemm_fwd(b, h, w, 9, [V(nhwc(s)) for s in srcs], [V(out)], engine.pack_conv_fwd(wt.cuda()), bias.cuda())
+    assert rel_err(nchw(out), ref) < TOL
+    # ReLU epilogue + BN partial sums
+    out2 = torch.empty_like(out)
+    blocks = ops.gemm_pixel_blocks(b, h, w)
+    part = torch.empty(blocks * co * 2, device=dev)
+    ops.gemm_fwd(b, h, w, 9, [V(nhwc(s)) for s in srcs], [V(out2)], engine.pack_conv_fwd(wt.cuda()), bias.cuda(), part)
+    sums = part.view(blocks, co, 2).double().sum(0).cpu()
+    assert rel_err(sums[:, 0], ref.double().sum((0, 2, 3))) < TOL * 10  # plain sums cancel; looser
+    assert rel_err(sums[:, 1], (ref.double() ** 2).sum((0, 2, 3))) < TOL
+
+
+def test_conv3x3_load_transform_and_slices(dev):
+    """affine + ReLU applied on load (zero padding AFTER the transform), channel-sliced views, store gate/accumulate."""
+    from unet_nested4tiny_objects_keypoints_amd import engine, ops
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    b, h, w = 2, 16, 16
+    g = torch.Generator().manual_seed(2)
+    big = torch.randn(b, 24, h, w, generator=g)          # use channels 8..20
+    scale, shift = torch.randn(12, generator=g), torch.randn(12, generator=g)
+    wt = torch.randn(16, 12, 3, 3, generator=g) * 0.2
+    xin = F.relu(big[:, 8:20] * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    ref = F.conv2d(xin.double(), wt.double(), None, padding=1).float()
+    gate = torch.randn(b, 16, h, w, generator=g)
+    prev = torch.randn(b, 16, h, w, generator=g)
+    expect = prev + ref * (gate > 0)
+    out = nhwc(prev)
+    ops.gemm_fwd(b, h, w, 9, [V(nhwc(big), c_off=8, c_len=12, scale=scale.cuda(), shift=shift.cuda(), relu=True)],
+                 [V(out, gate=nhwc(gate), accumulate=True)], engine.pack_conv_fwd(wt.cuda()))
+    assert rel_err(nchw(out), expect) < TOL
+
+
+def test_conv3x3_dgrad_matches_autograd(dev):
+    from unet_nested4tiny_objects_keypoints_amd import engine, ops
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    b, h, w, ci, co = 2, 16, 24, 20, 12
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(b, ci, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    wt = torch.randn(co, ci, 3, 3, generator=g, dtype=torch.float64)
+    dy = torch.randn(b, co, h, w, generator=g, dtype=torch.float64)
+    F.conv2d(x, wt, None, padding=1).backward(dy)
+    # split the input gradient over two destination tensors (virtual concat backward)
+    d0 = torch.empty(b, h, w, 8, device=dev)
+    d1 = torch.empty(b, h, w, 12, device=dev)
+    ops.gemm_fwd(b, h, w, 9, [V(nhwc(dy.float()))], [V(d0), V(d1)], engine.pack_conv_dgrad(wt.float().cuda()))
+    got = torch.cat([nchw(d0), nchw(d1)], 1)
+    assert rel_err(got, x.grad.float()) < TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 16, 8), (1, 16, 32, 64, 32), (1, 4, 4, 6, 5)])
+def test_deconv2x2_fwd_dgrad_wgrad(dev, shape):
+    from unet_nested4tiny_objects_keypoints_amd import engine, ops
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    b, h, w, ci, co = shape
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(b, ci, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    wt = torch.randn(ci, co, 2, 2, generator=g, dtype=torch.float64, requires_grad=True)
+    bias = torch.randn(co, generator=g, dtype=torch.float64, requires_grad=True)
+    y = F.conv_transpose2d(x, wt, bias, stride=2)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    xg, wg, bg = nhwc(x.detach().float()), wt.detach().float().cuda(), bias.detach().float().cuda()
+    up = torch.full((b, 2 * h, 2 * w, co), float("nan"), device=dev)
+    ops.gemm_fwd(b, h, w, 1, [V(xg)], engine._phase_views(up), engine.pack_deconv_fwd(wg), engine.tile_bias4(bg))
+    assert rel_err(nchw(up), y.detach().float()) < TOL
+    d_up = nhwc(dy.float())
+    dx = torch.empty_like(xg)
+    ops.gemm_fwd(b, h, w, 1, engine._phase_views(d_up), [V(dx)], engine.pack_deconv_dgrad(wg))
+    assert rel_err(nchw(dx), x.grad.float()) < TOL
+    dw, db = torch.empty_like(wg), torch.empty_like(bg)
+    ops.wgrad(b, h, w, 1, [V(xg)], engine._phase_views(d_up), dw, (0, 4 * co, 4, 1), db, n_inner=co)
+    assert rel_err(dw.cpu(), wt.grad.float()) < TOL
+    assert rel_err(db.cpu(), bias.grad.float()) < TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16, [8], 8), (1, 32, 32, [32, 32, 32], 32), (2, 24, 40, [3], 4),
+                                   (1, 8, 8, [40, 5], 33), (3, 64, 64, [16], 16)])
+def test_conv3x3_wgrad(dev, shape):
+    from unet_nested4tiny_objects_keypoints_amd import ops
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    b, h, w, cins, co = shape
+    g = torch.Generator().manual_seed(5)
+    srcs = [torch.randn(b, c, h, w, generator=g, dtype=torch.float64) for c in cins]
+    wt = torch.randn(co, sum(cins), 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(co, dtype=torch.float64, requires_grad=True)
+    act = torch.randn(b, co, h, w, generator=g, dtype=torch.float64)  # ReLU gate
+    dy = torch.randn(b, co, h, w, generator=g, dtype=torch.float64)
+    F.conv2d(torch.cat(srcs, 1), wt, bias, padding=1).backward(dy * (act > 0))
+    dw = torch.empty(co, sum(cins), 3, 3, device=dev)
+    db = torch.empty(co, device=dev)
+    ci = sum(cins)
+    for target_blocks in (1024, 3):  # many slabs / few slabs with a long per-block pixel loop
+        ops.wgrad(b, h, w, 9, [V(nhwc(s.float())) for s in srcs], [V(nhwc(dy.float()), gate=nhwc(act.float()))],
+                  dw, (1, 9, ci * 9, 0), db, target_blocks=target_blocks)
+        assert rel_err(dw.cpu(), wt.grad.float()) < TOL
+        assert rel_err(db.cpu(), bias.grad.float()) < TOL
+
+
+@pytest.mark.parametrize("c", [32, 8, 3])
+def test_batchnorm_relu_pool_fwd_bwd(dev, c):
+    from unet_nested4tiny_objects_keypoints_amd import ops
+    b, h, w = 3, 16, 24
+    g = torch.Generator().manual_seed(6)
+    y = (torch.randn(b, c, h, w, generator=g, dtype=torch.float64) * 2 + 0.5).requires_grad_(True)
+    gamma = (1 + 0.1 * torch.randn(c, generator=g, dtype=torch.float64)).requires_grad_(True)
+    beta = (0.1 * torch.randn(c, generator=g, dtype=torch.float64)).requires_grad_(True)
+    rm, rv = torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64)
+    act = F.relu(F.batch_norm(y, rm, rv, gamma, beta, True, 0.1, 1e-5))
+    pooled, idx = F.max_pool2d(act, 2, return_indices=True)
+    d_act = torch.randn(act.shape, generator=g, dtype=torch.float64)
+    d_pool = torch.randn(pooled.shape, generator=g, dtype=torch.float64)
+    (act * d_act).sum().backward(retain_graph=True)
+    gy_act, gg, gb = y.grad.clone(), gamma.grad.clone(), beta.grad.clone()
+    y.grad = None
+    (pooled * d_pool).sum().backward()
+    gy_pool = y.grad.clone()  # includes BN backward of the pooled path; used via d_act accumulation below
+
+    yg = nhwc(y.detach().float())
+    # statistics come from the conv epilogue in the product; here: per-"block" sums computed on the host
+    part = torch.stack([yg.view(-1, c).sum(0), (yg.view(-1, c) ** 2).sum(0)], 1).reshape(1, c, 2).contiguous()
+    rmg, rvg = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    mean, invstd, scale, shift = ops.bn_finalize(part.view(-1), 1, c, b * h * w, gamma.detach().float().cuda(),
+                                                 beta.detach().float().cuda(), 1e-5, 0.1, rmg, rvg)
+    assert rel_err(rmg.cpu(), rm.float()) < TOL and rel_err(rvg.cpu(), rv.float()) < TOL
+    act_g = torch.empty_like(yg)
+    pooled_g = torch.empty(b, h // 2, w // 2, c, device=dev)
+    idx_g = torch.empty(b, h // 2, w // 2, c, dtype=torch.uint8, device=dev)
+    ops.affine_relu_pool(yg, scale, shift, True, act_g, pooled_g, idx_g)
+    assert rel_err(nchw(act_g), act.detach().float()) < TOL
+    assert rel_err(nchw(pooled_g), pooled.detach().float()) < TOL
+    # backward: d_act (+ pool gradient routed to the argmax) -> BN backward
+    dact_g = nhwc(d_act.float())
+    dy_g = torch.empty_like(dact_g)
+    dgam, dbet = ops.bn_backward(dact_g, yg, scale, shift, mean, invstd, gamma.detach().float().cuda(), dy_g)
+    assert rel_err(nchw(dy_g), gy_act.float()) < TOL
+    assert rel_err(dgam.cpu(), gg.float()) < TOL and rel_err(dbet.cpu(), gb.float()) < TOL
+    acc = torch.zeros_like(dact_g)
+    ops.maxpool_bwd(nhwc(d_pool.float()), idx_g, acc)
+    ops.bn_backward(acc, yg, scale, shift, mean, invstd, gamma.detach().float().cuda(), acc)
+    assert rel_err(nchw(acc), gy_pool.float()) < TOL
+
+
+@pytest.mark.parametrize("c,ncls", [(32, 4), (8, 5), (6, 3)])
+def test_head_fwd_bwd_with_mask(dev, c, ncls):
+    from unet_nested4tiny_objects_keypoints_amd import ops
+    b, h, w = 2, 16, 24
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(b, c, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    wt = (torch.randn(ncls, c, 1, 1, generator=g, dtype=torch.float64) * 0.3).requires_grad_(True)
+    bias = torch.randn(ncls, generator=g, dtype=torch.float64, requires_grad=True)
+    keep = (torch.rand(b, c, h, w, generator=g) < 0.6)
+    for use_mask in (False, True):
+        for t in (x, wt, bias):
+            t.grad = None
+        xin = x * keep.double() / 0.6 if use_mask else x
+        out = torch.sigmoid(F.conv2d(xin, wt, bias))
+        d_out = torch.randn(out.shape, generator=g, dtype=torch.float64)
+        out.backward(d_out)
+        xg = nhwc(x.detach().float())
+        mask = keep.permute(0, 2, 3, 1).contiguous().to(torch.uint8).cuda() if use_mask else None
+        p = 0.4 if use_mask else 0.0
+        o = torch.empty(b, ncls, h, w, device=dev)
+        wv = wt.detach().float().cuda().view(ncls, c)
+        ops.head_fwd(xg, wv, bias.detach().float().cuda(), p, 0, mask, o)
+        assert rel_err(o.cpu(), out.detach().float()) < TOL
+        dx = torch.empty_like(xg)
+        dw, db = ops.head_bwd(d_out.float().cuda(), o, xg, wv, p, 0, mask, dx, False)
+        assert rel_err(nchw(dx), x.grad.float()) < TOL
+        assert rel_err(dw.cpu(), wt.grad.float()) < TOL
+        assert rel_err(db.cpu(), bias.grad.float()) < TOL
+
+
+def test_head_dropout_generator_is_consistent(dev):
+    """In-kernel dropout: keep rate ~ 1-p, identical mask in forward and backward, seed-dependent."""
+    from unet_nested4tiny_objects_keypoints_amd import ops
+    b, h, w, c, ncls = 2, 64, 64, 32, 4
+    x = torch.ones(b, h, w, c, device=dev)
+    wt = torch.zeros(ncls, c, device=dev)
+    wt[0] = 1.0 / c
+    bias = torch.zeros(ncls, device=dev)
+    o = torch.empty(b, ncls, h, w, device=dev)
+    ops.head_fwd(x, wt, bias, 0.4, 1234, None, o)
+    logit = torch.log(o[:, 0] / (1 - o[:, 0]))        # = kept fraction / 0.6
+    keep_rate = float(logit.mean()) * 0.6
+    assert abs(keep_rate - 0.6) < 0.01
+    # backward regenerates the same mask: dx is nonzero exactly where the element was kept
+    d_out = torch.ones_like(o)
+    dx = torch.empty_like(x)
+    ops.head_bwd(d_out, o, x, wt, 0.4, 1234, None, dx, False)
+    kept_per_pixel = (dx != 0).sum(-1).float()
+    assert torch.allclose(kept_per_pixel / c / 0.6, logit, atol=1e-4)
+    o2 = torch.empty_like(o)
+    ops.head_fwd(x, wt, bias, 0.4, 99, None, o2)
+    assert not torch.equal(o, o2)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 8, 6), (1, 5, 7, 4), (1, 1, 1, 3)])
+def test_bilinear2x_align_corners(dev, shape):
+    from unet_nested4tiny_objects_keypoints_amd import ops
+    b, h, w, c = shape
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(b, c, h, w, generator=g, dtype=torch.float64, requires_grad=True)
+    y = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    yg = torch.empty(b, 2 * h, 2 * w, c, device=dev)
+    ops.bilinear2x_fwd(nhwc(x.detach().float()), yg)
+    assert rel_err(nchw(yg), y.detach().float()) < TOL
+    dx = torch.ones(b, h, w, c, device=dev)
+    ops.bilinear2x_bwd(nhwc(dy.float()), dx, True)
+    assert rel_err(nchw(dx) - 1.0, x.grad.float()) < TOL
+
+
+def test_layout_converters(dev):
+    from unet_nested4tiny_objects_keypoints_amd import ops
+    x = torch.randn(2, 3, 8, 12)
+    assert torch.equal(ops.nchw_to_nhwc(x.cuda()).cpu(), x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(ops.nhwc_to_nchw(x.permute(0, 2, 3, 1).contiguous().cuda()).cpu(), x)

@@ -1,0 +1,240 @@
+"""Whole-path parity of the HIP UNet_Nested (through the C ABI) against
+  (1) the committed golden fixtures produced by the reference itself, and
+  (2) the CPU oracle (oracle/, proven == reference by tests/test_oracle_golden.py) on fresh seeded inputs,
+      including the generalised depths and BASELINE.json's config shapes at reduced batch.
+
+GPU only (pytest -m gpu).  Bar: <= 1e-4 relative fp32 (north_star).
+"""
+import pytest
+import torch
+
+from tests.helpers import GOLDEN_CASES, assert_grads_close, is_pre_bn_bias, load_golden, rel_err, sub
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _hip_model(ctor, state, dev):
+    from unet_nested4tiny_objects_keypoints_amd import UNet_Nested
+    m = UNet_Nested(**ctor)
+    m.load_state_dict(state, strict=True)
+    return m.to(dev)
+
+
+def _loss(outs, target):
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d
+    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+    return sum(crit(o, target) for o in outs) / len(outs)
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_golden_eval_forward(dev, name):
+    z, ctor = load_golden(name)
+    m = _hip_model(ctor, sub(z, "state0"), dev).eval()
+    with torch.no_grad():
+        outs = m(torch.from_numpy(z["x"]).to(dev))
+    assert isinstance(outs, tuple) and len(outs) == 3
+    for i, o in enumerate(outs):
+        assert o.shape == z["eval_out/%d" % i].shape
+        assert rel_err(o.cpu(), z["eval_out/%d" % i]) < TOL
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_golden_train_step(dev, name):
+    """train mode, dropout disabled: outputs, loss, every parameter gradient, BN running stats."""
+    z, ctor = load_golden(name)
+    m = _hip_model(ctor, sub(z, "state0"), dev).train()
+    m.drop_out.eval()
+    x, target = torch.from_numpy(z["x"]).to(dev), torch.from_numpy(z["target"]).to(dev)
+    outs = m(x)
+    loss = _loss(outs, target)
+    loss.backward()
+    for i, o in enumerate(outs):
+        assert rel_err(o.detach().cpu(), z["train_out/%d" % i]) < TOL
+    assert abs(float(loss) - float(z["loss"])) <= TOL * abs(float(z["loss"]))
+    assert_grads_close({k: p.grad.cpu() for k, p in m.named_parameters()}, sub(z, "grad"), ctor, TOL)
+    bufs = sub(z, "state1_buffers")
+    for k, b in m.named_buffers():
+        if b.dtype.is_floating_point:
+            assert rel_err(b.cpu(), bufs[k]) < TOL, k
+        else:
+            assert int(b) == int(bufs[k]), k
+
+
+@pytest.mark.parametrize("opt_name", ["adam", "sgd"])
+def test_golden_optimizer_step(dev, opt_name):
+    """the reference's step body (trainer/trainer.py:114-136) end to end: parameters after one update."""
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, train_step
+    z, ctor = load_golden("c1_fs4_64x64_b4_seed0")
+    m = _hip_model(ctor, sub(z, "state0"), dev).train()
+    m.drop_out.eval()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3) if opt_name == "adam" else \
+        torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
+    train_step(m, opt, FocalLoss_BCE_2d(gamma=3, size_average=False),
+               torch.from_numpy(z["x"]).to(dev), torch.from_numpy(z["target"]).to(dev))
+    after = sub(z, "after_" + opt_name)
+    worst = 0.0
+    for k, p in m.named_parameters():
+        if opt_name == "adam" and is_pre_bn_bias(k, ctor):
+            continue  # zero-gradient parameter: Adam amplifies the sign of rounding noise to +-lr
+        worst = max(worst, float((p.detach().cpu() - after[k]).abs().max()))
+    # Adam's first step is lr*sign-like: elements whose gradient is ~0 can flip; bound by a fraction of lr
+    assert worst < (2.5e-4 if opt_name == "adam" else 2e-5)
+
+
+ORACLE_CASES = [
+    # (ctor kwargs, batch, H, W)
+    (dict(in_channels=1, n_classes=4, feature_scale=4, depth=2), 4, 64, 64),      # configs[0] "depth=2, 1->8ch"
+    (dict(in_channels=1, n_classes=4, feature_scale=8, depth=3), 2, 32, 48),
+    (dict(in_channels=3, n_classes=5, feature_scale=8, depth=5), 1, 32, 32),      # configs[4] topology, tiny widths
+    (dict(in_channels=1, n_classes=4, feature_scale=8, depth=5, is_deconv=False), 1, 32, 32),
+    (dict(in_channels=1, n_classes=4, feature_scale=1), 2, 64, 64),               # configs[1] widths (base 32)
+    (dict(in_channels=1, n_classes=4, feature_scale=2, is_batchnorm=False), 1, 32, 32),
+]
+
+
+@pytest.mark.parametrize("case", ORACLE_CASES, ids=lambda c: "-".join("%s" % v for v in c[0].values()))
+def test_train_step_vs_oracle(dev, case):
+    from oracle.step_oracle import focal_bce_2d_oracle
+    from oracle.unet_nested_oracle import UNetNestedOracle
+    ctor, b, h, w = case
+    torch.manual_seed(11)
+    ref = UNetNestedOracle(**ctor).train()
+    ref.drop_out.eval()
+    m = _hip_model(ctor, ref.state_dict(), dev).train()
+    m.drop_out.eval()
+    x = torch.randn(b, ctor["in_channels"], h, w)
+    target = torch.rand(b, ctor["n_classes"], h, w)
+    ro = ref(x)
+    rl = sum(focal_bce_2d_oracle(o, target) for o in ro) / len(ro)
+    rl.backward()
+    outs = m(x.to(dev))
+    loss = _loss(outs, target.to(dev))
+    loss.backward()
+    assert len(outs) == len(ro)
+    for o, r in zip(outs, ro):
+        assert rel_err(o.detach().cpu(), r.detach()) < TOL
+    assert abs(float(loss) - float(rl)) <= TOL * abs(float(rl))
+    assert_grads_close({k: p.grad.cpu() for k, p in m.named_parameters()},
+                       {k: p.grad for k, p in ref.named_parameters()}, ctor, TOL)
+    for (k, bh), (_, br) in zip(m.named_buffers(), ref.named_buffers()):
+        if bh.dtype.is_floating_point:
+            assert rel_err(bh.cpu(), br) < TOL, k
+
+
+def test_dropout_path_vs_oracle_with_shared_mask(dev):
+    """Train-mode dropout (models/unet.py:254,283-286) with an explicit keep mask on both sides."""
+    from oracle.step_oracle import focal_bce_2d_oracle
+    from oracle.unet_nested_oracle import UNetNestedOracle
+    ctor = dict(in_channels=1, n_classes=4, feature_scale=8)
+    torch.manual_seed(12)
+    ref = UNetNestedOracle(**ctor).train()
+    m = _hip_model(ctor, ref.state_dict(), dev).train()
+    b, h, w, f0 = 2, 32, 32, 4
+    masks = [(torch.rand(b, f0, h, w) < 0.6) for _ in range(3)]
+
+    class SharedMask(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.i = 0
+
+        def forward(self, t):
+            k = masks[self.i]
+            self.i += 1
+            return t * k.float() / 0.6
+
+    ref.drop_out = SharedMask()
+    m.dropout_masks = [k.permute(0, 2, 3, 1).contiguous().to(torch.uint8).to(dev) for k in masks]
+    x, target = torch.randn(b, 1, h, w), torch.rand(b, 4, h, w)
+    ro = ref(x)
+    rl = sum(focal_bce_2d_oracle(o, target) for o in ro) / 3
+    rl.backward()
+    outs = m(x.to(dev))
+    loss = _loss(outs, target.to(dev))
+    loss.backward()
+    for o, r in zip(outs, ro):
+        assert rel_err(o.detach().cpu(), r.detach()) < TOL
+    assert_grads_close({k: p.grad.cpu() for k, p in m.named_parameters()},
+                       {k: p.grad for k, p in ref.named_parameters()}, ctor, TOL)
+
+
+def test_dropout_generator_statistics_and_determinism(dev):
+    from unet_nested4tiny_objects_keypoints_amd import UNet_Nested
+    torch.manual_seed(3)
+    m = UNet_Nested(in_channels=1, n_classes=4, feature_scale=8).to(dev).train()
+    x = torch.randn(2, 1, 32, 32, device=dev)
+    torch.manual_seed(5)
+    a = m(x)
+    torch.manual_seed(5)
+    b = m(x)
+    c = m(x)
+    assert all(torch.equal(p, q) for p, q in zip(a, b))       # same torch seed -> same masks
+    assert not all(torch.equal(p, q) for p, q in zip(a, c))   # fresh draw -> different masks
+
+
+def test_input_gradient_and_module_protocol(dev):
+    from oracle.unet_nested_oracle import UNetNestedOracle
+    from unet_nested4tiny_objects_keypoints_amd import UNet_Nested
+    ctor = dict(in_channels=3, n_classes=4, feature_scale=8)
+    torch.manual_seed(13)
+    ref = UNetNestedOracle(**ctor).train()
+    ref.drop_out.eval()
+    m = _hip_model(ctor, ref.state_dict(), dev).train()
+    m.drop_out.eval()
+    x = torch.randn(2, 3, 16, 24)
+    xr = x.clone().requires_grad_(True)
+    xg = x.to(dev).requires_grad_(True)
+    sum(o.square().sum() for o in ref(xr)).backward()
+    sum(o.square().sum() for o in m(xg)).backward()
+    assert rel_err(xg.grad.cpu(), xr.grad) < TOL
+    # state_dict round trip through the reference's key names; DataParallel-style .module wrapping
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    ref2 = UNetNestedOracle(**ctor)
+    ref2.load_state_dict(sd, strict=True)
+    wrapped = torch.nn.DataParallel(m, device_ids=[0])
+    assert hasattr(wrapped, "module") and list(wrapped.module.state_dict().keys()) == list(sd.keys())
+    # error behaviour: H/W not divisible by 8 raise (the reference fails inside torch.cat)
+    with pytest.raises(ValueError):
+        m(torch.randn(1, 3, 20, 24, device=dev))
+    with pytest.raises(RuntimeError):
+        m(torch.randn(1, 3, 16, 16))  # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        UNet_Nested(depth=7)
+
+
+def test_large_shape_properties(dev):
+    """BASELINE configs[1] shape (base 32, 256x256) at batch 8: size-independent properties.
+    (a) eval forward of a batch equals the concatenation of per-image forwards (images are independent);
+    (b) linearity of the weight gradient in the upstream gradient; (c) outputs in (0,1), finite grads."""
+    from unet_nested4tiny_objects_keypoints_amd import UNet_Nested
+    torch.manual_seed(14)
+    m = UNet_Nested(in_channels=1, n_classes=4, feature_scale=1).to(dev)
+    x = torch.randn(8, 1, 256, 256, device=dev)
+    m.eval()
+    with torch.no_grad():
+        full = m(x)
+        parts = [m(x[i:i + 2]) for i in range(0, 8, 2)]
+    for h in range(3):
+        assert torch.equal(full[h], torch.cat([p[h] for p in parts], 0))
+        assert float(full[h].min()) >= 0.0 and float(full[h].max()) <= 1.0
+    m.train()
+    m.drop_out.eval()
+
+    def grads(scale):
+        m.zero_grad()
+        outs = m(x)
+        (scale * sum(o.sum() for o in outs)).backward()
+        return [p.grad.clone() for p in m.parameters()]
+
+    g1, g2 = grads(1.0), grads(2.0)
+    for a, b in zip(g1, g2):
+        assert torch.isfinite(a).all()
+        assert rel_err(b, 2 * a) < 1e-5

@@ -1,0 +1,127 @@
+"""Loader for the C-ABI HIP library (include/unetpp_hip.h) -- ctypes, no torch types cross the ABI.
+
+The library is built in-tree by ``build_library()`` (hipcc --offload-arch=gfx950) as
+``unet_nested4tiny_objects_keypoints_amd/libunetpp_hip.so``.  There is no CPU fallback: if the
+shared object is missing or does not load, ``lib()`` raises and every op of the package fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(_PKG_DIR)
+LIB_PATH = os.path.join(_PKG_DIR, "libunetpp_hip.so")
+CSRC = os.path.join(_PKG_DIR, "csrc")
+INCLUDE = os.path.join(_REPO, "include")
+SOURCES = ("gemm_pix.hip", "wgrad.hip", "pointwise.hip")
+MAX_VIEWS = 8
+
+
+class View(C.Structure):
+    """mirror of struct unetpp_view"""
+    _fields_ = [
+        ("ptr", C.c_void_p),
+        ("C", C.c_int32), ("c_off", C.c_int32), ("c_len", C.c_int32),
+        ("Hs", C.c_int32), ("Ws", C.c_int32),
+        ("sy", C.c_int32), ("sx", C.c_int32), ("oy", C.c_int32), ("ox", C.c_int32),
+        ("scale", C.c_void_p), ("shift", C.c_void_p), ("gate", C.c_void_p),
+        ("relu", C.c_int32), ("accumulate", C.c_int32),
+    ]
+
+
+class GemmDesc(C.Structure):
+    """mirror of struct unetpp_gemm_desc"""
+    _fields_ = [
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("taps", C.c_int32), ("n_in", C.c_int32), ("n_out", C.c_int32),
+        ("inp", View * MAX_VIEWS), ("out", View * MAX_VIEWS),
+        ("weight", C.c_void_p), ("bias", C.c_void_p), ("stats_partial", C.c_void_p),
+    ]
+
+
+class WgradDesc(C.Structure):
+    """mirror of struct unetpp_wgrad_desc"""
+    _fields_ = [
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("taps", C.c_int32), ("n_x", C.c_int32), ("n_dy", C.c_int32),
+        ("x", View * MAX_VIEWS), ("dy", View * MAX_VIEWS),
+        ("n_split", C.c_int32),
+        ("slabs", C.c_void_p),
+    ]
+
+
+_P, _I32, _I64, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
+
+# name -> (restype, argtypes); kept in step with include/unetpp_hip.h (tests/test_abi.py checks it)
+SIGNATURES = {
+    "unetpp_abi_version": (C.c_int, []),
+    "unetpp_build_arch": (C.c_char_p, []),
+    "unetpp_gemm_pixel_blocks": (_I64, [_I32, _I32, _I32]),
+    "unetpp_gemm_fwd": (C.c_int, [C.POINTER(GemmDesc), _P]),
+    "unetpp_wgrad_max_split": (_I32, [_I32, _I32, _I32]),
+    "unetpp_wgrad": (C.c_int, [C.POINTER(WgradDesc), _P]),
+    "unetpp_wgrad_finish": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _I64, _I64, _I64, _I64, _P, _P]),
+    "unetpp_pack_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _P]),
+    "unetpp_bn_finalize": (C.c_int, [_P, _I64, _I32, _I64, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "unetpp_bn_eval_coeffs": (C.c_int, [_P, _P, _P, _P, _F, _I32, _P, _P, _P]),
+    "unetpp_affine_relu_pool": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "unetpp_maxpool_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P]),
+    "unetpp_bn_bwd_blocks": (_I64, [_I64, _I32]),
+    "unetpp_bn_bwd_reduce": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P]),
+    "unetpp_bn_bwd_finalize": (C.c_int, [_P, _I64, _I32, _P, _P, _P]),
+    "unetpp_bn_bwd_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P]),
+    "unetpp_head_fwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _P]),
+    "unetpp_head_bwd_blocks": (_I64, [_I64]),
+    "unetpp_head_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _I32, _P, _P]),
+    "unetpp_sum_partials": (C.c_int, [_P, _I64, _I64, _P, _P]),
+    "unetpp_bilinear2x_fwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P]),
+    "unetpp_bilinear2x_bwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _I32, _P]),
+    "unetpp_nchw_to_nhwc": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P]),
+    "unetpp_nhwc_to_nchw": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P]),
+}
+
+_LIB = None
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into the in-tree shared object (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "unetpp_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC,
+           "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    global _LIB
+    _LIB = None
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library with argtypes set.  Raises if the HIP library is not built -- by design."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "unetpp HIP library not built: %s is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for this path)." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if handle.unetpp_abi_version() != 1:
+            raise RuntimeError("unetpp HIP library ABI mismatch")
+        _LIB = handle
+    return _LIB
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise RuntimeError("%s failed with status %d (%s)" % (
+            what, status, {-1: "invalid argument", -2: "kernel launch error"}.get(status, "unknown")))

@@ -1,0 +1,88 @@
+// Shared device/host helpers for the gfx950 UNet_Nested kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "unetpp_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace unetpp {
+
+// Pixel tile of the MFMA kernels: 256 logical pixels per workgroup, laid out TH x TW with
+// TW a power of two in {8, 16, 32}; 4 waves, each owning 64 of those pixels.
+constexpr int kBlockPixels = 256;
+constexpr int kThreads = 256;
+constexpr int kMaxHaloPixels = 340;  // max over TW in {8,16,32} of (TH+2)*(TW+2)
+
+struct TileGeom {
+  int log2tw, tiles_x, tiles_y;
+};
+
+inline TileGeom tile_geom(int H, int W) {
+  int l = 3;
+  while ((1 << l) < W && l < 5) ++l;
+  TileGeom g;
+  g.log2tw = l;
+  const int TW = 1 << l, TH = kBlockPixels >> l;
+  g.tiles_x = (W + TW - 1) / TW;
+  g.tiles_y = (H + TH - 1) / TH;
+  return g;
+}
+
+inline bool view_ok(const unetpp_view& v, bool need_ptr = true) {
+  if (need_ptr && v.ptr == nullptr) return false;
+  if (v.C <= 0 || v.c_len <= 0 || v.c_off < 0 || v.c_off + v.c_len > v.C) return false;
+  if (v.Hs <= 0 || v.Ws <= 0 || v.sy <= 0 || v.sx <= 0 || v.oy < 0 || v.ox < 0) return false;
+  if ((v.scale == nullptr) != (v.shift == nullptr)) return false;
+  return true;
+}
+
+// every logical pixel of an H x W grid must land inside the view's tensor
+inline bool view_covers(const unetpp_view& v, int H, int W) {
+  return (H - 1) * v.sy + v.oy < v.Hs && (W - 1) * v.sx + v.ox < v.Ws;
+}
+
+__device__ __forceinline__ bool view_vec4(const unetpp_view& v) {
+  return ((v.C | v.c_off) & 3) == 0 && ((reinterpret_cast<uintptr_t>(v.ptr) & 15) == 0) &&
+         (v.gate == nullptr || (reinterpret_cast<uintptr_t>(v.gate) & 15) == 0);
+}
+
+__device__ __forceinline__ long view_pixel_offset(const unetpp_view& v, int n, int y, int x) {
+  return ((static_cast<long>(n) * v.Hs + (y * v.sy + v.oy)) * v.Ws + (x * v.sx + v.ox)) * v.C + v.c_off;
+}
+
+// Load 4 consecutive slice channels [c, c+4) of one pixel with the view's load transform.
+// `rem` = channels still valid from c (entries >= rem come back as 0).
+__device__ __forceinline__ f32x4 view_load4(const unetpp_view& v, long off, int c, int rem, bool vec) {
+  f32x4 val = {0.f, 0.f, 0.f, 0.f};
+  const float* p = v.ptr + off + c;
+  if (vec && rem >= 4) {
+    val = *reinterpret_cast<const f32x4*>(p);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < rem) val[i] = p[i];
+  }
+  if (v.scale != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < rem) val[i] = val[i] * v.scale[c + i] + v.shift[c + i];
+  }
+  if (v.relu) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) val[i] = fmaxf(val[i], 0.f);
+  }
+  if (v.gate != nullptr) {
+    const float* g = v.gate + off + c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < rem) val[i] = (g[i] > 0.f) ? val[i] : 0.f;
+  }
+  return val;
+}
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? UNETPP_OK : UNETPP_ELAUNCH; }
+
+}  // namespace unetpp

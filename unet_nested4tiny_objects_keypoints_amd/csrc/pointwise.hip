@@ -1,0 +1,772 @@
+// HBM-bound companions of the MFMA kernels: BatchNorm statistics / apply / backward, fused
+// affine+ReLU+2x2 max-pool, the 1x1 sigmoid heads with dropout, bilinear x2 (align_corners),
+// and the NCHW<->NHWC converters used at the network edge.  All NHWC fp32; 16-byte vector
+// accesses whenever the channel count is a multiple of 4, scalar fallback otherwise.
+#include "common.h"
+
+namespace unetpp {
+namespace {
+
+template <int VEC>
+struct Pack;
+template <>
+struct Pack<4> {
+  using T = f32x4;
+};
+template <>
+struct Pack<1> {
+  using T = float;
+};
+template <int VEC>
+__device__ __forceinline__ float& lane_of(typename Pack<VEC>::T& v, int i) {
+  if constexpr (VEC == 4)
+    return reinterpret_cast<float*>(&v)[i];
+  else
+    return v;
+}
+template <int VEC>
+__device__ __forceinline__ float lane_of(const typename Pack<VEC>::T& v, int i) {
+  if constexpr (VEC == 4)
+    return v[i];
+  else
+    return v;
+}
+
+inline unsigned grid_for(long items, int cap = 2048 * 8) {
+  long b = (items + kThreads - 1) / kThreads;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return static_cast<unsigned>(b);
+}
+
+// ------------------------------------------------------------------ BatchNorm statistics
+// partial [n_blocks][C][2] -> per-channel totals in double; one workgroup per channel.
+__device__ __forceinline__ void reduce_pair_over_blocks(const float* partial, long n_blocks, int C, int c,
+                                                         double& s1, double& s2) {
+  __shared__ double red[2][kThreads];
+  double a = 0.0, b = 0.0;
+  for (long i = threadIdx.x; i < n_blocks; i += kThreads) {
+    a += static_cast<double>(partial[(i * C + c) * 2 + 0]);
+    b += static_cast<double>(partial[(i * C + c) * 2 + 1]);
+  }
+  red[0][threadIdx.x] = a;
+  red[1][threadIdx.x] = b;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  s1 = red[0][0];
+  s2 = red[1][0];
+}
+
+__global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const float* partial, long n_blocks, int C, long count,
+                                                               const float* gamma, const float* beta, float eps,
+                                                               float momentum, float* running_mean, float* running_var,
+                                                               float* mean, float* invstd, float* scale, float* shift) {
+  const int c = blockIdx.x;
+  double s1, s2;
+  reduce_pair_over_blocks(partial, n_blocks, C, c, s1, s2);
+  if (threadIdx.x == 0) {
+    const double m = s1 / static_cast<double>(count);
+    double var = s2 / static_cast<double>(count) - m * m;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + static_cast<double>(eps));
+    const double sc = static_cast<double>(gamma[c]) * is;
+    mean[c] = static_cast<float>(m);
+    invstd[c] = static_cast<float>(is);
+    scale[c] = static_cast<float>(sc);
+    shift[c] = static_cast<float>(static_cast<double>(beta[c]) - m * sc);
+    if (running_mean != nullptr) {
+      const double unbiased = count > 1 ? var * static_cast<double>(count) / static_cast<double>(count - 1) : var;
+      running_mean[c] = static_cast<float>((1.0 - momentum) * running_mean[c] + momentum * m);
+      running_var[c] = static_cast<float>((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+  }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      int C, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.0f / sqrtf(rv[c] + eps);
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+__global__ __launch_bounds__(kThreads) void bn_bwd_finalize_kernel(const float* partial, long n_blocks, int C,
+                                                                   float* dgamma, float* dbeta) {
+  const int c = blockIdx.x;
+  double s1, s2;
+  reduce_pair_over_blocks(partial, n_blocks, C, c, s1, s2);
+  if (threadIdx.x == 0) {
+    dbeta[c] = static_cast<float>(s1);
+    dgamma[c] = static_cast<float>(s2);
+  }
+}
+
+// ------------------------------------------------------------------ affine + ReLU (+ 2x2 max-pool)
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void affine_relu_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, int relu, long items,
+                                                               int CG, float* __restrict__ act) {
+  using P = typename Pack<VEC>::T;
+  for (long i = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; i < items;
+       i += static_cast<long>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i % CG) * VEC;
+    P v = reinterpret_cast<const P*>(y)[i];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      float t = lane_of<VEC>(v, k);
+      if (scale != nullptr) t = t * scale[c + k] + shift[c + k];
+      if (relu) t = fmaxf(t, 0.f);
+      lane_of<VEC>(v, k) = t;
+    }
+    reinterpret_cast<P*>(act)[i] = v;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void affine_relu_pool_kernel(const float* __restrict__ y,
+                                                                    const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift, int relu, int N,
+                                                                    int H, int W, int CG, float* __restrict__ act,
+                                                                    float* __restrict__ pooled,
+                                                                    uint8_t* __restrict__ pool_idx) {
+  using P = typename Pack<VEC>::T;
+  const int Ho = H >> 1, Wo = W >> 1;
+  const long items = static_cast<long>(N) * Ho * Wo * CG;
+  for (long i = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; i < items;
+       i += static_cast<long>(gridDim.x) * kThreads) {
+    const int cg = static_cast<int>(i % CG);
+    long r = i / CG;
+    const int xo = static_cast<int>(r % Wo);
+    r /= Wo;
+    const int yo = static_cast<int>(r % Ho);
+    const int n = static_cast<int>(r / Ho);
+    const int c = cg * VEC;
+    float best[VEC];
+    uint8_t bi[VEC];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long pix = (static_cast<long>(n) * H + (2 * yo + (q >> 1))) * W + (2 * xo + (q & 1));
+      P v = reinterpret_cast<const P*>(y)[pix * CG + cg];
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) {
+        float t = lane_of<VEC>(v, k);
+        if (scale != nullptr) t = t * scale[c + k] + shift[c + k];
+        if (relu) t = fmaxf(t, 0.f);
+        lane_of<VEC>(v, k) = t;
+        if (q == 0 || t > best[k]) {  // first maximum wins, scan order (0,0),(0,1),(1,0),(1,1)
+          best[k] = t;
+          bi[k] = static_cast<uint8_t>(q);
+        }
+      }
+      if (act != nullptr) reinterpret_cast<P*>(act)[pix * CG + cg] = v;
+    }
+    P out;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) lane_of<VEC>(out, k) = best[k];
+    reinterpret_cast<P*>(pooled)[i] = out;
+    if (pool_idx != nullptr) {
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) pool_idx[i * VEC + k] = bi[k];
+    }
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const float* __restrict__ d_pooled,
+                                                               const uint8_t* __restrict__ pool_idx, int N, int H, int W,
+                                                               int CG, float* __restrict__ d_act) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const long items = static_cast<long>(N) * Ho * Wo * CG;
+  for (long i = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; i < items;
+       i += static_cast<long>(gridDim.x) * kThreads) {
+    const int cg = static_cast<int>(i % CG);
+    long r = i / CG;
+    const int xo = static_cast<int>(r % Wo);
+    r /= Wo;
+    const int yo = static_cast<int>(r % Ho);
+    const int n = static_cast<int>(r / Ho);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const int q = pool_idx[i * VEC + k];
+      const long pix = (static_cast<long>(n) * H + (2 * yo + (q >> 1))) * W + (2 * xo + (q & 1));
+      d_act[(pix * CG + cg) * VEC + k] += d_pooled[i * VEC + k];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ BatchNorm backward
+// Grid stride is a multiple of CG, so a thread keeps one channel group for its whole loop.
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float* __restrict__ d_act,
+                                                                 const float* __restrict__ y,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ invstd, long items, int CG,
+                                                                 float* __restrict__ partial) {
+  using P = typename Pack<VEC>::T;
+  __shared__ float sm[kThreads][VEC * 2];
+  const long first = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x;
+  const int c = static_cast<int>(first % CG) * VEC;
+  float sc[VEC], sh[VEC], mu[VEC], is[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    sc[k] = scale[c + k];
+    sh[k] = shift[c + k];
+    mu[k] = mean[c + k];
+    is[k] = invstd[c + k];
+    s1[k] = 0.f;
+    s2[k] = 0.f;
+  }
+  for (long i = first; i < items; i += static_cast<long>(gridDim.x) * kThreads) {
+    const P g = reinterpret_cast<const P*>(d_act)[i];
+    const P v = reinterpret_cast<const P*>(y)[i];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const float yy = lane_of<VEC>(v, k);
+      const float gg = (yy * sc[k] + sh[k] > 0.f) ? lane_of<VEC>(g, k) : 0.f;
+      s1[k] += gg;
+      s2[k] += gg * (yy - mu[k]) * is[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) {
+    sm[threadIdx.x][2 * k] = s1[k];
+    sm[threadIdx.x][2 * k + 1] = s2[k];
+  }
+  __syncthreads();
+  const int C = CG * VEC;
+  const int base = static_cast<int>((blockIdx.x * static_cast<long>(kThreads)) % CG);
+  for (int cc = threadIdx.x; cc < C; cc += kThreads) {
+    const int cg = cc / VEC, k = cc % VEC;
+    float a = 0.f, b = 0.f;
+    for (int t = (cg - base + CG) % CG; t < kThreads; t += CG) {
+      a += sm[t][2 * k];
+      b += sm[t][2 * k + 1];
+    }
+    partial[(static_cast<long>(blockIdx.x) * C + cc) * 2 + 0] = a;
+    partial[(static_cast<long>(blockIdx.x) * C + cc) * 2 + 1] = b;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* __restrict__ d_act, const float* __restrict__ y,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ dgamma,
+                                                                const float* __restrict__ dbeta, float inv_count,
+                                                                long items, int CG, float* __restrict__ dy) {
+  using P = typename Pack<VEC>::T;
+  for (long i = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; i < items;
+       i += static_cast<long>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i % CG) * VEC;
+    const P g = reinterpret_cast<const P*>(d_act)[i];
+    const P v = reinterpret_cast<const P*>(y)[i];
+    P out;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const float yy = lane_of<VEC>(v, k);
+      const float gg = (yy * scale[c + k] + shift[c + k] > 0.f) ? lane_of<VEC>(g, k) : 0.f;
+      const float xhat = (yy - mean[c + k]) * invstd[c + k];
+      lane_of<VEC>(out, k) =
+          gamma[c + k] * invstd[c + k] * (gg - dbeta[c + k] * inv_count - xhat * dgamma[c + k] * inv_count);
+    }
+    reinterpret_cast<P*>(dy)[i] = out;
+  }
+}
+
+// ------------------------------------------------------------------ dropout keep mask
+// Counter-based: one splitmix64 hash per group of 4 channels of one pixel gives four 16-bit
+// uniforms; forward and backward regenerate the same mask from (seed, pixel, group).
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint64_t keep_bits(uint64_t seed, long pixel, int cgroups4, int g4) {
+  return mix64(seed + 0x9E3779B97F4A7C15ULL * (static_cast<uint64_t>(pixel) * cgroups4 + g4 + 1));
+}
+// keep flag of slice channel c of pixel p
+__device__ __forceinline__ bool keep_one(uint64_t bits, int c_in_group, uint32_t thr16) {
+  return ((bits >> (16 * c_in_group)) & 0xFFFFu) < thr16;
+}
+
+constexpr int kHeadMaxC = 128;
+constexpr int kHeadMaxCls = 8;
+
+__global__ __launch_bounds__(kThreads) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ weight,
+                                                            const float* __restrict__ bias, long pixels, int HW, int C,
+                                                            int n_cls, float keep_scale, uint32_t thr16, uint64_t seed,
+                                                            const uint8_t* __restrict__ mask, int use_drop,
+                                                            float* __restrict__ out) {
+  __shared__ float wsm[kHeadMaxCls * kHeadMaxC];
+  for (int i = threadIdx.x; i < n_cls * C; i += kThreads) wsm[i] = weight[i];
+  __syncthreads();
+  const int g4n = (C + 3) >> 2;
+  for (long p = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; p < pixels;
+       p += static_cast<long>(gridDim.x) * kThreads) {
+    float acc[kHeadMaxCls];
+#pragma unroll
+    for (int k = 0; k < kHeadMaxCls; ++k) acc[k] = (k < n_cls) ? bias[k] : 0.f;
+    const float* xp = x + p * C;
+    for (int g = 0; g < g4n; ++g) {
+      const uint64_t bits = (use_drop && mask == nullptr) ? keep_bits(seed, p, g4n, g) : 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 4 * g + q;
+        if (c < C) {
+          float v = xp[c];
+          if (use_drop) {
+            const bool keep = (mask != nullptr) ? (mask[p * C + c] != 0) : keep_one(bits, q, thr16);
+            v = keep ? v * keep_scale : 0.f;
+          }
+#pragma unroll
+          for (int k = 0; k < kHeadMaxCls; ++k)
+            if (k < n_cls) acc[k] += v * wsm[k * C + c];
+        }
+      }
+    }
+    const long n = p / HW, hw = p - n * HW;
+#pragma unroll
+    for (int k = 0; k < kHeadMaxCls; ++k)
+      if (k < n_cls) out[(n * n_cls + k) * HW + hw] = 1.0f / (1.0f + expf(-acc[k]));
+  }
+}
+
+// tile = 64 consecutive pixels.  LDS: x*keep*scale [64][C+1], dlogit [64][8], W [8][C].
+__global__ __launch_bounds__(kThreads) void head_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ outp,
+                                                            const float* __restrict__ x, const float* __restrict__ weight,
+                                                            long pixels, int HW, int C, int n_cls, float keep_scale,
+                                                            uint32_t thr16, uint64_t seed, const uint8_t* __restrict__ mask,
+                                                            int use_drop, float* __restrict__ dx, int accumulate,
+                                                            float* __restrict__ partial) {
+  __shared__ float xs[64 * (kHeadMaxC + 1)];
+  __shared__ float dl[64 * kHeadMaxCls];
+  __shared__ float wsm[kHeadMaxCls * kHeadMaxC];
+  const int tid = threadIdx.x;
+  const int XS = C + 1;
+  const int g4n = (C + 3) >> 2;
+  for (int i = tid; i < n_cls * C; i += kThreads) wsm[i] = weight[i];
+  float wacc[4] = {0.f, 0.f, 0.f, 0.f};  // dW entries tid, tid+256, ... (n_cls*C <= 1024)
+  float bacc = 0.f;                      // db entry tid (< n_cls)
+  const long n_tiles = (pixels + 63) / 64;
+  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long p0 = tile * 64;
+    __syncthreads();
+    // dlogit = d_out * out * (1 - out)
+    for (int it = tid; it < 64 * n_cls; it += kThreads) {
+      const int pl = it & 63, k = it >> 6;
+      const long p = p0 + pl;
+      float v = 0.f;
+      if (p < pixels) {
+        const long n = p / HW, hw = p - n * HW;
+        const long o = (n * n_cls + k) * HW + hw;
+        const float pr = outp[o];
+        v = d_out[o] * pr * (1.f - pr);
+      }
+      dl[pl * kHeadMaxCls + k] = v;
+    }
+    // x * keep * scale
+    for (int it = tid; it < 64 * C; it += kThreads) {
+      const int pl = it / C, c = it - pl * C;
+      const long p = p0 + pl;
+      float v = 0.f;
+      if (p < pixels) {
+        v = x[p * C + c];
+        if (use_drop) {
+          const bool keep = (mask != nullptr) ? (mask[p * C + c] != 0)
+                                              : keep_one(keep_bits(seed, p, g4n, c >> 2), c & 3, thr16);
+          v = keep ? v * keep_scale : 0.f;
+        }
+      }
+      xs[pl * XS + c] = v;
+    }
+    __syncthreads();
+    // dx[p, c] = keep * scale * sum_k W[k, c] * dlogit[p, k]
+    for (int it = tid; it < 64 * C; it += kThreads) {
+      const int pl = it / C, c = it - pl * C;
+      const long p = p0 + pl;
+      if (p < pixels) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < kHeadMaxCls; ++k)
+          if (k < n_cls) s += wsm[k * C + c] * dl[pl * kHeadMaxCls + k];
+        if (use_drop) {
+          const bool keep = (mask != nullptr) ? (mask[p * C + c] != 0)
+                                              : keep_one(keep_bits(seed, p, g4n, c >> 2), c & 3, thr16);
+          s = keep ? s * keep_scale : 0.f;
+        }
+        if (accumulate) s += dx[p * C + c];
+        dx[p * C + c] = s;
+      }
+    }
+    // dW[k, c] += sum_p dlogit[p, k] * xs[p, c];  db[k] += sum_p dlogit[p, k]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + q * kThreads;
+      if (idx < n_cls * C) {
+        const int k = idx / C, c = idx - k * C;
+        float s = 0.f;
+        for (int pl = 0; pl < 64; ++pl) s += dl[pl * kHeadMaxCls + k] * xs[pl * XS + c];
+        wacc[q] += s;
+      }
+    }
+    if (tid < n_cls) {
+      float s = 0.f;
+      for (int pl = 0; pl < 64; ++pl) s += dl[pl * kHeadMaxCls + tid];
+      bacc += s;
+    }
+  }
+  float* dst = partial + static_cast<long>(blockIdx.x) * (n_cls * C + n_cls);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = tid + q * kThreads;
+    if (idx < n_cls * C) dst[idx] = wacc[q];
+  }
+  if (tid < n_cls) dst[n_cls * C + tid] = bacc;
+}
+
+__global__ void sum_partials_kernel(const float* __restrict__ partial, long n_blocks, long len, float* __restrict__ out) {
+  const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+  if (i >= len) return;
+  double s = 0.0;
+  for (long b = 0; b < n_blocks; ++b) s += static_cast<double>(partial[b * len + i]);
+  out[i] = static_cast<float>(s);
+}
+
+// ------------------------------------------------------------------ bilinear x2, align_corners = True
+__device__ __forceinline__ void bilinear_src(int dst, int in_size, float rscale, int& i0, int& i1, float& l1) {
+  const float s = rscale * static_cast<float>(dst);
+  i0 = static_cast<int>(s);
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = s - static_cast<float>(i0);
+}
+
+__global__ __launch_bounds__(kThreads) void bilinear2x_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C,
+                                                                  float* __restrict__ y) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const float ry = (Ho > 1) ? static_cast<float>(H - 1) / static_cast<float>(Ho - 1) : 0.f;
+  const float rx = (Wo > 1) ? static_cast<float>(W - 1) / static_cast<float>(Wo - 1) : 0.f;
+  const long items = static_cast<long>(N) * Ho * Wo * C;
+  for (long i = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; i < items;
+       i += static_cast<long>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i % C);
+    long r = i / C;
+    const int xo = static_cast<int>(r % Wo);
+    r /= Wo;
+    const int yo = static_cast<int>(r % Ho);
+    const int n = static_cast<int>(r / Ho);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilinear_src(yo, H, ry, y0, y1, ly);
+    bilinear_src(xo, W, rx, x0, x1, lx);
+    const float* b = x + static_cast<long>(n) * H * W * C + c;
+    const float v00 = b[(static_cast<long>(y0) * W + x0) * C], v01 = b[(static_cast<long>(y0) * W + x1) * C];
+    const float v10 = b[(static_cast<long>(y1) * W + x0) * C], v11 = b[(static_cast<long>(y1) * W + x1) * C];
+    y[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+  }
+}
+
+// gather form of the transposed stencil: every source pixel visits the <= 5x5 destination pixels that can
+// reference it and recomputes their weights, so the sum has a fixed order (no atomics).
+__global__ __launch_bounds__(kThreads) void bilinear2x_bwd_kernel(const float* __restrict__ dy, int N, int H, int W, int C,
+                                                                  float* __restrict__ dx, int accumulate) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const float ry = (Ho > 1) ? static_cast<float>(H - 1) / static_cast<float>(Ho - 1) : 0.f;
+  const float rx = (Wo > 1) ? static_cast<float>(W - 1) / static_cast<float>(Wo - 1) : 0.f;
+  const long items = static_cast<long>(N) * H * W * C;
+  for (long i = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; i < items;
+       i += static_cast<long>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i % C);
+    long r = i / C;
+    const int xs = static_cast<int>(r % W);
+    r /= W;
+    const int ys = static_cast<int>(r % H);
+    const int n = static_cast<int>(r / H);
+    const int ylo = max(0, 2 * ys - 3), yhi = min(Ho - 1, 2 * ys + 3);
+    const int xlo = max(0, 2 * xs - 3), xhi = min(Wo - 1, 2 * xs + 3);
+    float s = 0.f;
+    for (int yo = ylo; yo <= yhi; ++yo) {
+      int y0, y1;
+      float ly;
+      bilinear_src(yo, H, ry, y0, y1, ly);
+      float wy = 0.f;
+      if (y0 == ys) wy += 1.f - ly;
+      if (y1 == ys) wy += ly;
+      if (wy == 0.f) continue;
+      for (int xo = xlo; xo <= xhi; ++xo) {
+        int x0, x1;
+        float lx;
+        bilinear_src(xo, W, rx, x0, x1, lx);
+        float wx = 0.f;
+        if (x0 == xs) wx += 1.f - lx;
+        if (x1 == xs) wx += lx;
+        if (wx != 0.f) s += wy * wx * dy[((static_cast<long>(n) * Ho + yo) * Wo + xo) * C + c];
+      }
+    }
+    dx[i] = accumulate ? dx[i] + s : s;
+  }
+}
+
+// ------------------------------------------------------------------ layout converters
+__global__ __launch_bounds__(kThreads) void nchw_to_nhwc_kernel(const float* __restrict__ src, int N, int C, long HW,
+                                                                float* __restrict__ dst) {
+  const long items = static_cast<long>(N) * C * HW;
+  for (long i = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; i < items;
+       i += static_cast<long>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i % C);
+    const long r = i / C;
+    const long hw = r % HW, n = r / HW;
+    dst[i] = src[(n * C + c) * HW + hw];
+  }
+}
+__global__ __launch_bounds__(kThreads) void nhwc_to_nchw_kernel(const float* __restrict__ src, int N, int C, long HW,
+                                                                float* __restrict__ dst) {
+  const long items = static_cast<long>(N) * C * HW;
+  for (long i = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; i < items;
+       i += static_cast<long>(gridDim.x) * kThreads) {
+    const long hw = i % HW;
+    const long r = i / HW;
+    const int c = static_cast<int>(r % C);
+    const long n = r / C;
+    dst[i] = src[(n * HW + hw) * C + c];
+  }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+}  // namespace unetpp
+
+using namespace unetpp;
+#define ST(s) static_cast<hipStream_t>(s)
+
+extern "C" int unetpp_bn_finalize(const float* partial, int64_t n_blocks, int32_t C, int64_t count, const float* gamma,
+                                  const float* beta, float eps, float momentum, float* running_mean,
+                                  float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                                  void* stream) {
+  if (!partial || n_blocks < 1 || C < 1 || count < 1 || !gamma || !beta || !mean || !invstd || !scale || !shift)
+    return UNETPP_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return UNETPP_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(kThreads), 0, ST(stream), partial, n_blocks, C, count, gamma,
+                     beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  return launch_status();
+}
+
+extern "C" int unetpp_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                     const float* running_var, float eps, int32_t C, float* scale, float* shift,
+                                     void* stream) {
+  if (!gamma || !beta || !running_mean || !running_var || C < 1 || !scale || !shift) return UNETPP_EINVAL;
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 63) / 64), dim3(64), 0, ST(stream), gamma, beta, running_mean,
+                     running_var, eps, C, scale, shift);
+  return launch_status();
+}
+
+extern "C" int unetpp_affine_relu_pool(const float* y, const float* scale, const float* shift, int32_t relu, int32_t N,
+                                       int32_t H, int32_t W, int32_t C, float* act, float* pooled, uint8_t* pool_idx,
+                                       void* stream) {
+  if (!y || N < 1 || H < 1 || W < 1 || C < 1) return UNETPP_EINVAL;
+  if ((scale == nullptr) != (shift == nullptr)) return UNETPP_EINVAL;
+  if (act == nullptr && pooled == nullptr) return UNETPP_EINVAL;
+  const bool vec = (C % 4 == 0) && aligned16(y) && (!act || aligned16(act)) && (!pooled || aligned16(pooled));
+  if (pooled == nullptr) {
+    const long pixels = static_cast<long>(N) * H * W;
+    if (vec) {
+      const long items = pixels * (C / 4);
+      hipLaunchKernelGGL(affine_relu_kernel<4>, dim3(grid_for(items)), dim3(kThreads), 0, ST(stream), y, scale, shift,
+                         relu, items, C / 4, act);
+    } else {
+      const long items = pixels * C;
+      hipLaunchKernelGGL(affine_relu_kernel<1>, dim3(grid_for(items)), dim3(kThreads), 0, ST(stream), y, scale, shift,
+                         relu, items, C, act);
+    }
+    return launch_status();
+  }
+  if ((H & 1) || (W & 1)) return UNETPP_EINVAL;
+  const long windows = static_cast<long>(N) * (H / 2) * (W / 2);
+  if (vec)
+    hipLaunchKernelGGL(affine_relu_pool_kernel<4>, dim3(grid_for(windows * (C / 4))), dim3(kThreads), 0, ST(stream), y,
+                       scale, shift, relu, N, H, W, C / 4, act, pooled, pool_idx);
+  else
+    hipLaunchKernelGGL(affine_relu_pool_kernel<1>, dim3(grid_for(windows * C)), dim3(kThreads), 0, ST(stream), y, scale,
+                       shift, relu, N, H, W, C, act, pooled, pool_idx);
+  return launch_status();
+}
+
+extern "C" int unetpp_maxpool_bwd(const float* d_pooled, const uint8_t* pool_idx, int32_t N, int32_t H, int32_t W,
+                                  int32_t C, float* d_act, void* stream) {
+  if (!d_pooled || !pool_idx || !d_act || N < 1 || H < 2 || W < 2 || C < 1 || (H & 1) || (W & 1)) return UNETPP_EINVAL;
+  const long windows = static_cast<long>(N) * (H / 2) * (W / 2);
+  if (C % 4 == 0)
+    hipLaunchKernelGGL(maxpool_bwd_kernel<4>, dim3(grid_for(windows * (C / 4))), dim3(kThreads), 0, ST(stream), d_pooled,
+                       pool_idx, N, H, W, C / 4, d_act);
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel<1>, dim3(grid_for(windows * C)), dim3(kThreads), 0, ST(stream), d_pooled,
+                       pool_idx, N, H, W, C, d_act);
+  return launch_status();
+}
+
+namespace {
+// blocks for the BN-backward reduction: a multiple of the channel-group count so that the grid stride
+// keeps every thread on one channel group.
+inline long bn_bwd_blocks_for(long pixels, int C, bool vec) {
+  const int CG = vec ? C / 4 : C;
+  const long items = pixels * CG;
+  long want = (items + kThreads * 16L - 1) / (kThreads * 16L);
+  if (want > 2048) want = 2048;
+  if (want < 1) want = 1;
+  long blocks = ((want + CG - 1) / CG) * CG;
+  return blocks;
+}
+}  // namespace
+
+extern "C" int64_t unetpp_bn_bwd_blocks(int64_t pixels, int32_t C) {
+  if (pixels < 1 || C < 1) return 0;
+  // upper bound over both code paths (vector / scalar) so one workspace size serves either
+  const long a = (C % 4 == 0) ? bn_bwd_blocks_for(pixels, C, true) : 0;
+  const long b = bn_bwd_blocks_for(pixels, C, false);
+  return a > b ? a : b;
+}
+
+extern "C" int unetpp_bn_bwd_reduce(const float* d_act, const float* y, const float* scale, const float* shift,
+                                    const float* mean, const float* invstd, int64_t pixels, int32_t C, float* partial,
+                                    void* stream) {
+  if (!d_act || !y || !scale || !shift || !mean || !invstd || !partial || pixels < 1 || C < 1) return UNETPP_EINVAL;
+  const bool vec = (C % 4 == 0) && aligned16(d_act) && aligned16(y);
+  // the partial buffer always has unetpp_bn_bwd_blocks() rows; rows beyond this launch's grid are zeroed
+  const long rows = unetpp_bn_bwd_blocks(pixels, C);
+  const long blocks = bn_bwd_blocks_for(pixels, C, vec);
+  if (blocks < rows) {
+    if (hipMemsetAsync(partial + blocks * C * 2, 0, sizeof(float) * (rows - blocks) * C * 2, ST(stream)) != hipSuccess)
+      return UNETPP_ELAUNCH;
+  }
+  if (vec)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, ST(stream),
+                       d_act, y, scale, shift, mean, invstd, pixels * (C / 4), C / 4, partial);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, ST(stream),
+                       d_act, y, scale, shift, mean, invstd, pixels * C, C, partial);
+  return launch_status();
+}
+
+extern "C" int unetpp_bn_bwd_finalize(const float* partial, int64_t n_blocks, int32_t C, float* dgamma, float* dbeta,
+                                      void* stream) {
+  if (!partial || n_blocks < 1 || C < 1 || !dgamma || !dbeta) return UNETPP_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kThreads), 0, ST(stream), partial, n_blocks, C, dgamma,
+                     dbeta);
+  return launch_status();
+}
+
+extern "C" int unetpp_bn_bwd_apply(const float* d_act, const float* y, const float* scale, const float* shift,
+                                   const float* mean, const float* invstd, const float* gamma, const float* dgamma,
+                                   const float* dbeta, int64_t pixels, int32_t C, float* dy, void* stream) {
+  if (!d_act || !y || !scale || !shift || !mean || !invstd || !gamma || !dgamma || !dbeta || !dy || pixels < 1 || C < 1)
+    return UNETPP_EINVAL;
+  const bool vec = (C % 4 == 0) && aligned16(d_act) && aligned16(y) && aligned16(dy);
+  const float inv_count = 1.0f / static_cast<float>(pixels);
+  if (vec) {
+    const long items = pixels * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(grid_for(items)), dim3(kThreads), 0, ST(stream), d_act, y, scale,
+                       shift, mean, invstd, gamma, dgamma, dbeta, inv_count, items, C / 4, dy);
+  } else {
+    const long items = pixels * C;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(grid_for(items)), dim3(kThreads), 0, ST(stream), d_act, y, scale,
+                       shift, mean, invstd, gamma, dgamma, dbeta, inv_count, items, C, dy);
+  }
+  return launch_status();
+}
+
+namespace {
+inline bool head_args_ok(int N, int H, int W, int C, int n_cls, float p_drop) {
+  return N >= 1 && H >= 1 && W >= 1 && C >= 1 && C <= kHeadMaxC && n_cls >= 1 && n_cls <= kHeadMaxCls &&
+         p_drop >= 0.f && p_drop < 1.f;
+}
+inline uint32_t keep_threshold(float p_drop) {
+  const double keep = 1.0 - static_cast<double>(p_drop);
+  uint32_t t = static_cast<uint32_t>(keep * 65536.0 + 0.5);
+  return t > 65536u ? 65536u : t;
+}
+}  // namespace
+
+extern "C" int unetpp_head_fwd(const float* x, const float* weight, const float* bias, int32_t N, int32_t H, int32_t W,
+                               int32_t C, int32_t n_cls, float p_drop, uint64_t seed, const uint8_t* mask,
+                               float* out_nchw, void* stream) {
+  if (!x || !weight || !bias || !out_nchw || !head_args_ok(N, H, W, C, n_cls, p_drop)) return UNETPP_EINVAL;
+  const long pixels = static_cast<long>(N) * H * W;
+  const int use_drop = p_drop > 0.f;
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(grid_for(pixels)), dim3(kThreads), 0, ST(stream), x, weight, bias, pixels,
+                     H * W, C, n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, use_drop, out_nchw);
+  return launch_status();
+}
+
+extern "C" int64_t unetpp_head_bwd_blocks(int64_t pixels) {
+  if (pixels < 1) return 0;
+  const long tiles = (pixels + 63) / 64;
+  return tiles < 1024 ? tiles : 1024;
+}
+
+extern "C" int unetpp_head_bwd(const float* d_out_nchw, const float* out_nchw, const float* x, const float* weight,
+                               int32_t N, int32_t H, int32_t W, int32_t C, int32_t n_cls, float p_drop, uint64_t seed,
+                               const uint8_t* mask, float* dx, int32_t accumulate, float* partial, void* stream) {
+  if (!d_out_nchw || !out_nchw || !x || !weight || !dx || !partial || !head_args_ok(N, H, W, C, n_cls, p_drop))
+    return UNETPP_EINVAL;
+  const long pixels = static_cast<long>(N) * H * W;
+  const int use_drop = p_drop > 0.f;
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(static_cast<unsigned>(unetpp_head_bwd_blocks(pixels))), dim3(kThreads), 0,
+                     ST(stream), d_out_nchw, out_nchw, x, weight, pixels, H * W, C, n_cls, 1.0f / (1.0f - p_drop),
+                     keep_threshold(p_drop), seed, mask, use_drop, dx, accumulate, partial);
+  return launch_status();
+}
+
+extern "C" int unetpp_sum_partials(const float* partial, int64_t n_blocks, int64_t len, float* out, void* stream) {
+  if (!partial || !out || n_blocks < 1 || len < 1) return UNETPP_EINVAL;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(static_cast<unsigned>((len + 255) / 256)), dim3(256), 0, ST(stream),
+                     partial, n_blocks, len, out);
+  return launch_status();
+}
+
+extern "C" int unetpp_bilinear2x_fwd(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* y, void* stream) {
+  if (!x || !y || N < 1 || H < 1 || W < 1 || C < 1) return UNETPP_EINVAL;
+  const long items = static_cast<long>(N) * 4 * H * W * C;
+  hipLaunchKernelGGL(bilinear2x_fwd_kernel, dim3(grid_for(items)), dim3(kThreads), 0, ST(stream), x, N, H, W, C, y);
+  return launch_status();
+}
+
+extern "C" int unetpp_bilinear2x_bwd(const float* dy, int32_t N, int32_t H, int32_t W, int32_t C, float* dx,
+                                     int32_t accumulate, void* stream) {
+  if (!dy || !dx || N < 1 || H < 1 || W < 1 || C < 1) return UNETPP_EINVAL;
+  const long items = static_cast<long>(N) * H * W * C;
+  hipLaunchKernelGGL(bilinear2x_bwd_kernel, dim3(grid_for(items)), dim3(kThreads), 0, ST(stream), dy, N, H, W, C, dx, accumulate);
+  return launch_status();
+}
+
+extern "C" int unetpp_nchw_to_nhwc(const float* src, int32_t N, int32_t C, int32_t H, int32_t W, float* dst, void* stream) {
+  if (!src || !dst || N < 1 || C < 1 || H < 1 || W < 1) return UNETPP_EINVAL;
+  const long items = static_cast<long>(N) * C * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(items)), dim3(kThreads), 0, ST(stream), src, N, C,
+                     static_cast<long>(H) * W, dst);
+  return launch_status();
+}
+
+extern "C" int unetpp_nhwc_to_nchw(const float* src, int32_t N, int32_t C, int32_t H, int32_t W, float* dst, void* stream) {
+  if (!src || !dst || N < 1 || C < 1 || H < 1 || W < 1) return UNETPP_EINVAL;
+  const long items = static_cast<long>(N) * C * H * W;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(items)), dim3(kThreads), 0, ST(stream), src, N, C,
+                     static_cast<long>(H) * W, dst);
+  return launch_status();
+}
+
+extern "C" int unetpp_abi_version(void) { return UNETPP_ABI_VERSION; }
+extern "C" const char* unetpp_build_arch(void) { return "gfx950"; }

@@ -1,0 +1,403 @@
+"""Forward / backward schedule of UNet_Nested over the HIP C ABI.
+
+One ``torch.autograd.Function`` covers the whole network (models/unet.py:255-300): ``forward`` walks the
+nested graph launching HIP kernels and keeps the activations it needs; ``backward`` walks it in reverse
+(gradient-ready order of SURVEY.md section 3c: heads, X_03, X_12, X_02, X_21, X_11, X_01, X_30 .. X_00),
+summing the dense-skip fan-in directly in the dgrad epilogues (first contribution stores, later ones
+accumulate -- no memsets, no concat/split copies).  PyTorch supplies device memory, the stream and the
+autograd hand-off to the loss; every FLOP of the path is in ``libunetpp_hip.so``.
+
+Layout: activations NHWC fp32; the dense-skip concatenation ``cat([up, X_i0, .., X_i,j-1], 1)``
+(models/unet.py:198-202) is never materialised -- the consumer GEMM reads one view per source.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .ops import V
+
+
+# ----------------------------------------------------------------------------- weight re-layouts
+def _empty(n, like):
+    return torch.empty(n, dtype=torch.float32, device=like.device)
+
+
+def pack_conv_fwd(w):
+    """[co, ci, k, k] -> [taps][ci][co]"""
+    co, ci, kh, kw = w.shape
+    t = kh * kw
+    dst = _empty(t * ci * co, w)
+    ops.pack_weight(dst, w, t, ci, co, (ci * co, co, 1), (1, t, ci * t))
+    return dst
+
+
+def pack_conv_dgrad(w):
+    """[co, ci, k, k] -> [taps (rotated 180)][co][ci]: dx = conv(dy, this)"""
+    co, ci, kh, kw = w.shape
+    t = kh * kw
+    dst = _empty(t * co * ci, w)
+    ops.pack_weight(dst, w, t, co, ci, (co * ci, ci, 1), (1, ci * t, t), flip=True)
+    return dst
+
+
+def pack_deconv_fwd(w):
+    """[ci, co, 2, 2] -> [1][ci][4*co], column = (a*2+b)*co + c"""
+    ci, co = w.shape[0], w.shape[1]
+    dst = _empty(ci * 4 * co, w)
+    ops.pack_weight(dst, w, 4, ci, co, (co, 4 * co, 1), (1, 4 * co, 4))
+    return dst
+
+
+def pack_deconv_dgrad(w):
+    """[ci, co, 2, 2] -> [1][4*co][ci], row = (a*2+b)*co + c"""
+    ci, co = w.shape[0], w.shape[1]
+    dst = _empty(4 * co * ci, w)
+    ops.pack_weight(dst, w, 4, co, ci, (co * ci, ci, 1), (1, 4, 4 * co))
+    return dst
+
+
+def tile_bias4(b):
+    co = b.numel()
+    dst = _empty(4 * co, b)
+    ops.pack_weight(dst, b, 4, 1, co, (co, 0, 1), (0, 0, 1))
+    return dst
+
+
+def _phase_views(t, **kw):
+    """The four pixel phases (a, b) of a tensor at twice the logical resolution, in t = a*2+b order."""
+    return [V(t, sy=2, sx=2, oy=a, ox=b, **kw) for a in (0, 1) for b in (0, 1)]
+
+
+# ----------------------------------------------------------------------------- records kept for backward
+class _PairRec:
+    __slots__ = ("ins", "y1", "a1", "y2", "out", "pooled", "pool_idx", "bn1", "bn2", "h", "w")
+
+    def __init__(self):
+        for s in self.__slots__:
+            setattr(self, s, None)
+
+
+class _UpRec:
+    __slots__ = ("src", "up", "interp", "h", "w")
+
+    def __init__(self):
+        for s in self.__slots__:
+            setattr(self, s, None)
+
+
+class _Saved:
+    pass
+
+
+def _conv_bn_fwd(ins, conv, bn, y, b, h, w, training):
+    """conv3x3 + bias -> y, with the BatchNorm partial sums taken in the GEMM epilogue (training)."""
+    co = conv.out_channels
+    wp = pack_conv_fwd(conv.weight.detach())
+    if training:
+        blocks = ops.gemm_pixel_blocks(b, h, w)
+        partial = _empty(blocks * co * 2, y)
+        ops.gemm_fwd(b, h, w, 9, ins, [V(y)], wp, conv.bias.detach(), partial)
+        stats = ops.bn_finalize(partial, blocks, co, b * h * w, bn.weight.detach(), bn.bias.detach(), bn.eps,
+                                bn.momentum, bn.running_mean, bn.running_var)
+        bn.num_batches_tracked.add_(1)
+        return stats  # (mean, invstd, scale, shift)
+    ops.gemm_fwd(b, h, w, 9, ins, [V(y)], wp, conv.bias.detach(), None)
+    scale, shift = ops.bn_eval_coeffs(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
+    return (None, None, scale, shift)
+
+
+def _pair_fwd(blk, ins: List[V], b, h, w, training, pool) -> _PairRec:
+    """models/unet.py:150-156: two [conv3x3 (+BN) + ReLU] stages; optional fused 2x2 max-pool of the result."""
+    conv1, conv2 = getattr(blk.conv1, "0"), getattr(blk.conv2, "0")
+    co = conv1.out_channels
+    like = ins[0].t
+    new = lambda: torch.empty((b, h, w, co), dtype=torch.float32, device=like.device)  # noqa: E731
+    r = _PairRec()
+    r.ins, r.h, r.w = ins, h, w
+    if pool:
+        r.pooled = torch.empty((b, h // 2, w // 2, co), dtype=torch.float32, device=like.device)
+        r.pool_idx = torch.empty((b, h // 2, w // 2, co), dtype=torch.uint8, device=like.device)
+    if blk.is_batchnorm:
+        bn1, bn2 = getattr(blk.conv1, "1"), getattr(blk.conv2, "1")
+        r.y1 = new()
+        r.bn1 = _conv_bn_fwd(ins, conv1, bn1, r.y1, b, h, w, training)
+        r.a1 = new()
+        ops.affine_relu_pool(r.y1, r.bn1[2], r.bn1[3], True, r.a1, None, None)
+        r.y2 = new()
+        r.bn2 = _conv_bn_fwd([V(r.a1)], conv2, bn2, r.y2, b, h, w, training)
+        r.out = new()
+        ops.affine_relu_pool(r.y2, r.bn2[2], r.bn2[3], True, r.out, r.pooled, r.pool_idx)
+    else:
+        r.a1 = new()
+        ops.gemm_fwd(b, h, w, 9, ins, [V(r.a1, relu=True)], pack_conv_fwd(conv1.weight.detach()), conv1.bias.detach())
+        r.out = new()
+        ops.gemm_fwd(b, h, w, 9, [V(r.a1)], [V(r.out, relu=True)], pack_conv_fwd(conv2.weight.detach()),
+                     conv2.bias.detach())
+        if pool:
+            ops.affine_relu_pool(r.out, None, None, False, None, r.pooled, r.pool_idx)
+    return r
+
+
+def _up_fwd(upmod, is_deconv, src, b, hs, ws) -> _UpRec:
+    """models/unet.py:186-191,199: ConvTranspose2d(2,2) or bilinear x2 (align_corners) + conv1x1; src is [b,hs,ws,ci]."""
+    u = _UpRec()
+    u.src, u.h, u.w = src, hs, ws
+    if is_deconv:
+        co = upmod.out_channels
+        u.up = torch.empty((b, 2 * hs, 2 * ws, co), dtype=torch.float32, device=src.device)
+        ops.gemm_fwd(b, hs, ws, 1, [V(src)], _phase_views(u.up), pack_deconv_fwd(upmod.weight.detach()),
+                     tile_bias4(upmod.bias.detach()))
+    else:
+        conv = getattr(upmod, "1")
+        ci, co = conv.in_channels, conv.out_channels
+        u.interp = torch.empty((b, 2 * hs, 2 * ws, ci), dtype=torch.float32, device=src.device)
+        ops.bilinear2x_fwd(src, u.interp)
+        u.up = torch.empty((b, 2 * hs, 2 * ws, co), dtype=torch.float32, device=src.device)
+        ops.gemm_fwd(b, 2 * hs, 2 * ws, 1, [V(u.interp)], [V(u.up)], pack_conv_fwd(conv.weight.detach()),
+                     conv.bias.detach())
+    return u
+
+
+def _check_input(model, x):
+    if x.dim() != 4:
+        raise ValueError("expected NCHW input, got %d dims" % x.dim())
+    if not x.is_cuda:
+        raise RuntimeError("UNet_Nested (HIP) needs its input on the GPU: there is no CPU fallback for this path")
+    if x.dtype != torch.float32:
+        raise TypeError("expected float32 input, got %s" % x.dtype)
+    if x.shape[1] != model.in_channels:
+        raise ValueError("expected %d input channels, got %d" % (model.in_channels, x.shape[1]))
+    m = 1 << (model.depth - 1)
+    if x.shape[2] % m or x.shape[3] % m:
+        # the reference fails inside torch.cat for such sizes; fail up front instead
+        raise ValueError("H and W must be divisible by %d, got %dx%d" % (m, x.shape[2], x.shape[3]))
+    if next(model.parameters()).device != x.device:
+        raise RuntimeError("model and input are on different devices")
+
+
+def _dropout_config(model, training):
+    p = float(model.drop_out.p) if (training and model.drop_out.training) else 0.0
+    heads = model.depth - 1
+    masks = model.dropout_masks if p > 0.0 else None
+    if masks is not None and len(masks) != heads:
+        raise ValueError("dropout_masks needs one mask per head")
+    base = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p > 0.0 and masks is None) else 0
+    seeds = [(base + 0x632BE59BD9B4E019 * (j + 1)) & 0xFFFFFFFFFFFFFFFF for j in range(heads)]
+    return p, seeds, masks
+
+
+def forward_impl(model, x, training: bool, save: bool):
+    """Runs the forward DAG of models/unet.py:255-300.  Returns (outputs, saved-for-backward or None)."""
+    _check_input(model, x)
+    b, _, h0, w0 = x.shape
+    d = model.depth
+    x_nhwc = ops.nchw_to_nhwc(x.detach().contiguous())
+    X: Dict[Tuple[int, int], torch.Tensor] = {}
+    pairs: Dict[Tuple[int, int], _PairRec] = {}
+    ups: Dict[Tuple[int, int], _UpRec] = {}
+    inp, h, w = x_nhwc, h0, w0
+    for i in range(d):  # encoder column (:257-265)
+        r = _pair_fwd(getattr(model, "conv%d0" % i), [V(inp)], b, h, w, training, pool=(i < d - 1))
+        pairs[(i, 0)], X[(i, 0)] = r, r.out
+        if i < d - 1:
+            inp, h, w = r.pooled, h // 2, w // 2
+    for j in range(1, d):  # decoder columns (:268-280)
+        for i in range(d - j):
+            mod = getattr(model, "up_concat%d%d" % (i, j))
+            hi, wi = h0 >> i, w0 >> i
+            u = _up_fwd(mod.up, model.is_deconv, X[(i + 1, j - 1)], b, hi // 2, wi // 2)
+            ins = [V(u.up)] + [V(X[(i, jj)]) for jj in range(j)]  # up first, then X_i0.. (:198-202)
+            r = _pair_fwd(mod.conv, ins, b, hi, wi, training, pool=False)
+            ups[(i, j)], pairs[(i, j)], X[(i, j)] = u, r, r.out
+    p_drop, seeds, masks = _dropout_config(model, training)
+    outs = []
+    for j in range(1, d):  # heads (:283-286)
+        head = getattr(model, "final_%d" % j)
+        o = torch.empty((b, model.n_classes, h0, w0), dtype=torch.float32, device=x.device)
+        ops.head_fwd(X[(0, j)], head.weight.detach().view(model.n_classes, -1), head.bias.detach(), p_drop,
+                     seeds[j - 1], None if masks is None else masks[j - 1], o)
+        outs.append(o)
+    if not save:
+        return outs, None
+    s = _Saved()
+    s.x_nhwc, s.X, s.pairs, s.ups, s.outs = x_nhwc, X, pairs, ups, outs
+    s.p_drop, s.seeds, s.masks = p_drop, seeds, masks
+    s.shape = (b, h0, w0)
+    return outs, s
+
+
+# ----------------------------------------------------------------------------- backward pieces
+class _GradBook:
+    """Gradient buffers of the node outputs; tracks whether a buffer already holds a contribution."""
+
+    def __init__(self, X):
+        self.X = X
+        self.buf: Dict[Tuple[int, int], torch.Tensor] = {}
+
+    def target(self, key):
+        """(tensor, accumulate?) for the next contribution to d X[key]."""
+        if key in self.buf:
+            return self.buf[key], True
+        t = torch.empty_like(self.X[key])
+        self.buf[key] = t
+        return t, False
+
+    def take(self, key):
+        return self.buf.pop(key)
+
+
+def _conv_wgrad(conv, xs, dys, b, h, w, grads):
+    co, ci, kh, kw = conv.weight.shape
+    t = kh * kw
+    dw = torch.empty_like(conv.weight)
+    db = torch.empty_like(conv.bias)
+    ops.wgrad(b, h, w, t, xs, dys, dw, (1, t, ci * t, 0), db)
+    grads[conv.weight] = dw
+    grads[conv.bias] = db
+
+
+def _pair_bwd(blk, r: _PairRec, d_out, in_targets: Optional[List[V]], b, grads):
+    """Backward of models/unet.py:150-156.  d_out (gradient of r.out) is consumed.  in_targets: output views
+    for the gradient of every entry of r.ins (None = the inputs need no gradient)."""
+    conv1, conv2 = getattr(blk.conv1, "0"), getattr(blk.conv2, "0")
+    h, w = r.h, r.w
+    if blk.is_batchnorm:
+        bn1, bn2 = getattr(blk.conv1, "1"), getattr(blk.conv2, "1")
+        mean, invstd, scale, shift = r.bn2
+        dg, dbt = ops.bn_backward(d_out, r.y2, scale, shift, mean, invstd, bn2.weight.detach(), d_out)
+        grads[bn2.weight], grads[bn2.bias] = dg, dbt
+        dy2 = V(d_out)
+        _conv_wgrad(conv2, [V(r.a1)], [dy2], b, h, w, grads)
+        d_a1 = torch.empty_like(r.a1)
+        ops.gemm_fwd(b, h, w, 9, [dy2], [V(d_a1)], pack_conv_dgrad(conv2.weight.detach()))
+        mean, invstd, scale, shift = r.bn1
+        dg, dbt = ops.bn_backward(d_a1, r.y1, scale, shift, mean, invstd, bn1.weight.detach(), d_a1)
+        grads[bn1.weight], grads[bn1.bias] = dg, dbt
+        dy1 = V(d_a1)
+    else:
+        dy2 = V(d_out, gate=r.out)  # ReLU backward folded into the operand load
+        _conv_wgrad(conv2, [V(r.a1)], [dy2], b, h, w, grads)
+        d_a1 = torch.empty_like(r.a1)
+        ops.gemm_fwd(b, h, w, 9, [dy2], [V(d_a1, gate=r.a1)], pack_conv_dgrad(conv2.weight.detach()))
+        dy1 = V(d_a1)
+    _conv_wgrad(conv1, r.ins, [dy1], b, h, w, grads)
+    if in_targets is not None:
+        ops.gemm_fwd(b, h, w, 9, [dy1], in_targets, pack_conv_dgrad(conv1.weight.detach()))
+
+
+def _up_bwd(upmod, is_deconv, u: _UpRec, d_up, d_src, accumulate, b, grads):
+    hs, ws = u.h, u.w
+    if is_deconv:
+        ci, co = upmod.weight.shape[0], upmod.weight.shape[1]
+        dw = torch.empty_like(upmod.weight)
+        db = torch.empty_like(upmod.bias)
+        ops.wgrad(b, hs, ws, 1, [V(u.src)], _phase_views(d_up), dw, (0, 4 * co, 4, 1), db, n_inner=co)
+        grads[upmod.weight], grads[upmod.bias] = dw, db
+        ops.gemm_fwd(b, hs, ws, 1, _phase_views(d_up), [V(d_src, accumulate=accumulate)],
+                     pack_deconv_dgrad(upmod.weight.detach()))
+    else:
+        conv = getattr(upmod, "1")
+        _conv_wgrad(conv, [V(u.interp)], [V(d_up)], b, 2 * hs, 2 * ws, grads)
+        d_interp = torch.empty_like(u.interp)
+        ops.gemm_fwd(b, 2 * hs, 2 * ws, 1, [V(d_up)], [V(d_interp)], pack_conv_dgrad(conv.weight.detach()))
+        ops.bilinear2x_bwd(d_interp, d_src, accumulate)
+
+
+def backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=None):
+    """Returns (dict param -> grad, dx NHWC or None).  grad_sink(list of (param, grad)) is called each time a
+    node's parameter gradients are final (used by the data-parallel bucketed all-reduce)."""
+    b, h0, w0 = s.shape
+    d = model.depth
+    grads: Dict[torch.nn.Parameter, torch.Tensor] = {}
+    book = _GradBook(s.X)
+    seen = set()
+
+    def flush():
+        if grad_sink is not None:
+            fresh = [(p, g) for p, g in grads.items() if id(p) not in seen]
+            seen.update(id(p) for p, _ in fresh)
+            if fresh:
+                grad_sink(fresh)
+
+    for j in range(d - 1, 0, -1):  # heads: the first contribution to d X[0][j]
+        head = getattr(model, "final_%d" % j)
+        go = d_outs[j - 1]
+        if go is None:
+            go = torch.zeros_like(s.outs[j - 1])
+        go = go.contiguous()
+        dx, acc = book.target((0, j))
+        dw, db = ops.head_bwd(go, s.outs[j - 1], s.X[(0, j)], head.weight.detach().view(model.n_classes, -1), s.p_drop,
+                              s.seeds[j - 1], None if s.masks is None else s.masks[j - 1], dx, acc)
+        grads[head.weight], grads[head.bias] = dw.contiguous(), db.contiguous()
+    flush()
+    for j in range(d - 1, 0, -1):  # decoder columns, last column first
+        for i in range(d - 1 - j, -1, -1):
+            mod = getattr(model, "up_concat%d%d" % (i, j))
+            r, u = s.pairs[(i, j)], s.ups[(i, j)]
+            d_out = book.take((i, j))
+            d_up = torch.empty_like(u.up)
+            targets = [V(d_up)]
+            for jj in range(j):
+                t, acc = book.target((i, jj))
+                targets.append(V(t, accumulate=acc))
+            _pair_bwd(mod.conv, r, d_out, targets, b, grads)
+            t, acc = book.target((i + 1, j - 1))
+            _up_bwd(mod.up, model.is_deconv, u, d_up, t, acc, b, grads)
+            flush()
+    dx_in = None
+    for i in range(d - 1, -1, -1):  # encoder column, deepest first
+        blk = getattr(model, "conv%d0" % i)
+        r = s.pairs[(i, 0)]
+        d_out = book.take((i, 0))
+        if i > 0:
+            d_pooled = torch.empty_like(s.pairs[(i - 1, 0)].pooled)
+            _pair_bwd(blk, r, d_out, [V(d_pooled)], b, grads)
+            prev = s.pairs[(i - 1, 0)]
+            ops.maxpool_bwd(d_pooled, prev.pool_idx, book.buf[(i - 1, 0)])
+        elif want_input_grad:
+            dx_in = torch.empty_like(s.x_nhwc)
+            _pair_bwd(blk, r, d_out, [V(dx_in)], b, grads)
+        else:
+            _pair_bwd(blk, r, d_out, None, b, grads)
+        flush()
+    return grads, dx_in
+
+
+class _UNetNestedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        outs, saved = forward_impl(model, x, model.training, save=True)
+        ctx.model, ctx.saved = model, saved
+        ctx.params = params
+        return tuple(outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *d_outs):
+        model, saved = ctx.model, ctx.saved
+        if saved is None:
+            raise RuntimeError("UNet_Nested (HIP): backward called twice on the same forward")
+        ctx.saved = None
+        sink = getattr(model, "_grad_sink", None)
+        grads, dx = backward_impl(model, saved, d_outs, ctx.needs_input_grad[1], sink)
+        dx_nchw = None
+        if dx is not None:
+            dx_nchw = ops.nhwc_to_nchw(dx)
+        done = getattr(model, "_grad_done", None)
+        if done is not None:
+            done()
+        return (None, dx_nchw) + tuple(grads.get(p) if need else None
+                                      for p, need in zip(ctx.params, ctx.needs_input_grad[2:]))
+
+
+def run(model, x):
+    """The body of UNet_Nested.forward."""
+    params = tuple(model.parameters())
+    track = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+    if track:
+        return _UNetNestedFn.apply(model, x, *params)
+    outs, _ = forward_impl(model, x, model.training, save=False)
+    return tuple(outs)

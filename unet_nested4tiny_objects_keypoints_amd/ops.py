@@ -1,0 +1,228 @@
+"""Tensor-facing wrappers over the C ABI (include/unetpp_hip.h).
+
+Every function takes CUDA(HIP) fp32 tensors owned by PyTorch, hands raw pointers, sizes and the
+current HIP stream to the library, and returns immediately (asynchronous on that stream).  PyTorch
+here is plumbing only: device memory and the stream.  Activations are NHWC ``[N, H, W, C]``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import MAX_VIEWS, GemmDesc, View, WgradDesc, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _need(t: torch.Tensor, what: str, dtype=torch.float32):
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU: this path has no CPU fallback" % what)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (what, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % what)
+    return t
+
+
+@dataclass
+class V:
+    """A channel slice of an NHWC tensor, optionally on a strided pixel grid (struct unetpp_view)."""
+    t: torch.Tensor
+    c_off: int = 0
+    c_len: Optional[int] = None
+    sy: int = 1
+    sx: int = 1
+    oy: int = 0
+    ox: int = 0
+    scale: Optional[torch.Tensor] = None
+    shift: Optional[torch.Tensor] = None
+    gate: Optional[torch.Tensor] = None
+    relu: bool = False
+    accumulate: bool = False
+
+    def fill(self, dst: View) -> int:
+        t = _need(self.t, "view tensor")
+        if t.dim() != 4:
+            raise ValueError("view tensor must be NHWC [N,H,W,C]")
+        c = t.shape[3]
+        n = c - self.c_off if self.c_len is None else self.c_len
+        dst.ptr = t.data_ptr()
+        dst.C, dst.c_off, dst.c_len = c, self.c_off, n
+        dst.Hs, dst.Ws = t.shape[1], t.shape[2]
+        dst.sy, dst.sx, dst.oy, dst.ox = self.sy, self.sx, self.oy, self.ox
+        dst.scale = None if self.scale is None else _need(self.scale, "scale").data_ptr()
+        dst.shift = None if self.shift is None else _need(self.shift, "shift").data_ptr()
+        if self.gate is not None:
+            g = _need(self.gate, "gate")
+            if g.shape != t.shape:
+                raise ValueError("gate must have the geometry of the gated tensor")
+            dst.gate = g.data_ptr()
+        else:
+            dst.gate = None
+        dst.relu = int(self.relu)
+        dst.accumulate = int(self.accumulate)
+        return n
+
+
+def gemm_pixel_blocks(n: int, h: int, w: int) -> int:
+    return int(_lib.lib().unetpp_gemm_pixel_blocks(n, h, w))
+
+
+def gemm_fwd(n: int, h: int, w: int, taps: int, ins: Sequence[V], outs: Sequence[V], weight: torch.Tensor,
+             bias: Optional[torch.Tensor] = None, stats_partial: Optional[torch.Tensor] = None) -> None:
+    if len(ins) > MAX_VIEWS or len(outs) > MAX_VIEWS:
+        raise ValueError("too many views")
+    d = GemmDesc()
+    d.N, d.H, d.W, d.taps = n, h, w, taps
+    d.n_in, d.n_out = len(ins), len(outs)
+    k = sum(v.fill(d.inp[i]) for i, v in enumerate(ins))
+    nc = sum(v.fill(d.out[i]) for i, v in enumerate(outs))
+    _need(weight, "packed weight")
+    if weight.numel() != taps * k * nc:
+        raise ValueError("packed weight has %d elements, expected %d*%d*%d" % (weight.numel(), taps, k, nc))
+    if bias is not None and _need(bias, "bias").numel() != nc:
+        raise ValueError("bias length mismatch")
+    if stats_partial is not None and _need(stats_partial, "stats").numel() != gemm_pixel_blocks(n, h, w) * nc * 2:
+        raise ValueError("stats_partial size mismatch")
+    d.weight = weight.data_ptr()
+    d.bias = None if bias is None else bias.data_ptr()
+    d.stats_partial = None if stats_partial is None else stats_partial.data_ptr()
+    check(_lib.lib().unetpp_gemm_fwd(C.byref(d), _stream()), "unetpp_gemm_fwd")
+
+
+def pack_weight(dst: torch.Tensor, src: torch.Tensor, t: int, k: int, n: int, dstr, sstr, flip: bool = False) -> None:
+    _need(dst, "pack dst")
+    _need(src, "pack src")
+    check(_lib.lib().unetpp_pack_weight(_ptr(dst), _ptr(src), t, k, n, dstr[0], dstr[1], dstr[2],
+                                        sstr[0], sstr[1], sstr[2], int(flip), _stream()), "unetpp_pack_weight")
+
+
+def wgrad(n: int, h: int, w: int, taps: int, xs: Sequence[V], dys: Sequence[V], dw: Optional[torch.Tensor],
+          dw_strides, db: Optional[torch.Tensor], n_inner: Optional[int] = None, target_blocks: int = 1024) -> None:
+    """dw / db are written (not accumulated).  dw_strides = (d_t, d_k, d_n, d_o) into the torch-layout gradient."""
+    lib = _lib.lib()
+    d = WgradDesc()
+    d.N, d.H, d.W, d.taps = n, h, w, taps
+    d.n_x, d.n_dy = len(xs), len(dys)
+    k = sum(v.fill(d.x[i]) for i, v in enumerate(xs))
+    nc = sum(v.fill(d.dy[i]) for i, v in enumerate(dys))
+    pairs = sum((v.c_len + 31) // 32 for v in d.x[:len(xs)]) * sum((v.c_len + 31) // 32 for v in d.dy[:len(dys)])
+    split = max(1, min(int(lib.unetpp_wgrad_max_split(n, h, w)), target_blocks // max(1, pairs)))
+    slabs = torch.empty(split * (taps * k + 1) * nc, dtype=torch.float32, device=xs[0].t.device)
+    d.n_split = split
+    d.slabs = slabs.data_ptr()
+    check(lib.unetpp_wgrad(C.byref(d), _stream()), "unetpp_wgrad")
+    if n_inner is None:
+        n_inner = nc
+    check(lib.unetpp_wgrad_finish(_ptr(slabs), split, taps, k, nc, n_inner, _ptr(dw), dw_strides[0], dw_strides[1],
+                                  dw_strides[2], dw_strides[3], _ptr(db), _stream()), "unetpp_wgrad_finish")
+
+
+def bn_finalize(partial, n_blocks, c, count, gamma, beta, eps, momentum, running_mean, running_var):
+    dev = partial.device
+    mean, invstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(4))
+    check(_lib.lib().unetpp_bn_finalize(_ptr(partial), n_blocks, c, count, _ptr(gamma), _ptr(beta), eps, momentum,
+                                        _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(invstd), _ptr(scale),
+                                        _ptr(shift), _stream()), "unetpp_bn_finalize")
+    return mean, invstd, scale, shift
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
+    c = gamma.numel()
+    scale, shift = (torch.empty(c, dtype=torch.float32, device=gamma.device) for _ in range(2))
+    check(_lib.lib().unetpp_bn_eval_coeffs(_ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), eps, c,
+                                           _ptr(scale), _ptr(shift), _stream()), "unetpp_bn_eval_coeffs")
+    return scale, shift
+
+
+def affine_relu_pool(y, scale, shift, relu, act, pooled, pool_idx):
+    n, h, w, c = y.shape
+    check(_lib.lib().unetpp_affine_relu_pool(_ptr(y), _ptr(scale), _ptr(shift), int(relu), n, h, w, c, _ptr(act),
+                                             _ptr(pooled), _ptr(pool_idx), _stream()), "unetpp_affine_relu_pool")
+
+
+def maxpool_bwd(d_pooled, pool_idx, d_act):
+    n, h, w, c = d_act.shape
+    check(_lib.lib().unetpp_maxpool_bwd(_ptr(d_pooled), _ptr(pool_idx), n, h, w, c, _ptr(d_act), _stream()),
+          "unetpp_maxpool_bwd")
+
+
+def bn_backward(d_act, y, scale, shift, mean, invstd, gamma, dy_out):
+    """Training-mode BatchNorm+ReLU backward.  Returns (dgamma, dbeta); dy_out may alias d_act."""
+    lib = _lib.lib()
+    n, h, w, c = y.shape
+    pixels = n * h * w
+    blocks = int(lib.unetpp_bn_bwd_blocks(pixels, c))
+    partial = torch.empty(blocks * c * 2, dtype=torch.float32, device=y.device)
+    dgamma, dbeta = (torch.empty(c, dtype=torch.float32, device=y.device) for _ in range(2))
+    st = _stream()
+    check(lib.unetpp_bn_bwd_reduce(_ptr(d_act), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), pixels, c,
+                                   _ptr(partial), st), "unetpp_bn_bwd_reduce")
+    check(lib.unetpp_bn_bwd_finalize(_ptr(partial), blocks, c, _ptr(dgamma), _ptr(dbeta), st), "unetpp_bn_bwd_finalize")
+    check(lib.unetpp_bn_bwd_apply(_ptr(d_act), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                  _ptr(dgamma), _ptr(dbeta), pixels, c, _ptr(dy_out), st), "unetpp_bn_bwd_apply")
+    return dgamma, dbeta
+
+
+def head_fwd(x, weight, bias, p_drop, seed, mask, out_nchw):
+    n, h, w, c = x.shape
+    n_cls = weight.shape[0]
+    check(_lib.lib().unetpp_head_fwd(_ptr(x), _ptr(weight), _ptr(bias), n, h, w, c, n_cls, float(p_drop),
+                                     C.c_uint64(seed), _ptr(mask), _ptr(out_nchw), _stream()), "unetpp_head_fwd")
+
+
+def head_bwd(d_out, out, x, weight, p_drop, seed, mask, dx, accumulate):
+    """Returns (dW [n_cls, C, 1, 1], db [n_cls]); dx is written or accumulated in place."""
+    lib = _lib.lib()
+    n, h, w, c = x.shape
+    n_cls = weight.shape[0]
+    blocks = int(lib.unetpp_head_bwd_blocks(n * h * w))
+    ln = n_cls * c + n_cls
+    partial = torch.empty(blocks * ln, dtype=torch.float32, device=x.device)
+    sums = torch.empty(ln, dtype=torch.float32, device=x.device)
+    st = _stream()
+    check(lib.unetpp_head_bwd(_ptr(d_out), _ptr(out), _ptr(x), _ptr(weight), n, h, w, c, n_cls, float(p_drop),
+                              C.c_uint64(seed), _ptr(mask), _ptr(dx), int(accumulate), _ptr(partial), st),
+          "unetpp_head_bwd")
+    check(lib.unetpp_sum_partials(_ptr(partial), blocks, ln, _ptr(sums), st), "unetpp_sum_partials")
+    return sums[:n_cls * c].view(n_cls, c, 1, 1), sums[n_cls * c:]
+
+
+def bilinear2x_fwd(x, y):
+    n, h, w, c = x.shape
+    check(_lib.lib().unetpp_bilinear2x_fwd(_ptr(x), n, h, w, c, _ptr(y), _stream()), "unetpp_bilinear2x_fwd")
+
+
+def bilinear2x_bwd(dy, dx, accumulate):
+    n, h, w, c = dx.shape
+    check(_lib.lib().unetpp_bilinear2x_bwd(_ptr(dy), n, h, w, c, _ptr(dx), int(accumulate), _stream()),
+          "unetpp_bilinear2x_bwd")
+
+
+def nchw_to_nhwc(src):
+    n, c, h, w = src.shape
+    _need(src, "input")
+    if c == 1:
+        return src.view(n, h, w, 1)  # same bytes
+    dst = torch.empty((n, h, w, c), dtype=torch.float32, device=src.device)
+    check(_lib.lib().unetpp_nchw_to_nhwc(_ptr(src), n, c, h, w, _ptr(dst), _stream()), "unetpp_nchw_to_nhwc")
+    return dst
+
+
+def nhwc_to_nchw(src):
+    n, h, w, c = src.shape
+    if c == 1:
+        return src.view(n, 1, h, w)
+    dst = torch.empty((n, c, h, w), dtype=torch.float32, device=src.device)
+    check(_lib.lib().unetpp_nhwc_to_nchw(_ptr(src), n, c, h, w, _ptr(dst), _stream()), "unetpp_nhwc_to_nchw")
+    return dst

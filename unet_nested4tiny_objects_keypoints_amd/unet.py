@@ -1,0 +1,152 @@
+"""Drop-in ``UNet_Nested`` for MI355X: the reference's module API over the HIP path.
+
+Mirrors ``/root/reference/models/unet.py:204-300`` at the ``torch.nn.Module`` boundary -- same
+constructor (``UNet_Nested(in_channels=3, n_classes=4, feature_scale=2, is_deconv=True,
+is_batchnorm=True, is_ds=True)``, constructible with zero arguments as ``trainer/trainer.py:337``
+does), same attributes, same ``forward(x) -> (final_1, final_2, final_3)`` tuple, and exactly the
+reference's ``state_dict`` key names and shapes, so a ``.pth`` written by either loads in the other.
+
+Nothing here executes a ``torch.nn`` layer.  The sub-modules below only *hold* parameters under the
+reference's names; all arithmetic runs in ``libunetpp_hip.so`` (see ``engine.py``).  ``depth`` (default
+4 = the reference as shipped) extends the topology along the reference's commented-out level-5 lines.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from . import engine
+
+_BASE_WIDTHS = (32, 64, 128, 256, 512)  # models/unet.py:215
+
+
+class ConvParams(nn.Module):
+    """weight [co, ci, k, k] + bias [co], named like nn.Conv2d's (models/unet.py:132,140,191,242)."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = cin, cout, k
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.empty(cout))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # weights: kaiming-normal fan_in (models/unet.py:165-169); bias keeps torch's default
+        # U(-1/sqrt(fan_in), 1/sqrt(fan_in)) because the reference never re-initialises biases.
+        fan_in = self.in_channels * self.kernel_size * self.kernel_size
+        with torch.no_grad():
+            self.weight.normal_(0.0, math.sqrt(2.0 / fan_in))
+            bound = 1.0 / math.sqrt(fan_in)
+            self.bias.uniform_(-bound, bound)
+
+
+class DeconvParams(nn.Module):
+    """weight [ci, co, 2, 2] + bias [co], named like nn.ConvTranspose2d's (models/unet.py:187)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.in_channels, self.out_channels = cin, cout
+        self.weight = nn.Parameter(torch.empty(cin, cout, 2, 2))
+        self.bias = nn.Parameter(torch.empty(cout))
+        fan_in = cout * 4  # torch's fan_in for a transposed-conv weight: size(1) * receptive field
+        with torch.no_grad():
+            self.weight.normal_(0.0, math.sqrt(2.0 / fan_in))
+            bound = 1.0 / math.sqrt(fan_in)
+            self.bias.uniform_(-bound, bound)
+
+
+class BatchNormParams(nn.Module):
+    """gamma/beta + running statistics, named like nn.BatchNorm2d's (models/unet.py:133)."""
+
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = c, eps, momentum
+        self.weight = nn.Parameter(torch.empty(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        with torch.no_grad():
+            self.weight.normal_(1.0, 0.02)  # models/unet.py:172-174
+
+
+class _Slot(nn.Module):
+    """Parameter-less placeholder that keeps nn.Sequential's child numbering (ReLU / Upsample slots)."""
+
+
+def _numbered(*mods):
+    holder = nn.Module()
+    for i, m in enumerate(mods):
+        holder.add_module(str(i), m)
+    return holder
+
+
+class unetConv2(nn.Module):
+    """Parameters of models/unet.py:121-156: conv{1,2}.0 = conv, conv{1,2}.1 = BN when is_batchnorm."""
+
+    def __init__(self, in_size, out_size, is_batchnorm, n=2):
+        super().__init__()
+        self.n, self.is_batchnorm = n, is_batchnorm
+        for i in range(1, n + 1):
+            mods = [ConvParams(in_size, out_size, 3)]
+            if is_batchnorm:
+                mods.append(BatchNormParams(out_size))
+            mods.append(_Slot())
+            self.add_module("conv%d" % i, _numbered(*mods))
+            in_size = out_size
+
+
+class unetUp(nn.Module):
+    """Parameters of models/unet.py:182-202: `up` (deconv, or [bilinear, conv1x1]) and the BN-less conv pair."""
+
+    def __init__(self, in_size, out_size, is_deconv, n_concat=2):
+        super().__init__()
+        self.conv = unetConv2(in_size + (n_concat - 2) * out_size, out_size, False)
+        if is_deconv:
+            self.up = DeconvParams(in_size, out_size)
+        else:
+            self.up = _numbered(_Slot(), ConvParams(in_size, out_size, 1))
+
+
+class UNet_Nested(nn.Module):
+
+    def __init__(self, in_channels=3, n_classes=4, feature_scale=2, is_deconv=True, is_batchnorm=True, is_ds=True,
+                 depth=4):
+        super().__init__()
+        if not 2 <= depth <= len(_BASE_WIDTHS):
+            raise ValueError("depth must be in 2..5")
+        self.in_channels = in_channels
+        self.n_classes = n_classes
+        self.feature_scale = feature_scale
+        self.is_deconv = is_deconv
+        self.is_batchnorm = is_batchnorm
+        self.is_ds = is_ds
+        self.depth = depth
+        filters = [int(x / self.feature_scale) for x in _BASE_WIDTHS]
+        if min(filters[:depth]) < 1:
+            raise ValueError("feature_scale too large")
+        self.filters = filters[:depth]
+
+        cin = in_channels
+        for i in range(depth):  # models/unet.py:220-224
+            setattr(self, "conv%d0" % i, unetConv2(cin, filters[i], is_batchnorm))
+            cin = filters[i]
+        for j in range(1, depth):  # :227-239
+            for i in range(depth - j):
+                setattr(self, "up_concat%d%d" % (i, j), unetUp(filters[i + 1], filters[i], is_deconv, j + 1))
+        for j in range(1, depth):  # :242-245
+            setattr(self, "final_%d" % j, ConvParams(filters[0], n_classes, 1))
+        # Configuration holder only (p and train/eval state are read by the engine; it is never called).
+        self.drop_out = nn.Dropout(p=0.4)  # :254
+        # Test hook: list of uint8 NHWC keep-masks (one per head) used instead of the in-kernel generator.
+        self.dropout_masks = None
+
+    def forward(self, inputs):
+        return engine.run(self, inputs)
+
+
+def count_param(model):
+    """models/unet.py:176-180"""
+    return sum(p.numel() for p in model.parameters())
