@@ -68,7 +68,7 @@ __device__ __forceinline__ f32x4 view_load4(const unetpp_view& v, long off, int 
   if (v.scale != nullptr) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (i < rem) val[i] = val[i] * v.scale[c + i] + v.shift[c + i];
+      if (i < rem) val[i] = fmaf(val[i], v.scale[c + i], v.shift[c + i]);
   }
   if (v.relu) {
 #pragma unroll

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kThreads) void affine_relu_kernel(const float* __re
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       float t = lane_of<VEC>(v, k);
-      if (scale != nullptr) t = t * scale[c + k] + shift[c + k];
+      if (scale != nullptr) t = fmaf(t, scale[c + k], shift[c + k]);
       if (relu) t = fmaxf(t, 0.f);
       lane_of<VEC>(v, k) = t;
     }
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kThreads) void affine_relu_pool_kernel(const float*
 #pragma unroll
       for (int k = 0; k < VEC; ++k) {
         float t = lane_of<VEC>(v, k);
-        if (scale != nullptr) t = t * scale[c + k] + shift[c + k];
+        if (scale != nullptr) t = fmaf(t, scale[c + k], shift[c + k]);
         if (relu) t = fmaxf(t, 0.f);
         lane_of<VEC>(v, k) = t;
         if (q == 0 || t > best[k]) {  // first maximum wins, scan order (0,0),(0,1),(1,0),(1,1)
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(const float* __
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       const float yy = lane_of<VEC>(v, k);
-      const float gg = (yy * sc[k] + sh[k] > 0.f) ? lane_of<VEC>(g, k) : 0.f;
+      const float gg = (fmaf(yy, sc[k], sh[k]) > 0.f) ? lane_of<VEC>(g, k) : 0.f;
       s1[k] += gg;
       s2[k] += gg * (yy - mu[k]) * is[k];
     }
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* __r
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       const float yy = lane_of<VEC>(v, k);
-      const float gg = (yy * scale[c + k] + shift[c + k] > 0.f) ? lane_of<VEC>(g, k) : 0.f;
+      const float gg = (fmaf(yy, scale[c + k], shift[c + k]) > 0.f) ? lane_of<VEC>(g, k) : 0.f;
       const float xhat = (yy - mean[c + k]) * invstd[c + k];
       lane_of<VEC>(out, k) =
           gamma[c + k] * invstd[c + k] * (gg - dbeta[c + k] * inv_count - xhat * dgamma[c + k] * inv_count);

@@ -370,6 +370,8 @@ class _UNetNestedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, *params):
         outs, saved = forward_impl(model, x, model.training, save=True)
+        if getattr(model, "_debug_keep_saved", False):  # test hook: expose the activations kept for backward
+            model._debug_saved = saved
         ctx.model, ctx.saved = model, saved
         ctx.params = params
         return tuple(outs)
