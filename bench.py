@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: images/sec of one full training step of UNet_Nested on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+UNet_Nested(in_channels=1, n_classes=4, feature_scale=1) = depth 4, base width 32, 256x256, batch 32 PER GPU,
+fp32, synthetic data (seed 0: x ~ N(0,1), target ~ U(0,1)), weights from the module's own kaiming init.
+One "step" is the reference's loop body (trainer/trainer.py:114-136): zero_grad + forward (dropout active)
++ FocalLoss_BCE_2d on the 3 heads + mean + backward + Adam step (+ gradient all-reduce when N > 1).
+Weak scaling: the per-GPU batch is fixed; `value` is global images/sec.
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      the dominant kernel (most device time) timed live with HIP events on the launch stream over the
+                timed steps: achieved = algorithmic FLOP of its launches / their summed duration, against the
+                dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).  `traffic` (HBM bytes from PMC
+                counters) cannot be collected from inside the process: see profiles/ for the rocprofv3 runs.
+  roofline_x00  the X_0,0 conv block forward (1.2457 GFLOP and 42.2 MB algorithmic per image):
+                frac = max(compute floor, HBM floor) / measured block time.
+  cpu_baseline  the CPU oracle (oracle/, a PyTorch restatement of the reference proven equal to it on golden
+                fixtures) timed on this host's cores on a bounded sample of the same workload (batch 4).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_TBS = 8.0
+X00_GFLOP_PER_IMG = 1.2457
+X00_MB_PER_IMG = 42.2
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (configs[1]: 32)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--feature-scale", type=float, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-launch-timing", action="store_true", help="skip per-launch HIP events (roofline = null)")
+    return ap.parse_args()
+
+
+def usable_cores():
+    """Cores this process may actually use: affinity mask and cgroup CPU quota, not the host's core count
+    (a 1-GPU box exposes 256 logical CPUs but grants a share of them; 256 threads on a 16-CPU quota thrash)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, int(q / int(f.read()))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return min(n, int(os.environ.get("UNETPP_CPU_THREADS", "16")))
+
+
+def cpu_baseline(args, n_cls):
+    """The oracle's train step (trainer/trainer.py:114-136 restated) on the host cores, batch 4."""
+    import torch
+
+    from oracle.step_oracle import focal_bce_2d_oracle
+    from oracle.unet_nested_oracle import UNetNestedOracle
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    fs = int(args.feature_scale) if float(args.feature_scale).is_integer() else args.feature_scale
+    model = UNetNestedOracle(in_channels=1, n_classes=n_cls, feature_scale=fs).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    b = 4
+    x = torch.randn(b, 1, args.size, args.size)
+    target = torch.rand(b, n_cls, args.size, args.size)
+
+    def step():
+        opt.zero_grad()
+        outs = model(x)
+        loss = sum(focal_bce_2d_oracle(o, target) for o in outs) / len(outs)
+        loss.backward()
+        opt.step()
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        step()
+    dt = time.perf_counter() - t0
+    model.eval()
+    with torch.no_grad():
+        model(x)
+        t1 = time.perf_counter()
+        model(x)
+        fwd = time.perf_counter() - t1
+    return {
+        "value": round(b * args.cpu_steps / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+        "torch_threads": torch.get_num_threads(),
+        "fwd_ms_per_img": round(1e3 * fwd / b, 3),
+        "sample": "%d timed train steps (+1 warm-up) of the CPU oracle at batch %d, %dx%d, base width %d, fp32, Adam"
+                  % (args.cpu_steps, b, args.size, args.size, int(32 / args.feature_scale)),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus != world and rank == 0 and distributed:
+        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if distributed:
+        dist.barrier()
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, UNet_Nested, dp, ops, train_step
+
+    n_cls = 4
+    fs = int(args.feature_scale) if float(args.feature_scale).is_integer() else args.feature_scale
+    torch.manual_seed(0)
+    model = UNet_Nested(in_channels=1, n_classes=n_cls, feature_scale=fs).to(dev).train()
+    averager = None
+    if distributed:
+        averager = dp.make_data_parallel(model)
+    torch.manual_seed(1000 + rank)  # every rank its own shard of synthetic data
+    x = torch.randn(args.batch, 1, args.size, args.size, device=dev)
+    target = torch.rand(args.batch, n_cls, args.size, args.size, device=dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+
+    for _ in range(args.warmup):
+        train_step(model, opt, crit, x, target)
+
+    timer = None
+    if rank == 0 and not args.no_launch_timing:
+        timer = ops.LaunchTimer()
+        ops.set_timer(timer)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        train_step(model, opt, crit, x, target)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ops.set_timer(None)
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # eval-mode forward latency (the reference's "high-speed inference" claim; BASELINE metric part 2)
+    model.eval()
+    with torch.no_grad():
+        for _ in range(2):
+            model(x)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            model(x)
+        torch.cuda.synchronize()
+        fwd_ms_per_img = 1e3 * (time.perf_counter() - t1) / (reps * args.batch)
+    model.train()
+
+    if rank != 0:
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * args.batch * args.steps / elapsed
+    roofline, roofline_x00, kernels = None, None, None
+    if timer is not None:
+        launches, regions = timer.summary()
+        kernels = {k: {"launches_per_step": v["launches"] / args.steps, "ms_per_step": round(v["ms"] / args.steps, 3),
+                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in launches.items()}
+        dom = max(launches.items(), key=lambda kv: kv[1]["ms"])
+        ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
+        roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": dom[1]["launches"] / args.steps,
+                    "avg_launch_ms": round(dom[1]["ms"] / dom[1]["launches"], 4),
+                    "flop_per_launch_avg": dom[1]["flops"] / dom[1]["launches"]}
+        if "X00.fwd" in regions and args.size == 256 and fs == 1:
+            t_img_us = 1e3 * regions["X00.fwd"]["ms"] / regions["X00.fwd"]["count"] / args.batch
+            floor_c = X00_GFLOP_PER_IMG * 1e9 / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e6
+            floor_h = X00_MB_PER_IMG * 1e6 / (PEAK_HBM_TBS * 1e12) * 1e6
+            roofline_x00 = {"block": "X_0,0 forward (conv-BN-ReLU x2 + pool, train mode)",
+                            "us_per_img": round(t_img_us, 2), "floor_compute_us": round(floor_c, 2),
+                            "floor_hbm_us": round(floor_h, 2), "bound": "mfma" if floor_c >= floor_h else "hbm",
+                            "frac": round(max(floor_c, floor_h) / t_img_us, 4)}
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, n_cls)
+    line = {
+        "metric": "images/sec (train step) UNet++ L=4 256x256",
+        "value": round(value, 2),
+        "unit": "images/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "UNet_Nested(in=1,n_classes=4,base=%d,depth=4) %dx%d train step, batch %d/GPU, "
+                               "FocalLoss_BCE_2d on 3 heads, Adam, dropout p=0.4 active"
+                               % (int(32 / args.feature_scale), args.size, args.size, args.batch),
+                   "global_batch": world * args.batch, "per_gpu_batch": args.batch,
+                   "parallelism": "dp%d" % world if distributed else "single",
+                   "grad_allreduce_buckets": None if averager is None else len(averager.buckets_last_step)},
+        "fwd_ms_per_img": round(fwd_ms_per_img, 4),
+        "roofline": roofline,
+        "roofline_x00": roofline_x00,
+        "kernels": kernels,
+        "cpu_baseline": cpu,
+    }
+    if cpu is not None:
+        line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+    print(json.dumps(line))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

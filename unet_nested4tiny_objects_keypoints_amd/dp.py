@@ -1,0 +1,161 @@
+"""Data-parallel training: one process per GPU, gradients averaged with bucketed all-reduces (RCCL over xGMI)
+that overlap the remaining backward kernels.
+
+Replaces the reference's single-process ``torch.nn.DataParallel`` (trainer/trainer.py:336-340), which
+re-broadcasts every parameter each forward and reduce-adds every gradient onto GPU 0.  Here parameters stay
+replicated (one broadcast at start-up), BatchNorm statistics stay per replica exactly as under DataParallel,
+and the only exchange per step is the gradient average:
+
+  * all parameter gradients live in ONE flat fp32 buffer laid out in gradient-ready order (heads, X_03,
+    X_12, X_02, X_21, X_11, X_01, X_30 .. X_00 -- SURVEY.md section 3c), the wgrad kernels write straight into
+    it (engine._new_grad), so a bucket is a contiguous slice and needs no packing copy;
+  * whenever the engine reports a node's gradients final and the open bucket has reached ``bucket_bytes``,
+    the slice is all-reduced on a side stream behind an event; backward keeps launching kernels meanwhile;
+  * the compute stream joins the side stream once, at the end of backward.
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): 8.8 MB of gradients (BASELINE configs[1]/[2]) is
+latency-bound, so the default is few, large buckets (2 MiB) rather than many small ones.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def ready_order(model) -> List[torch.nn.Parameter]:
+    """Parameters in the order engine.backward_impl finishes their gradients."""
+    d = model.depth
+    out: List[torch.nn.Parameter] = []
+
+    def pair(blk):
+        # backward runs conv2 (+BN2) before conv1 (+BN1)
+        for name in ("conv2", "conv1"):
+            seq = getattr(blk, name)
+            if blk.is_batchnorm:
+                bn = getattr(seq, "1")
+                out.extend([bn.weight, bn.bias])
+            conv = getattr(seq, "0")
+            out.extend([conv.weight, conv.bias])
+
+    for j in range(d - 1, 0, -1):
+        head = getattr(model, "final_%d" % j)
+        out.extend([head.weight, head.bias])
+    for j in range(d - 1, 0, -1):
+        for i in range(d - 1 - j, -1, -1):
+            mod = getattr(model, "up_concat%d%d" % (i, j))
+            pair(mod.conv)
+            up = mod.up if model.is_deconv else getattr(mod.up, "1")
+            out.extend([up.weight, up.bias])
+    for i in range(d - 1, -1, -1):
+        pair(getattr(model, "conv%d0" % i))
+    assert len(out) == len(list(model.parameters())) and len({id(p) for p in out}) == len(out)
+    return out
+
+
+class GradientAverager:
+    """Flat gradient buffer + bucketed, overlapped all-reduce.  Works on any backend (nccl = RCCL on ROCm;
+    gloo on CPU for tests, where the 'side stream' degenerates to in-order execution)."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], process_group=None, bucket_bytes: int = 2 << 20):
+        self.params = list(params)
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        dev = self.params[0].device
+        self.cuda = dev.type == "cuda"
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offset = {}
+        off = 0
+        for p in self.params:
+            self.offset[id(p)] = off
+            off += p.numel()
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.stream = torch.cuda.Stream(device=dev) if self.cuda else None
+        self._ready_upto = 0     # elements of `flat` whose gradients are final
+        self._sent_upto = 0      # elements already handed to an all-reduce
+        self._pending = set()
+        self._works = []
+        self.buckets_last_step: List[Tuple[int, int]] = []
+
+    # ---- hooks installed on the model -------------------------------------------------------
+    def alloc(self, p):
+        o = self.offset[id(p)]
+        return self.flat[o:o + p.numel()].view(p.shape)
+
+    def sink(self, fresh):
+        """fresh: [(param, grad)] whose gradients just became final (any order within the call)."""
+        for p, _ in fresh:
+            self._pending.add(id(p))
+        # advance the contiguous "ready" frontier along the flat layout
+        idx = self._frontier_index
+        while idx < len(self.params) and id(self.params[idx]) in self._pending:
+            self._ready_upto += self.params[idx].numel()
+            idx += 1
+        self._frontier_index = idx
+        if self._ready_upto - self._sent_upto >= self.bucket_elems:
+            self._launch(self._ready_upto)
+
+    def done(self):
+        """End of backward: flush the tail bucket and make the compute stream wait for the averages."""
+        if self._frontier_index != len(self.params):
+            raise RuntimeError("backward finished but %d parameter gradients were never reported"
+                               % (len(self.params) - self._frontier_index))
+        if self._sent_upto < self._ready_upto:
+            self._launch(self._ready_upto)
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        else:
+            for w in self._works:
+                w.wait()
+        self._works = []
+        self._begin()
+
+    # ---- internals --------------------------------------------------------------------------------
+    def _begin(self):
+        self._ready_upto = 0
+        self._sent_upto = 0
+        self._frontier_index = 0
+        self._pending = set()
+
+    def _launch(self, upto):
+        chunk = self.flat[self._sent_upto:upto]
+        self.buckets_last_step.append((self._sent_upto, upto))
+        self._sent_upto = upto
+        if self.world == 1:
+            return
+        if self.cuda:
+            self.stream.wait_stream(torch.cuda.current_stream())  # the slice's wgrad kernels are enqueued before this
+            with torch.cuda.stream(self.stream):
+                dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+                chunk.div_(self.world)
+        else:
+            w = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w.wait()
+            chunk.div_(self.world)
+
+    def attach(self, model):
+        self._begin()
+        self.buckets_last_step = []
+        model._grad_alloc = self.alloc
+        model._grad_sink = self._sink_and_log
+        model._grad_done = self.done
+        return self
+
+    def _sink_and_log(self, fresh):
+        if self._frontier_index == 0 and self._ready_upto == 0:
+            self.buckets_last_step = []
+        self.sink(fresh)
+
+
+def broadcast_parameters(model, src: int = 0, process_group=None) -> None:
+    """Identical start on every rank (DataParallel's per-forward replicate, done once)."""
+    for t in list(model.parameters()) + list(model.buffers()):
+        dist.broadcast(t.data, src=src, group=process_group)
+
+
+def make_data_parallel(model, process_group=None, bucket_bytes: int = 2 << 20) -> GradientAverager:
+    """Broadcast rank 0's parameters/buffers, then hook the gradient averager into the model's backward."""
+    broadcast_parameters(model, 0, process_group)
+    return GradientAverager(ready_order(model), process_group, bucket_bytes).attach(model)

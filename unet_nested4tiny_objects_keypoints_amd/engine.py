@@ -200,7 +200,8 @@ def forward_impl(model, x, training: bool, save: bool):
     ups: Dict[Tuple[int, int], _UpRec] = {}
     inp, h, w = x_nhwc, h0, w0
     for i in range(d):  # encoder column (:257-265)
-        r = _pair_fwd(getattr(model, "conv%d0" % i), [V(inp)], b, h, w, training, pool=(i < d - 1))
+        with ops.region("X%d0.fwd" % i):
+            r = _pair_fwd(getattr(model, "conv%d0" % i), [V(inp)], b, h, w, training, pool=(i < d - 1))
         pairs[(i, 0)], X[(i, 0)] = r, r.out
         if i < d - 1:
             inp, h, w = r.pooled, h // 2, w // 2
@@ -249,11 +250,18 @@ class _GradBook:
         return self.buf.pop(key)
 
 
+_ALLOC = [None]  # set for the duration of one backward: param -> gradient buffer (data-parallel flat buffer)
+
+
+def _new_grad(p):
+    return torch.empty_like(p) if _ALLOC[0] is None else _ALLOC[0](p)
+
+
 def _conv_wgrad(conv, xs, dys, b, h, w, grads):
     co, ci, kh, kw = conv.weight.shape
     t = kh * kw
-    dw = torch.empty_like(conv.weight)
-    db = torch.empty_like(conv.bias)
+    dw = _new_grad(conv.weight)
+    db = _new_grad(conv.bias)
     ops.wgrad(b, h, w, t, xs, dys, dw, (1, t, ci * t, 0), db)
     grads[conv.weight] = dw
     grads[conv.bias] = db
@@ -267,14 +275,16 @@ def _pair_bwd(blk, r: _PairRec, d_out, in_targets: Optional[List[V]], b, grads):
     if blk.is_batchnorm:
         bn1, bn2 = getattr(blk.conv1, "1"), getattr(blk.conv2, "1")
         mean, invstd, scale, shift = r.bn2
-        dg, dbt = ops.bn_backward(d_out, r.y2, scale, shift, mean, invstd, bn2.weight.detach(), d_out)
+        dg, dbt = ops.bn_backward(d_out, r.y2, scale, shift, mean, invstd, bn2.weight.detach(), d_out,
+                                  _new_grad(bn2.weight), _new_grad(bn2.bias))
         grads[bn2.weight], grads[bn2.bias] = dg, dbt
         dy2 = V(d_out)
         _conv_wgrad(conv2, [V(r.a1)], [dy2], b, h, w, grads)
         d_a1 = torch.empty_like(r.a1)
         ops.gemm_fwd(b, h, w, 9, [dy2], [V(d_a1)], pack_conv_dgrad(conv2.weight.detach()))
         mean, invstd, scale, shift = r.bn1
-        dg, dbt = ops.bn_backward(d_a1, r.y1, scale, shift, mean, invstd, bn1.weight.detach(), d_a1)
+        dg, dbt = ops.bn_backward(d_a1, r.y1, scale, shift, mean, invstd, bn1.weight.detach(), d_a1,
+                                  _new_grad(bn1.weight), _new_grad(bn1.bias))
         grads[bn1.weight], grads[bn1.bias] = dg, dbt
         dy1 = V(d_a1)
     else:
@@ -292,8 +302,8 @@ def _up_bwd(upmod, is_deconv, u: _UpRec, d_up, d_src, accumulate, b, grads):
     hs, ws = u.h, u.w
     if is_deconv:
         ci, co = upmod.weight.shape[0], upmod.weight.shape[1]
-        dw = torch.empty_like(upmod.weight)
-        db = torch.empty_like(upmod.bias)
+        dw = _new_grad(upmod.weight)
+        db = _new_grad(upmod.bias)
         ops.wgrad(b, hs, ws, 1, [V(u.src)], _phase_views(d_up), dw, (0, 4 * co, 4, 1), db, n_inner=co)
         grads[upmod.weight], grads[upmod.bias] = dw, db
         ops.gemm_fwd(b, hs, ws, 1, _phase_views(d_up), [V(d_src, accumulate=accumulate)],
@@ -331,7 +341,12 @@ def backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=Non
         dx, acc = book.target((0, j))
         dw, db = ops.head_bwd(go, s.outs[j - 1], s.X[(0, j)], head.weight.detach().view(model.n_classes, -1), s.p_drop,
                               s.seeds[j - 1], None if s.masks is None else s.masks[j - 1], dx, acc)
-        grads[head.weight], grads[head.bias] = dw.contiguous(), db.contiguous()
+        if _ALLOC[0] is not None:
+            gw, gb = _new_grad(head.weight), _new_grad(head.bias)
+            gw.copy_(dw)
+            gb.copy_(db)
+            dw, db = gw, gb
+        grads[head.weight], grads[head.bias] = dw, db
     flush()
     for j in range(d - 1, 0, -1):  # decoder columns, last column first
         for i in range(d - 1 - j, -1, -1):
@@ -384,7 +399,11 @@ class _UNetNestedFn(torch.autograd.Function):
             raise RuntimeError("UNet_Nested (HIP): backward called twice on the same forward")
         ctx.saved = None
         sink = getattr(model, "_grad_sink", None)
-        grads, dx = backward_impl(model, saved, d_outs, ctx.needs_input_grad[1], sink)
+        _ALLOC[0] = getattr(model, "_grad_alloc", None)
+        try:
+            grads, dx = backward_impl(model, saved, d_outs, ctx.needs_input_grad[1], sink)
+        finally:
+            _ALLOC[0] = None
         dx_nchw = None
         if dx is not None:
             dx_nchw = ops.nhwc_to_nchw(dx)

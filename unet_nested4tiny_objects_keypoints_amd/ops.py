@@ -20,6 +20,71 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class LaunchTimer:
+    """Optional per-launch timing with HIP events on the launching stream (used by bench.py for the
+    roofline line).  Records (kind, flops, bytes, start_event, end_event) for every MFMA-kernel launch
+    and (name, start, end) for named regions; read the times after a device synchronise."""
+
+    def __init__(self):
+        self.launches = []
+        self.regions = []
+
+    def _pair(self):
+        return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def summary(self):
+        out = {}
+        for kind, flops, s, e in self.launches:
+            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += flops
+        reg = {}
+        for name, s, e in self.regions:
+            d = reg.setdefault(name, {"count": 0, "ms": 0.0})
+            d["count"] += 1
+            d["ms"] += s.elapsed_time(e)
+        return out, reg
+
+
+_TIMER: Optional[LaunchTimer] = None
+
+
+def set_timer(t: Optional[LaunchTimer]) -> None:
+    global _TIMER
+    _TIMER = t
+
+
+class region:
+    """with ops.region("X00.fwd"): ...  -- a named span on the current stream when a LaunchTimer is set."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _TIMER is not None:
+            self.s, self.e = _TIMER._pair()
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _TIMER is not None:
+            self.e.record()
+            _TIMER.regions.append((self.name, self.s, self.e))
+        return False
+
+
+def _timed_call(kind, flops, fn):
+    if _TIMER is None:
+        return fn()
+    s, e = _TIMER._pair()
+    s.record()
+    r = fn()
+    e.record()
+    _TIMER.launches.append((kind, flops, s, e))
+    return r
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -97,7 +162,8 @@ def gemm_fwd(n: int, h: int, w: int, taps: int, ins: Sequence[V], outs: Sequence
     d.weight = weight.data_ptr()
     d.bias = None if bias is None else bias.data_ptr()
     d.stats_partial = None if stats_partial is None else stats_partial.data_ptr()
-    check(_lib.lib().unetpp_gemm_fwd(C.byref(d), _stream()), "unetpp_gemm_fwd")
+    _timed_call("gemm_pix_kernel<%d>" % taps, 2.0 * n * h * w * taps * k * nc,
+                lambda: check(_lib.lib().unetpp_gemm_fwd(C.byref(d), _stream()), "unetpp_gemm_fwd"))
 
 
 def pack_weight(dst: torch.Tensor, src: torch.Tensor, t: int, k: int, n: int, dstr, sstr, flip: bool = False) -> None:
@@ -121,7 +187,8 @@ def wgrad(n: int, h: int, w: int, taps: int, xs: Sequence[V], dys: Sequence[V], 
     slabs = torch.empty(split * (taps * k + 1) * nc, dtype=torch.float32, device=xs[0].t.device)
     d.n_split = split
     d.slabs = slabs.data_ptr()
-    check(lib.unetpp_wgrad(C.byref(d), _stream()), "unetpp_wgrad")
+    _timed_call("wgrad_kernel<%d>" % taps, 2.0 * n * h * w * taps * k * nc,
+                lambda: check(lib.unetpp_wgrad(C.byref(d), _stream()), "unetpp_wgrad"))
     if n_inner is None:
         n_inner = nc
     check(lib.unetpp_wgrad_finish(_ptr(slabs), split, taps, k, nc, n_inner, _ptr(dw), dw_strides[0], dw_strides[1],
@@ -157,14 +224,17 @@ def maxpool_bwd(d_pooled, pool_idx, d_act):
           "unetpp_maxpool_bwd")
 
 
-def bn_backward(d_act, y, scale, shift, mean, invstd, gamma, dy_out):
+def bn_backward(d_act, y, scale, shift, mean, invstd, gamma, dy_out, dgamma=None, dbeta=None):
     """Training-mode BatchNorm+ReLU backward.  Returns (dgamma, dbeta); dy_out may alias d_act."""
     lib = _lib.lib()
     n, h, w, c = y.shape
     pixels = n * h * w
     blocks = int(lib.unetpp_bn_bwd_blocks(pixels, c))
     partial = torch.empty(blocks * c * 2, dtype=torch.float32, device=y.device)
-    dgamma, dbeta = (torch.empty(c, dtype=torch.float32, device=y.device) for _ in range(2))
+    if dgamma is None:
+        dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
+    if dbeta is None:
+        dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
     st = _stream()
     check(lib.unetpp_bn_bwd_reduce(_ptr(d_act), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), pixels, c,
                                    _ptr(partial), st), "unetpp_bn_bwd_reduce")
