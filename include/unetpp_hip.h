@@ -49,6 +49,9 @@ typedef struct unetpp_view {
   const float* gate;
   int32_t relu;        /* load: max(v, 0) after the affine; store: max(v, 0) after the bias */
   int32_t accumulate;  /* store only: dst += v instead of dst = v */
+  int32_t gate_sum;    /* store only, with gate: 0 = gate this contribution before it is added,
+                        * 1 = gate the accumulated sum (the last contribution applies the ReLU mask) */
+  int32_t reserved;
 } unetpp_view;
 
 /* rows = N*H*W logical pixels;  out[p, n] = bias[n] + sum_{tap, k} in[p (+) tap, k] * weight[tap][k][n]
@@ -68,6 +71,9 @@ typedef struct unetpp_gemm_desc {
   /* optional BatchNorm statistics epilogue: per pixel-block partial (sum, sum of squares) of the
    * stored values, [unetpp_gemm_pixel_blocks()][Ncols][2]; requires n_out == 1. */
   float* stats_partial;
+  /* optional fast path: `weight` re-laid as the kernel's LDS image by unetpp_gemm_pack_weight_image
+   * (unetpp_gemm_weight_image_floats() floats).  NULL selects the generic kernel. */
+  const float* weight_image;
 } unetpp_gemm_desc;
 
 /* weight gradient:  dW[tap][k][n] = sum_p x[p (+) tap, k] * dy[p, n]  (+ db[n] = sum_p dy[p, n]).
@@ -91,6 +97,11 @@ const char* unetpp_build_arch(void); /* "gfx950" */
 /* ---- multi-view pixel GEMM on MFMA (v_mfma_f32_32x32x2_f32) ------------------------------ */
 int64_t unetpp_gemm_pixel_blocks(int32_t N, int32_t H, int32_t W);
 int unetpp_gemm_fwd(const unetpp_gemm_desc* d, void* stream);
+/* Fast path (register-prefetched, swizzled-LDS kernel): applies when every input view is a plain 16-byte
+ * aligned slice (no scale/gate/relu on load, C, c_off and c_len multiples of 4).  Returns the image size in
+ * floats, or 0 when the descriptor must use the generic kernel. */
+int64_t unetpp_gemm_weight_image_floats(const unetpp_gemm_desc* d);
+int unetpp_gemm_pack_weight_image(const unetpp_gemm_desc* d, float* image, void* stream);
 
 int32_t unetpp_wgrad_max_split(int32_t N, int32_t H, int32_t W);
 int unetpp_wgrad(const unetpp_wgrad_desc* d, void* stream);
@@ -150,7 +161,8 @@ int64_t unetpp_head_bwd_blocks(int64_t pixels);
 /* d_out, out: NCHW.  dx (NHWC) is written (accumulate = 0) or added to; partial [blocks][n_cls*C + n_cls]. */
 int unetpp_head_bwd(const float* d_out_nchw, const float* out_nchw, const float* x, const float* weight,
                     int32_t N, int32_t H, int32_t W, int32_t C, int32_t n_cls, float p_drop, uint64_t seed,
-                    const uint8_t* mask, float* dx, int32_t accumulate, float* partial, void* stream);
+                    const uint8_t* mask, float* dx, int32_t accumulate, int32_t gate_x, float* partial,
+                    void* stream); /* gate_x: after the (optional) accumulate, dx *= (x > 0) -- the ReLU mask of x */
 /* out[i] = sum_b partial[b][i], i < len (used for head dW/db) */
 int unetpp_sum_partials(const float* partial, int64_t n_blocks, int64_t len, float* out, void* stream);
 

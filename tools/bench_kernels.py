@@ -1,0 +1,73 @@
+"""Kernel microbenchmark (GPU box): the MFMA GEMM / wgrad launches of BASELINE configs[1] (base 32, 256x256, batch 32),
+each timed alone with HIP events.  Prints TFLOP/s per shape and the FLOP-weighted total.  Used to iterate on kernels."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from unet_nested4tiny_objects_keypoints_amd import engine, ops  # noqa: E402
+from unet_nested4tiny_objects_keypoints_amd.ops import V  # noqa: E402
+
+B = int(os.environ.get("B", "32"))
+REPS = int(os.environ.get("REPS", "5"))
+only = sys.argv[1] if len(sys.argv) > 1 else ""
+
+
+def timeit(fn):
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(REPS):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / REPS
+
+
+def rnd(*shape):
+    return torch.randn(*shape, device="cuda")
+
+
+# (name, level spatial, [cin per view], cout)
+CONVS = []
+f = [32, 64, 128, 256]
+for i in range(4):
+    hw = 256 >> i
+    CONVS.append(("enc%d.conv2" % i, hw, [f[i]], f[i]))
+    if i > 0:
+        CONVS.append(("enc%d.conv1" % i, hw, [f[i - 1]], f[i]))
+for j in range(1, 4):
+    for i in range(4 - j):
+        hw = 256 >> i
+        CONVS.append(("X%d%d.conv1" % (i, j), hw, [f[i]] * (j + 1), f[i]))
+        CONVS.append(("X%d%d.conv2" % (i, j), hw, [f[i]], f[i]))
+
+tot_ms = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+tot_fl = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+print("%-14s %5s %-22s %5s | %9s %7s | %9s %7s | %9s %7s" % ("layer", "hw", "cin", "cout", "fwd ms", "TF/s", "dgrad ms",
+                                                               "TF/s", "wgrad ms", "TF/s"))
+for name, hw, cins, co in CONVS:
+    if only and only not in name:
+        continue
+    ci = sum(cins)
+    xs = [rnd(B, hw, hw, c) for c in cins]
+    y = rnd(B, hw, hw, co)
+    w = rnd(co, ci, 3, 3) * 0.05
+    bias = rnd(co)
+    wp, wd = engine.pack_conv_fwd(w), engine.pack_conv_dgrad(w)
+    flops = 2.0 * B * hw * hw * 9 * ci * co
+    t_f = timeit(lambda: ops.gemm_fwd(B, hw, hw, 9, [V(t) for t in xs], [V(y, relu=True)], wp, bias))
+    dxs = [torch.empty_like(t) for t in xs]
+    t_d = timeit(lambda: ops.gemm_fwd(B, hw, hw, 9, [V(y)], [V(t) for t in dxs], wd))
+    dw, db = torch.empty_like(w), torch.empty_like(bias)
+    t_w = timeit(lambda: ops.wgrad(B, hw, hw, 9, [V(t) for t in xs], [V(y)], dw, (1, 9, ci * 9, 0), db))
+    for k, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)):
+        tot_ms[k] += t
+        tot_fl[k] += flops
+    print("%-14s %5d %-22s %5d | %9.3f %7.1f | %9.3f %7.1f | %9.3f %7.1f" % (
+        name, hw, str(cins), co, t_f, flops / t_f / 1e9, t_d, flops / t_d / 1e9, t_w, flops / t_w / 1e9))
+for k in tot_ms:
+    if tot_ms[k] > 0:
+        print("TOTAL %-6s %8.3f ms  %7.1f TF/s" % (k, tot_ms[k], tot_fl[k] / tot_ms[k] / 1e9))

@@ -15,7 +15,7 @@ _REPO = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.path.join(_PKG_DIR, "libunetpp_hip.so")
 CSRC = os.path.join(_PKG_DIR, "csrc")
 INCLUDE = os.path.join(_REPO, "include")
-SOURCES = ("gemm_pix.hip", "wgrad.hip", "pointwise.hip")
+SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "wgrad.hip", "wgrad_fast.hip", "pointwise.hip")
 MAX_VIEWS = 8
 
 
@@ -27,7 +27,7 @@ class View(C.Structure):
         ("Hs", C.c_int32), ("Ws", C.c_int32),
         ("sy", C.c_int32), ("sx", C.c_int32), ("oy", C.c_int32), ("ox", C.c_int32),
         ("scale", C.c_void_p), ("shift", C.c_void_p), ("gate", C.c_void_p),
-        ("relu", C.c_int32), ("accumulate", C.c_int32),
+        ("relu", C.c_int32), ("accumulate", C.c_int32), ("gate_sum", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -38,6 +38,7 @@ class GemmDesc(C.Structure):
         ("taps", C.c_int32), ("n_in", C.c_int32), ("n_out", C.c_int32),
         ("inp", View * MAX_VIEWS), ("out", View * MAX_VIEWS),
         ("weight", C.c_void_p), ("bias", C.c_void_p), ("stats_partial", C.c_void_p),
+        ("weight_image", C.c_void_p),
     ]
 
 
@@ -60,6 +61,8 @@ SIGNATURES = {
     "unetpp_build_arch": (C.c_char_p, []),
     "unetpp_gemm_pixel_blocks": (_I64, [_I32, _I32, _I32]),
     "unetpp_gemm_fwd": (C.c_int, [C.POINTER(GemmDesc), _P]),
+    "unetpp_gemm_weight_image_floats": (_I64, [C.POINTER(GemmDesc)]),
+    "unetpp_gemm_pack_weight_image": (C.c_int, [C.POINTER(GemmDesc), _P, _P]),
     "unetpp_wgrad_max_split": (_I32, [_I32, _I32, _I32]),
     "unetpp_wgrad": (C.c_int, [C.POINTER(WgradDesc), _P]),
     "unetpp_wgrad_finish": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _I64, _I64, _I64, _I64, _P, _P]),
@@ -74,7 +77,7 @@ SIGNATURES = {
     "unetpp_bn_bwd_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P]),
     "unetpp_head_fwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _P]),
     "unetpp_head_bwd_blocks": (_I64, [_I64]),
-    "unetpp_head_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _I32, _P, _P]),
+    "unetpp_head_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _I32, _I32, _P, _P]),
     "unetpp_sum_partials": (C.c_int, [_P, _I64, _I64, _P, _P]),
     "unetpp_bilinear2x_fwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P]),
     "unetpp_bilinear2x_bwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _I32, _P]),

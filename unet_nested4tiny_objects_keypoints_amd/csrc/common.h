@@ -85,4 +85,9 @@ __device__ __forceinline__ f32x4 view_load4(const unetpp_view& v, long off, int 
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? UNETPP_OK : UNETPP_ELAUNCH; }
 
+// gemm_fast.hip: register-prefetched kernel for plain aligned views (needs d->weight_image)
+int launch_gemm_fast(const unetpp_gemm_desc* d, hipStream_t st);
+// wgrad_fast.hip: 8-wave double-buffered kernel for plain aligned views; returns 1 when it does not apply
+int launch_wgrad_fast(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_tiles_cols, int k_tiles, hipStream_t st);
+
 }  // namespace unetpp

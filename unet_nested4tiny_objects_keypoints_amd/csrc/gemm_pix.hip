@@ -150,8 +150,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pix_kernel(const GemmArgs a)
         s1 += v;
         s2 += v * v;
         const long off = view_pixel_offset(O, n, y, x) + nt * 32 + j;
-        if (O.gate != nullptr) v = (O.gate[off] > 0.f) ? v : 0.f;
+        if (O.gate != nullptr && !O.gate_sum) v = (O.gate[off] > 0.f) ? v : 0.f;
         if (O.accumulate) v += O.ptr[off];
+        if (O.gate != nullptr && O.gate_sum) v = (O.gate[off] > 0.f) ? v : 0.f;
         O.ptr[off] = v;
       }
     }
@@ -196,6 +197,7 @@ extern "C" int unetpp_gemm_fwd(const unetpp_gemm_desc* d, void* stream) {
   if (d->n_in < 1 || d->n_in > UNETPP_MAX_VIEWS || d->n_out < 1 || d->n_out > UNETPP_MAX_VIEWS) return UNETPP_EINVAL;
   if (d->weight == nullptr) return UNETPP_EINVAL;
   if (d->stats_partial != nullptr && d->n_out != 1) return UNETPP_EINVAL;
+  if (d->weight_image != nullptr) return launch_gemm_fast(d, static_cast<hipStream_t>(stream));
   GemmArgs a;
   a.d = *d;
   a.Ktot = 0;

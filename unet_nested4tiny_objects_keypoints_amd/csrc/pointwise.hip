@@ -344,12 +344,68 @@ __global__ __launch_bounds__(kThreads) void head_fwd_kernel(const float* __restr
   }
 }
 
+// Forward head, coalesced: one wave per workgroup stages 64 pixels x C channels through LDS with full-line
+// 16-byte loads (dropout applied on the way in), then lane = pixel reads its row (stride C+1: conflict-free)
+// and the class weights come through scalar loads (uniform index).  Output is NCHW, coalesced along pixels.
+__global__ __launch_bounds__(64) void head_fwd_tiled_kernel(const float* __restrict__ x, const float* __restrict__ weight,
+                                                            const float* __restrict__ bias, long pixels, int HW, int C,
+                                                            int n_cls, float keep_scale, uint32_t thr16, uint64_t seed,
+                                                            const uint8_t* __restrict__ mask, int use_drop,
+                                                            float* __restrict__ out) {
+  __shared__ float xs[64 * (kHeadMaxC + 1)];
+  const int lane = threadIdx.x;
+  const int XS = C + 1, g4n = C >> 2;  // launcher guarantees C % 4 == 0
+  const long n_tiles = (pixels + 63) / 64;
+  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long p0 = tile * 64;
+    __syncthreads();
+    for (int it = lane; it < 64 * g4n; it += 64) {
+      const int pl = it / g4n, gq = it - pl * g4n;
+      const long p = p0 + pl;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (p < pixels) {
+        v = *reinterpret_cast<const f32x4*>(x + p * C + 4 * gq);
+        if (use_drop) {
+          const uint64_t bits = (mask == nullptr) ? keep_bits(seed, p, g4n, gq) : 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bool keep = (mask != nullptr) ? (mask[p * C + 4 * gq + q] != 0) : keep_one(bits, q, thr16);
+            v[q] = keep ? v[q] * keep_scale : 0.f;
+          }
+        }
+      }
+      float* dst = &xs[pl * XS + 4 * gq];
+      dst[0] = v[0];
+      dst[1] = v[1];
+      dst[2] = v[2];
+      dst[3] = v[3];
+    }
+    __syncthreads();
+    const long p = p0 + lane;
+    float acc[kHeadMaxCls];
+#pragma unroll
+    for (int k = 0; k < kHeadMaxCls; ++k) acc[k] = (k < n_cls) ? bias[k] : 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float v = xs[lane * XS + c];
+#pragma unroll
+      for (int k = 0; k < kHeadMaxCls; ++k)
+        if (k < n_cls) acc[k] += v * weight[k * C + c];
+    }
+    if (p < pixels) {
+      const long n = p / HW, hw = p - n * HW;
+#pragma unroll
+      for (int k = 0; k < kHeadMaxCls; ++k)
+        if (k < n_cls) out[(n * n_cls + k) * HW + hw] = 1.0f / (1.0f + expf(-acc[k]));
+    }
+  }
+}
+
 // tile = 64 consecutive pixels.  LDS: x*keep*scale [64][C+1], dlogit [64][8], W [8][C].
 __global__ __launch_bounds__(kThreads) void head_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ outp,
                                                             const float* __restrict__ x, const float* __restrict__ weight,
                                                             long pixels, int HW, int C, int n_cls, float keep_scale,
                                                             uint32_t thr16, uint64_t seed, const uint8_t* __restrict__ mask,
-                                                            int use_drop, float* __restrict__ dx, int accumulate,
+                                                            int use_drop, float* __restrict__ dx, int accumulate, int gate_x,
                                                             float* __restrict__ partial) {
   __shared__ float xs[64 * (kHeadMaxC + 1)];
   __shared__ float dl[64 * kHeadMaxCls];
@@ -408,6 +464,7 @@ __global__ __launch_bounds__(kThreads) void head_bwd_kernel(const float* __restr
           s = keep ? s * keep_scale : 0.f;
         }
         if (accumulate) s += dx[p * C + c];
+        if (gate_x) s = (x[p * C + c] > 0.f) ? s : 0.f;
         dx[p * C + c] = s;
       }
     }
@@ -438,11 +495,16 @@ __global__ __launch_bounds__(kThreads) void head_bwd_kernel(const float* __restr
 }
 
 __global__ void sum_partials_kernel(const float* __restrict__ partial, long n_blocks, long len, float* __restrict__ out) {
-  const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
-  if (i >= len) return;
+  // 64 outputs x 4 row groups per workgroup; groups combined through LDS in fixed order
+  __shared__ double part[4][64];
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long i = blockIdx.x * 64L + e;
   double s = 0.0;
-  for (long b = 0; b < n_blocks; ++b) s += static_cast<double>(partial[b * len + i]);
-  out[i] = static_cast<float>(s);
+  if (i < len)
+    for (long b = g; b < n_blocks; b += 4) s += static_cast<double>(partial[b * len + i]);
+  part[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i < len) out[i] = static_cast<float>((part[0][e] + part[1][e]) + (part[2][e] + part[3][e]));
 }
 
 // ------------------------------------------------------------------ bilinear x2, align_corners = True
@@ -706,6 +768,13 @@ extern "C" int unetpp_head_fwd(const float* x, const float* weight, const float*
   if (!x || !weight || !bias || !out_nchw || !head_args_ok(N, H, W, C, n_cls, p_drop)) return UNETPP_EINVAL;
   const long pixels = static_cast<long>(N) * H * W;
   const int use_drop = p_drop > 0.f;
+  if ((C & 3) == 0 && aligned16(x)) {
+    const long tiles = (pixels + 63) / 64;
+    const unsigned blocks = static_cast<unsigned>(tiles < 256 * 16 ? tiles : 256 * 16);
+    hipLaunchKernelGGL(head_fwd_tiled_kernel, dim3(blocks), dim3(64), 0, ST(stream), x, weight, bias, pixels, H * W, C,
+                       n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, use_drop, out_nchw);
+    return launch_status();
+  }
   hipLaunchKernelGGL(head_fwd_kernel, dim3(grid_for(pixels)), dim3(kThreads), 0, ST(stream), x, weight, bias, pixels,
                      H * W, C, n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, use_drop, out_nchw);
   return launch_status();
@@ -719,20 +788,21 @@ extern "C" int64_t unetpp_head_bwd_blocks(int64_t pixels) {
 
 extern "C" int unetpp_head_bwd(const float* d_out_nchw, const float* out_nchw, const float* x, const float* weight,
                                int32_t N, int32_t H, int32_t W, int32_t C, int32_t n_cls, float p_drop, uint64_t seed,
-                               const uint8_t* mask, float* dx, int32_t accumulate, float* partial, void* stream) {
+                               const uint8_t* mask, float* dx, int32_t accumulate, int32_t gate_x, float* partial,
+                               void* stream) {
   if (!d_out_nchw || !out_nchw || !x || !weight || !dx || !partial || !head_args_ok(N, H, W, C, n_cls, p_drop))
     return UNETPP_EINVAL;
   const long pixels = static_cast<long>(N) * H * W;
   const int use_drop = p_drop > 0.f;
   hipLaunchKernelGGL(head_bwd_kernel, dim3(static_cast<unsigned>(unetpp_head_bwd_blocks(pixels))), dim3(kThreads), 0,
                      ST(stream), d_out_nchw, out_nchw, x, weight, pixels, H * W, C, n_cls, 1.0f / (1.0f - p_drop),
-                     keep_threshold(p_drop), seed, mask, use_drop, dx, accumulate, partial);
+                     keep_threshold(p_drop), seed, mask, use_drop, dx, accumulate, gate_x, partial);
   return launch_status();
 }
 
 extern "C" int unetpp_sum_partials(const float* partial, int64_t n_blocks, int64_t len, float* out, void* stream) {
   if (!partial || !out || n_blocks < 1 || len < 1) return UNETPP_EINVAL;
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(static_cast<unsigned>((len + 255) / 256)), dim3(256), 0, ST(stream),
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(static_cast<unsigned>((len + 63) / 64)), dim3(256), 0, ST(stream),
                      partial, n_blocks, len, out);
   return launch_status();
 }

@@ -157,25 +157,48 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(const WgradArgs a) {
 __global__ void wgrad_finish_kernel(const float* __restrict__ slabs, int n_split, int taps, int K, int Ncols,
                                     int n_inner, float* __restrict__ dw, long d_t, long d_k, long d_n, long d_o,
                                     float* __restrict__ db) {
+  // 256 threads = 64 consecutive slab elements x 4 slab groups: group g sums slabs g, g+4, ... (4 loads in
+  // flight), the groups are combined through LDS in fixed order -> reproducible, and 4x the parallelism of a
+  // one-thread-per-element loop over up to 1024 slabs.
+  __shared__ float part[4][64];
   const long rows = static_cast<long>(taps) * K + 1;
   const long total = rows * Ncols;
-  const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
-  if (i >= total) return;
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long i = blockIdx.x * 64L + e;
+  float s = 0.f;
+  if (i < total) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = g;
+    for (; b + 12 < n_split; b += 16) {
+      s0 += slabs[static_cast<long>(b) * total + i];
+      s1 += slabs[static_cast<long>(b + 4) * total + i];
+      s2 += slabs[static_cast<long>(b + 8) * total + i];
+      s3 += slabs[static_cast<long>(b + 12) * total + i];
+    }
+    for (; b < n_split; b += 4) s0 += slabs[static_cast<long>(b) * total + i];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  part[g][e] = s;
+  __syncthreads();
+  if (g != 0 || i >= total) return;
+  s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
   const long row = i / Ncols;
   const int nn = static_cast<int>(i - row * Ncols);
   if (row == rows - 1) {
-    // bias gradient: columns that share an inner index are summed (fixed order: outer, then slab)
+    // bias gradient.  Plain convolution (n_inner == Ncols): the sum just formed.  2x2 deconvolution: the four
+    // pixel-phase columns of one output channel are added by the thread of the inner index (fixed order).
     if (db != nullptr && nn < n_inner) {
-      float s = 0.f;
-      for (int o = nn; o < Ncols; o += n_inner)
-        for (int b = 0; b < n_split; ++b) s += slabs[b * total + row * Ncols + o];
-      db[nn] = s;
+      float t = 0.f;
+      for (int o = nn; o < Ncols; o += n_inner) {
+        float u = 0.f;
+        for (int b = 0; b < n_split; ++b) u += slabs[static_cast<long>(b) * total + row * Ncols + o];
+        t += u;
+      }
+      db[nn] = (n_inner == Ncols) ? s : t;
     }
     return;
   }
   if (dw == nullptr) return;
-  float s = 0.f;
-  for (int b = 0; b < n_split; ++b) s += slabs[b * total + i];
   const long t = row / K, k = row - t * K;
   dw[t * d_t + k * d_k + (nn % n_inner) * d_n + (nn / n_inner) * d_o] = s;
 }
@@ -236,6 +259,8 @@ extern "C" int unetpp_wgrad(const unetpp_wgrad_desc* d, void* stream) {
   if (pairs > 65535) return UNETPP_EINVAL;
   const dim3 grid(static_cast<unsigned>(d->n_split), static_cast<unsigned>(pairs));
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const int fast = launch_wgrad_fast(d, a.Ktot, a.Ncols, a.n_tiles_cols, k_tiles, st);
+  if (fast != 1) return fast;  // launched (or failed to); 1 = views need the generic kernel
   if (d->taps == 9)
     hipLaunchKernelGGL(wgrad_kernel<9>, grid, dim3(kThreads), 0, st, a);
   else
@@ -249,7 +274,7 @@ extern "C" int unetpp_wgrad_finish(const float* slabs, int32_t n_split, int32_t 
   if (slabs == nullptr || n_split < 1 || taps < 1 || K < 1 || Ncols < 1) return UNETPP_EINVAL;
   if (n_inner < 1 || Ncols % n_inner != 0) return UNETPP_EINVAL;
   const long total = (static_cast<long>(taps) * K + 1) * Ncols;
-  const unsigned blocks = static_cast<unsigned>((total + 255) / 256);
+  const unsigned blocks = static_cast<unsigned>((total + 63) / 64);
   hipLaunchKernelGGL(wgrad_finish_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), slabs,
                      n_split, taps, K, Ncols, n_inner, dw, d_t, d_k, d_n, d_o, db);
   return launch_status();

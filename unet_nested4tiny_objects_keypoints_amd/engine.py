@@ -234,20 +234,39 @@ def forward_impl(model, x, training: bool, save: bool):
 class _GradBook:
     """Gradient buffers of the node outputs; tracks whether a buffer already holds a contribution."""
 
-    def __init__(self, X):
+    def __init__(self, X, depth, gate_keys):
         self.X = X
         self.buf: Dict[Tuple[int, int], torch.Tensor] = {}
+        self.got: Dict[Tuple[int, int], int] = {}
+        self.gate_keys = gate_keys   # nodes whose ReLU mask may be applied by their last contributor
+        self.gated = set()
+        # how many gradient contributions every node output receives (fan-in table of SURVEY.md 3c)
+        self.expected = {}
+        for (i, j) in X:
+            n = (1 if (i == 0 and j >= 1) else 0)            # its deep-supervision head
+            n += max(0, (depth - 1 - i) - j)                  # concat input of X[i][j'] for j' > j
+            n += 1 if i >= 1 else 0                           # upsampled into X[i-1][j+1]
+            n += 1 if (j == 0 and i < depth - 1) else 0       # max-pooled into X[i+1][0]
+            self.expected[(i, j)] = n
 
-    def target(self, key):
-        """(tensor, accumulate?) for the next contribution to d X[key]."""
+    def target(self, key, can_gate=False):
+        """(tensor, accumulate?, gate) for the next contribution to d X[key].  `gate` is X[key] when this is
+        the node's LAST contribution, the node is gate-eligible and the contributor can apply it
+        (gate_sum semantics: mask the accumulated sum); the consumer then reads an already-masked gradient."""
+        self.got[key] = self.got.get(key, 0) + 1
+        gate = None
+        if can_gate and key in self.gate_keys and self.got[key] == self.expected[key]:
+            gate = self.X[key]
+            self.gated.add(key)
         if key in self.buf:
-            return self.buf[key], True
+            return self.buf[key], True, gate
         t = torch.empty_like(self.X[key])
         self.buf[key] = t
-        return t, False
+        return t, False, gate
 
     def take(self, key):
-        return self.buf.pop(key)
+        assert self.got.get(key, 0) == self.expected[key], "gradient fan-in mismatch at node %s" % (key,)
+        return self.buf.pop(key), key in self.gated
 
 
 _ALLOC = [None]  # set for the duration of one backward: param -> gradient buffer (data-parallel flat buffer)
@@ -267,9 +286,10 @@ def _conv_wgrad(conv, xs, dys, b, h, w, grads):
     grads[conv.bias] = db
 
 
-def _pair_bwd(blk, r: _PairRec, d_out, in_targets: Optional[List[V]], b, grads):
+def _pair_bwd(blk, r: _PairRec, d_out, in_targets: Optional[List[V]], b, grads, pre_gated=False):
     """Backward of models/unet.py:150-156.  d_out (gradient of r.out) is consumed.  in_targets: output views
-    for the gradient of every entry of r.ins (None = the inputs need no gradient)."""
+    for the gradient of every entry of r.ins (None = the inputs need no gradient).  pre_gated: the last
+    contributor already multiplied d_out by (r.out > 0)."""
     conv1, conv2 = getattr(blk.conv1, "0"), getattr(blk.conv2, "0")
     h, w = r.h, r.w
     if blk.is_batchnorm:
@@ -288,7 +308,8 @@ def _pair_bwd(blk, r: _PairRec, d_out, in_targets: Optional[List[V]], b, grads):
         grads[bn1.weight], grads[bn1.bias] = dg, dbt
         dy1 = V(d_a1)
     else:
-        dy2 = V(d_out, gate=r.out)  # ReLU backward folded into the operand load
+        # ReLU backward: already applied by the last contributor's epilogue, else folded into the operand load
+        dy2 = V(d_out) if pre_gated else V(d_out, gate=r.out)
         _conv_wgrad(conv2, [V(r.a1)], [dy2], b, h, w, grads)
         d_a1 = torch.empty_like(r.a1)
         ops.gemm_fwd(b, h, w, 9, [dy2], [V(d_a1, gate=r.a1)], pack_conv_dgrad(conv2.weight.detach()))
@@ -298,7 +319,7 @@ def _pair_bwd(blk, r: _PairRec, d_out, in_targets: Optional[List[V]], b, grads):
         ops.gemm_fwd(b, h, w, 9, [dy1], in_targets, pack_conv_dgrad(conv1.weight.detach()))
 
 
-def _up_bwd(upmod, is_deconv, u: _UpRec, d_up, d_src, accumulate, b, grads):
+def _up_bwd(upmod, is_deconv, u: _UpRec, d_up, d_src, accumulate, gate, b, grads):
     hs, ws = u.h, u.w
     if is_deconv:
         ci, co = upmod.weight.shape[0], upmod.weight.shape[1]
@@ -306,7 +327,7 @@ def _up_bwd(upmod, is_deconv, u: _UpRec, d_up, d_src, accumulate, b, grads):
         db = _new_grad(upmod.bias)
         ops.wgrad(b, hs, ws, 1, [V(u.src)], _phase_views(d_up), dw, (0, 4 * co, 4, 1), db, n_inner=co)
         grads[upmod.weight], grads[upmod.bias] = dw, db
-        ops.gemm_fwd(b, hs, ws, 1, _phase_views(d_up), [V(d_src, accumulate=accumulate)],
+        ops.gemm_fwd(b, hs, ws, 1, _phase_views(d_up), [V(d_src, accumulate=accumulate, gate=gate, gate_sum=True)],
                      pack_deconv_dgrad(upmod.weight.detach()))
     else:
         conv = getattr(upmod, "1")
@@ -322,7 +343,10 @@ def backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=Non
     b, h0, w0 = s.shape
     d = model.depth
     grads: Dict[torch.nn.Parameter, torch.Tensor] = {}
-    book = _GradBook(s.X)
+    # Nodes without BatchNorm end in a plain ReLU whose mask the last gradient contributor can apply for free
+    # (decoder nodes always; encoder nodes only when is_batchnorm=False -- with BN the mask lives in BN backward).
+    gate_keys = {k for k in s.X if k[1] >= 1 or not model.is_batchnorm}
+    book = _GradBook(s.X, d, gate_keys)
     seen = set()
 
     def flush():
@@ -338,9 +362,10 @@ def backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=Non
         if go is None:
             go = torch.zeros_like(s.outs[j - 1])
         go = go.contiguous()
-        dx, acc = book.target((0, j))
+        dx, acc, gate = book.target((0, j), can_gate=True)
         dw, db = ops.head_bwd(go, s.outs[j - 1], s.X[(0, j)], head.weight.detach().view(model.n_classes, -1), s.p_drop,
-                              s.seeds[j - 1], None if s.masks is None else s.masks[j - 1], dx, acc)
+                              s.seeds[j - 1], None if s.masks is None else s.masks[j - 1], dx, acc,
+                              gate_x=gate is not None)
         if _ALLOC[0] is not None:
             gw, gb = _new_grad(head.weight), _new_grad(head.bias)
             gw.copy_(dw)
@@ -352,31 +377,32 @@ def backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=Non
         for i in range(d - 1 - j, -1, -1):
             mod = getattr(model, "up_concat%d%d" % (i, j))
             r, u = s.pairs[(i, j)], s.ups[(i, j)]
-            d_out = book.take((i, j))
+            d_out, pre_gated = book.take((i, j))
             d_up = torch.empty_like(u.up)
             targets = [V(d_up)]
             for jj in range(j):
-                t, acc = book.target((i, jj))
-                targets.append(V(t, accumulate=acc))
-            _pair_bwd(mod.conv, r, d_out, targets, b, grads)
-            t, acc = book.target((i + 1, j - 1))
-            _up_bwd(mod.up, model.is_deconv, u, d_up, t, acc, b, grads)
+                t, acc, gate = book.target((i, jj), can_gate=True)
+                targets.append(V(t, accumulate=acc, gate=gate, gate_sum=True))
+            _pair_bwd(mod.conv, r, d_out, targets, b, grads, pre_gated)
+            t, acc, gate = book.target((i + 1, j - 1), can_gate=model.is_deconv)
+            _up_bwd(mod.up, model.is_deconv, u, d_up, t, acc, gate, b, grads)
             flush()
     dx_in = None
     for i in range(d - 1, -1, -1):  # encoder column, deepest first
         blk = getattr(model, "conv%d0" % i)
         r = s.pairs[(i, 0)]
-        d_out = book.take((i, 0))
+        d_out, pre_gated = book.take((i, 0))
         if i > 0:
             d_pooled = torch.empty_like(s.pairs[(i - 1, 0)].pooled)
-            _pair_bwd(blk, r, d_out, [V(d_pooled)], b, grads)
+            _pair_bwd(blk, r, d_out, [V(d_pooled)], b, grads, pre_gated)
             prev = s.pairs[(i - 1, 0)]
-            ops.maxpool_bwd(d_pooled, prev.pool_idx, book.buf[(i - 1, 0)])
+            t, _, _ = book.target((i - 1, 0))  # the pool gradient is the node's last contribution (no gate here)
+            ops.maxpool_bwd(d_pooled, prev.pool_idx, t)
         elif want_input_grad:
             dx_in = torch.empty_like(s.x_nhwc)
-            _pair_bwd(blk, r, d_out, [V(dx_in)], b, grads)
+            _pair_bwd(blk, r, d_out, [V(dx_in)], b, grads, pre_gated)
         else:
-            _pair_bwd(blk, r, d_out, None, b, grads)
+            _pair_bwd(blk, r, d_out, None, b, grads, pre_gated)
         flush()
     return grads, dx_in
 

@@ -114,6 +114,7 @@ class V:
     gate: Optional[torch.Tensor] = None
     relu: bool = False
     accumulate: bool = False
+    gate_sum: bool = False
 
     def fill(self, dst: View) -> int:
         t = _need(self.t, "view tensor")
@@ -136,7 +137,11 @@ class V:
             dst.gate = None
         dst.relu = int(self.relu)
         dst.accumulate = int(self.accumulate)
+        dst.gate_sum = int(self.gate_sum)
         return n
+
+
+USE_FAST_GEMM = True  # tests flip this to exercise the generic kernel on the same shapes
 
 
 def gemm_pixel_blocks(n: int, h: int, w: int) -> int:
@@ -162,6 +167,14 @@ def gemm_fwd(n: int, h: int, w: int, taps: int, ins: Sequence[V], outs: Sequence
     d.weight = weight.data_ptr()
     d.bias = None if bias is None else bias.data_ptr()
     d.stats_partial = None if stats_partial is None else stats_partial.data_ptr()
+    d.weight_image = None
+    if USE_FAST_GEMM:
+        lib = _lib.lib()
+        n_img = int(lib.unetpp_gemm_weight_image_floats(C.byref(d)))
+        if n_img > 0:  # plain aligned views: the register-prefetched kernel applies
+            image = torch.empty(n_img, dtype=torch.float32, device=weight.device)
+            check(lib.unetpp_gemm_pack_weight_image(C.byref(d), _ptr(image), _stream()), "unetpp_gemm_pack_weight_image")
+            d.weight_image = image.data_ptr()
     _timed_call("gemm_pix_kernel<%d>" % taps, 2.0 * n * h * w * taps * k * nc,
                 lambda: check(_lib.lib().unetpp_gemm_fwd(C.byref(d), _stream()), "unetpp_gemm_fwd"))
 
@@ -174,7 +187,7 @@ def pack_weight(dst: torch.Tensor, src: torch.Tensor, t: int, k: int, n: int, ds
 
 
 def wgrad(n: int, h: int, w: int, taps: int, xs: Sequence[V], dys: Sequence[V], dw: Optional[torch.Tensor],
-          dw_strides, db: Optional[torch.Tensor], n_inner: Optional[int] = None, target_blocks: int = 1024) -> None:
+          dw_strides, db: Optional[torch.Tensor], n_inner: Optional[int] = None, target_blocks: int = 512) -> None:
     """dw / db are written (not accumulated).  dw_strides = (d_t, d_k, d_n, d_o) into the torch-layout gradient."""
     lib = _lib.lib()
     d = WgradDesc()
@@ -251,7 +264,7 @@ def head_fwd(x, weight, bias, p_drop, seed, mask, out_nchw):
                                      C.c_uint64(seed), _ptr(mask), _ptr(out_nchw), _stream()), "unetpp_head_fwd")
 
 
-def head_bwd(d_out, out, x, weight, p_drop, seed, mask, dx, accumulate):
+def head_bwd(d_out, out, x, weight, p_drop, seed, mask, dx, accumulate, gate_x=False):
     """Returns (dW [n_cls, C, 1, 1], db [n_cls]); dx is written or accumulated in place."""
     lib = _lib.lib()
     n, h, w, c = x.shape
@@ -262,7 +275,7 @@ def head_bwd(d_out, out, x, weight, p_drop, seed, mask, dx, accumulate):
     sums = torch.empty(ln, dtype=torch.float32, device=x.device)
     st = _stream()
     check(lib.unetpp_head_bwd(_ptr(d_out), _ptr(out), _ptr(x), _ptr(weight), n, h, w, c, n_cls, float(p_drop),
-                              C.c_uint64(seed), _ptr(mask), _ptr(dx), int(accumulate), _ptr(partial), st),
+                              C.c_uint64(seed), _ptr(mask), _ptr(dx), int(accumulate), int(gate_x), _ptr(partial), st),
           "unetpp_head_bwd")
     check(lib.unetpp_sum_partials(_ptr(partial), blocks, ln, _ptr(sums), st), "unetpp_sum_partials")
     return sums[:n_cls * c].view(n_cls, c, 1, 1), sums[n_cls * c:]
