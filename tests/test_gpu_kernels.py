@@ -79,6 +79,44 @@ def test_conv3x3_load_transform_and_slices(dev):
     ops.gemm_fwd(b, h, w, 9, [V(nhwc(big), c_off=8, c_len=12, scale=scale.cuda(), shift=shift.cuda(), relu=True)],
                  [V(out, gate=nhwc(gate), accumulate=True)], engine.pack_conv_fwd(wt.cuda()))
     assert rel_err(nchw(out), expect) < TOL
+    # gate_sum: the ReLU mask is applied to the accumulated sum (the "last contributor" form); plain input
+    # views so the fast kernel runs, then the same through the generic kernel
+    plain = nhwc(xin)
+    for fast in (True, False):
+        ops.USE_FAST_GEMM = fast
+        try:
+            out = nhwc(prev)
+            ops.gemm_fwd(b, h, w, 9, [V(plain)], [V(out, gate=nhwc(gate), accumulate=True, gate_sum=True)],
+                         engine.pack_conv_fwd(wt.cuda()))
+        finally:
+            ops.USE_FAST_GEMM = True
+        assert rel_err(nchw(out), (prev + ref) * (gate > 0)) < TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, [32], 32), (1, 64, 64, [32, 32, 32, 32], 32), (2, 8, 8, [16, 8, 8], 40),
+                                   (1, 24, 40, [4], 4), (3, 16, 16, [64, 32], 96)])
+def test_fast_and_generic_gemm_agree(dev, shape):
+    """The register-prefetched kernel and the generic kernel are the same function of their inputs (bitwise:
+    same MFMA order), including the BatchNorm partial sums."""
+    from unet_nested4tiny_objects_keypoints_amd import engine, ops
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    b, h, w, cins, co = shape
+    g = torch.Generator().manual_seed(9)
+    srcs = [nhwc(torch.randn(b, c, h, w, generator=g)) for c in cins]
+    wp = engine.pack_conv_fwd((torch.randn(co, sum(cins), 3, 3, generator=g) * 0.2).cuda())
+    bias = torch.randn(co, generator=g).cuda()
+    res = []
+    for fast in (True, False):
+        ops.USE_FAST_GEMM = fast
+        try:
+            out = torch.empty(b, h, w, co, device=dev)
+            part = torch.empty(ops.gemm_pixel_blocks(b, h, w) * co * 2, device=dev)
+            ops.gemm_fwd(b, h, w, 9, [V(s) for s in srcs], [V(out)], wp, bias, part)
+        finally:
+            ops.USE_FAST_GEMM = True
+        res.append((out, part))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
 
 
 def test_conv3x3_dgrad_matches_autograd(dev):
@@ -219,6 +257,12 @@ def test_head_fwd_bwd_with_mask(dev, c, ncls):
         assert rel_err(nchw(dx), x.grad.float()) < TOL
         assert rel_err(dw.cpu(), wt.grad.float()) < TOL
         assert rel_err(db.cpu(), bias.grad.float()) < TOL
+        # accumulate into an existing gradient, then ReLU-gate the sum by (x > 0)
+        prev = torch.randn(b, h, w, c, generator=g)
+        dx2 = prev.clone().cuda()
+        ops.head_bwd(d_out.float().cuda(), o, xg, wv, p, 0, mask, dx2, True, gate_x=True)
+        want = (prev.permute(0, 3, 1, 2) + x.grad.float()) * (x.detach() > 0)
+        assert rel_err(nchw(dx2), want) < TOL
 
 
 def test_head_dropout_generator_is_consistent(dev):

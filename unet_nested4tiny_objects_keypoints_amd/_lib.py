@@ -12,7 +12,7 @@ import subprocess
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(_PKG_DIR)
-LIB_PATH = os.path.join(_PKG_DIR, "libunetpp_hip.so")
+LIB_PATH = os.environ.get("UNETPP_LIB", os.path.join(_PKG_DIR, "libunetpp_hip.so"))  # override: kernel A/B runs
 CSRC = os.path.join(_PKG_DIR, "csrc")
 INCLUDE = os.path.join(_REPO, "include")
 SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "wgrad.hip", "wgrad_fast.hip", "pointwise.hip")

@@ -7,9 +7,10 @@
 //     under ~9 k cycles of MFMA work per chunk instead of stalling the workgroup;
 //   * the weights arrive as a pre-built LDS image (unetpp_gemm_pack_weight_image): staging them is a
 //     straight 16-byte copy, no strided gathers, no index math;
-//   * LDS images are XOR-swizzled instead of padded (input: 64-B pixel rows, slot ^= (pixel>>2)&3;
-//     weights: 32-B columns, half ^= (col>>3)&1) -- still conflict-free for ds_read_b128 but 40 KB
-//     instead of 55 KB per workgroup, so three workgroups fit a CU;
+//   * LDS: the input patch keeps the padded 80-byte pixel stride (conflict-free ds_read_b128 AND every tap's
+//     address is the lane's base plus a compile-time offset -- an XOR swizzle here costs 36 address registers),
+//     the weight image is XOR-swizzled instead of padded (32-B columns, half ^= (col>>3)&1): 45.6 KB instead
+//     of 55 KB per workgroup, so three workgroups fit a CU;
 //   * the per-item pixel geometry (halo position, bounds) is computed once per workgroup, per view only
 //     the base offset is refreshed;
 //   * one linear grid with the 32-column tile as the fastest index (consecutive workgroups re-read the
@@ -78,7 +79,14 @@ template <int TAPS>
 __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a) {
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
   constexpr int MAXPIX = (TAPS == 9) ? kMaxHaloPixels : kBlockPixels;
-  constexpr int IN_FLOATS = MAXPIX * KC;
+#ifdef UNETPP_A_SWIZZLE
+  constexpr int KCP = 16;
+#define A_ADDR(hp, slot) ((hp) * 16 + ((((slot)) ^ (((hp) >> 2) & 3)) << 2))
+#else
+  constexpr int KCP = 20;  // input pixel stride in LDS (floats)
+#define A_ADDR(hp, slot) ((hp) * 20 + ((slot) << 2))
+#endif
+  constexpr int IN_FLOATS = MAXPIX * KCP;
   constexpr int IMG = TAPS * 512;
   constexpr int IN_ITEMS = (MAXPIX * 4 + kThreads - 1) / kThreads;
   constexpr int W_ITEMS = (IMG / 4 + kThreads - 1) / kThreads;
@@ -116,18 +124,17 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
   const int n0 = col_base + nt * 32;
   const int n_cnt = min(32, O.c_len - nt * 32);
 
-  // ---- per-thread staging items: geometry once per workgroup ----
-  int it_y[IN_ITEMS], it_x[IN_ITEMS], it_lds[IN_ITEMS];
-  bool it_in[IN_ITEMS];
+  // ---- per-thread staging items.  Kept in registers across the K loop: one 32-bit element offset per item and
+  // one bit per item (pixel inside the image); everything else is recomputed from tid where it is needed, so
+  // the MFMA loop keeps enough registers to software-pipeline its LDS reads. ----
+  unsigned in_mask = 0;
 #pragma unroll
   for (int q = 0; q < IN_ITEMS; ++q) {
     const int it = tid + q * kThreads;
-    const int hp = it >> 2, q4 = it & 3;
+    const int hp = it >> 2;
     const int hy = hp / HWp, hx = hp - hy * HWp;
-    it_y[q] = ty0 + hy - HALO;
-    it_x[q] = tx0 + hx - HALO;
-    it_in[q] = (it < npix * 4) && it_y[q] >= 0 && it_y[q] < d.H && it_x[q] >= 0 && it_x[q] < d.W;
-    it_lds[q] = (it < npix * 4) ? hp * KC + ((q4 ^ ((hp >> 2) & 3)) << 2) : -1;
+    const int y = ty0 + hy - HALO, x = tx0 + hx - HALO;
+    if ((it < npix * 4) && y >= 0 && y < d.H && x >= 0 && x < d.W) in_mask |= 1u << q;
   }
   int apix[2];
 #pragma unroll
@@ -144,42 +151,72 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
   f32x4 reg_in[IN_ITEMS], reg_w[W_ITEMS];
-  long voff[IN_ITEMS];
+  // element offsets, unsigned 32-bit so the loads use the scalar-base + vector-offset form (no 64-bit address
+  // register pairs); the launcher only takes this path for tensors below 2^31 elements
+  unsigned voff[IN_ITEMS];
+  int pf_cnt = 0;      // valid channels of the chunk currently held in reg_in
   const float* wimg = d.weight_image + static_cast<long>(nt_global) * a.n_chunks * IMG;
 
   // chunk cursor
   int s = 0, c0 = 0;
+  // The prefetch is straight-line code: every item loads from a VALID address (out-of-image halo pixels and
+  // padding items are clamped into the image, channels past the view to channel 0) and the zeroing happens
+  // at the LDS write.  Conditional loads would put the loads under divergent branches, where hipcc drains
+  // vmcnt at every join and the prefetch stops overlapping the MFMA loop.
   auto view_offsets = [&](const unetpp_view& V) {
 #pragma unroll
-    for (int q = 0; q < IN_ITEMS; ++q) voff[q] = it_in[q] ? view_pixel_offset(V, n, it_y[q], it_x[q]) : -1;
+    for (int q = 0; q < IN_ITEMS; ++q) {
+      const int hp = (tid + q * kThreads) >> 2;
+      const int hy = hp / HWp, hx = hp - hy * HWp;
+      const int yy = min(max(ty0 + hy - HALO, 0), d.H - 1), xx = min(max(tx0 + hx - HALO, 0), d.W - 1);
+      voff[q] = static_cast<unsigned>(view_pixel_offset(V, n, yy, xx));
+    }
   };
   auto load_chunk = [&](const unetpp_view& V, int cbeg, int chunk_idx) {
-    const int c_cnt = min(KC, V.c_len - cbeg);
+    pf_cnt = min(KC, V.c_len - cbeg);
 #pragma unroll
     for (int q = 0; q < IN_ITEMS; ++q) {
       const int cc = ((tid + q * kThreads) & 3) << 2;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (voff[q] >= 0 && cc < c_cnt) v = *reinterpret_cast<const f32x4*>(V.ptr + voff[q] + cbeg + cc);
-      reg_in[q] = v;
+      const unsigned off = voff[q] + static_cast<unsigned>(cbeg + (cc < pf_cnt ? cc : 0));
+      reg_in[q] = *reinterpret_cast<const f32x4*>(V.ptr + off);
     }
     const float* wp = wimg + static_cast<long>(chunk_idx) * IMG;
 #pragma unroll
     for (int q = 0; q < W_ITEMS; ++q) {
-      const int it = tid + q * kThreads;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (it < IMG / 4) v = *reinterpret_cast<const f32x4*>(wp + it * 4);
-      reg_w[q] = v;
+      const unsigned it = min(tid + q * kThreads, IMG / 4 - 1);
+      reg_w[q] = *reinterpret_cast<const f32x4*>(wp + it * 4u);
     }
   };
   auto store_chunk = [&]() {
 #pragma unroll
-    for (int q = 0; q < IN_ITEMS; ++q)
-      if (it_lds[q] >= 0) *reinterpret_cast<f32x4*>(&in_tile[it_lds[q]]) = reg_in[q];
+    for (int q = 0; q < IN_ITEMS; ++q) {
+      const int it = tid + q * kThreads;
+      const int hp = it >> 2, q4 = it & 3;
+      const bool keep = ((in_mask >> q) & 1u) && (q4 << 2) < pf_cnt;
+      f32x4 v = reg_in[q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0.f;
+      if (it < npix * 4) *reinterpret_cast<f32x4*>(&in_tile[A_ADDR(hp, q4)]) = v;
+    }
 #pragma unroll
     for (int q = 0; q < W_ITEMS; ++q) {
       const int it = tid + q * kThreads;
       if (it < IMG / 4) *reinterpret_cast<f32x4*>(&w_tile[it * 4]) = reg_w[q];
     }
+  };
+  // one (tap, 8-channel group) step of LDS fragments: B for the 32 columns, A for both pixel tiles
+  struct Frag {
+    f32x4 b, a0, a1;
+  };
+  auto read_frag = [&](int step) {
+    const int tap = step >> 1, g = step & 1;
+    const int tpix = (TAPS == 9) ? (tap / 3) * HWp + (tap % 3) : 0;
+    Frag f;
+    f.b = *reinterpret_cast<const f32x4*>(&w_tile[step * 256 + wb]);
+    const int hp0 = apix[0] + tpix, hp1 = apix[1] + tpix;
+    f.a0 = *reinterpret_cast<const f32x4*>(&in_tile[A_ADDR(hp0, 2 * g + h)]);
+    f.a1 = *reinterpret_cast<const f32x4*>(&in_tile[A_ADDR(hp1, 2 * g + h)]);
+    return f;
   };
 
   view_offsets(d.in[0]);
@@ -188,7 +225,6 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
   __syncthreads();
 
   for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
-    const int c_cnt = min(KC, d.in[s].c_len - c0);
     // advance the cursor and prefetch the next chunk into registers
     int s2 = s, c2 = c0 + KC;
     if (c2 >= d.in[s].c_len) {
@@ -200,26 +236,18 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
       if (s2 != s) view_offsets(d.in[s2]);
       load_chunk(d.in[s2], c2, chunk + 1);
     }
-    // ---- LDS -> MFMA for the current chunk ----
-    const int ngroups = (c_cnt + 7) >> 3;
+    // ---- LDS -> MFMA for the current chunk: the fragments of step k+1 are read while the 8 MFMAs of step k
+    // issue (both 8-channel groups always run; a short last chunk is zero-padded in LDS) ----
+    Frag cur = read_frag(0);
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int tpix = (TAPS == 9) ? (tap / 3) * HWp + (tap % 3) : 0;
+    for (int step = 0; step < TAPS * 2; ++step) {
+      Frag nxt = cur;
+      if (step + 1 < TAPS * 2) nxt = read_frag(step + 1);
 #pragma unroll
-      for (int g = 0; g < KC / 8; ++g) {
-        if (g < ngroups) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(&w_tile[(tap * 2 + g) * 256 + wb]);
+      for (int t = 0; t < 4; ++t) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a0[t], cur.b[t], acc[0], 0, 0, 0);
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
-            const int hp = apix[mt] + tpix;
-            const f32x4 av =
-                *reinterpret_cast<const f32x4*>(&in_tile[hp * KC + (((2 * g + h) ^ ((hp >> 2) & 3)) << 2)]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], b[t], acc[mt], 0, 0, 0);
-          }
-        }
-      }
+      for (int t = 0; t < 4; ++t) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a1[t], cur.b[t], acc[1], 0, 0, 0);
+      cur = nxt;
     }
     __syncthreads();
     if (more) {
@@ -288,6 +316,7 @@ bool fast_args(const unetpp_gemm_desc* d, FastArgs& a) {
     if (!view_ok(v) || !view_covers(v, d->H, d->W)) return false;
     if (v.scale != nullptr || v.gate != nullptr || v.relu) return false;
     if (((v.C | v.c_off | v.c_len) & 3) != 0 || (reinterpret_cast<uintptr_t>(v.ptr) & 15) != 0) return false;
+    if (static_cast<long>(d->N) * v.Hs * v.Ws * v.C >= 0x7fffffffL) return false;  // 32-bit element offsets
     a.Ktot += v.c_len;
     a.n_chunks += (v.c_len + KC - 1) / KC;
   }

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64) void head_fwd_tiled_kernel(const float* __restr
                                                             int n_cls, float keep_scale, uint32_t thr16, uint64_t seed,
                                                             const uint8_t* __restrict__ mask, int use_drop,
                                                             float* __restrict__ out) {
-  __shared__ float xs[64 * (kHeadMaxC + 1)];
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // 64 * (C + 1) floats (sized by the launcher)
   const int lane = threadIdx.x;
   const int XS = C + 1, g4n = C >> 2;  // launcher guarantees C % 4 == 0
   const long n_tiles = (pixels + 63) / 64;
@@ -492,6 +492,119 @@ __global__ __launch_bounds__(kThreads) void head_bwd_kernel(const float* __restr
     if (idx < n_cls * C) dst[idx] = wacc[q];
   }
   if (tid < n_cls) dst[n_cls * C + tid] = bacc;
+}
+
+// Backward head, vectorised (C % 4 == 0): per 64-pixel tile
+//   1. dlogit = d_out * out * (1 - out)                    (NCHW reads, coalesced along pixels) -> LDS
+//   2. one pass over x in 16-byte pieces: dropout keep mask from ONE hash per piece, x*keep*scale -> LDS for
+//      the weight gradient, and dx = keep*scale * (W^T dlogit) (+ old dx, ReLU gate) written straight back
+//   3. dW[k, c] += sum_p dlogit[p, k] * xs[p, c]: all 256 threads, two pixel halves per (k, c)
+// Dynamic LDS: xs [64][C+1] | dlogit [64][8] | W [8][C] | scratch [2][n_cls*C].
+__global__ __launch_bounds__(kThreads) void head_bwd_vec_kernel(const float* __restrict__ d_out,
+                                                                const float* __restrict__ outp,
+                                                                const float* __restrict__ x,
+                                                                const float* __restrict__ weight, long pixels, int HW,
+                                                                int C, int n_cls, float keep_scale, uint32_t thr16,
+                                                                uint64_t seed, const uint8_t* __restrict__ mask,
+                                                                int use_drop, float* __restrict__ dx, int accumulate,
+                                                                int gate_x, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float hsm[];
+  const int XS = C + 1, g4n = C >> 2, NW = n_cls * C;
+  float* xs = hsm;
+  float* dl = xs + 64 * XS;
+  float* wsm = dl + 64 * kHeadMaxCls;
+  float* scratch = wsm + kHeadMaxCls * C;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NW; i += kThreads) wsm[i] = weight[i];
+  constexpr int kMaxPairs = (kHeadMaxCls * kHeadMaxC + 127) / 128;  // (k, c) pairs per thread
+  float wacc[kMaxPairs];
+#pragma unroll
+  for (int q = 0; q < kMaxPairs; ++q) wacc[q] = 0.f;
+  float bacc = 0.f;
+  const int pair0 = tid & 127, half = tid >> 7;
+  const long n_tiles = (pixels + 63) / 64;
+  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long p0 = tile * 64;
+    __syncthreads();
+    for (int it = tid; it < 64 * n_cls; it += kThreads) {
+      const int pl = it & 63, k = it >> 6;
+      const long p = p0 + pl;
+      float v = 0.f;
+      if (p < pixels) {
+        const long n = p / HW, hw = p - n * HW;
+        const long o = (n * n_cls + k) * HW + hw;
+        const float pr = outp[o];
+        v = d_out[o] * pr * (1.f - pr);
+      }
+      dl[pl * kHeadMaxCls + k] = v;
+    }
+    __syncthreads();
+    for (int it = tid; it < 64 * g4n; it += kThreads) {
+      const int pl = it / g4n, gq = it - pl * g4n;
+      const long p = p0 + pl;
+      f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+      float ms[4] = {1.f, 1.f, 1.f, 1.f};
+      if (p < pixels) {
+        xv = *reinterpret_cast<const f32x4*>(x + p * C + 4 * gq);
+        if (use_drop) {
+          const uint64_t bits = (mask == nullptr) ? keep_bits(seed, p, g4n, gq) : 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bool keep = (mask != nullptr) ? (mask[p * C + 4 * gq + q] != 0) : keep_one(bits, q, thr16);
+            ms[q] = keep ? keep_scale : 0.f;
+          }
+        }
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < kHeadMaxCls; ++k) {
+          if (k < n_cls) {
+            const float dk = dl[pl * kHeadMaxCls + k];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[q] += wsm[k * C + 4 * gq + q] * dk;
+          }
+        }
+        float* dst = dx + p * C + 4 * gq;
+        f32x4 old = {0.f, 0.f, 0.f, 0.f};
+        if (accumulate) old = *reinterpret_cast<const f32x4*>(dst);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = s[q] * ms[q] + old[q];
+          if (gate_x) v = (xv[q] > 0.f) ? v : 0.f;
+          s[q] = v;
+        }
+        *reinterpret_cast<f32x4*>(dst) = s;
+      }
+      float* xd = &xs[pl * XS + 4 * gq];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xd[q] = xv[q] * ms[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kMaxPairs; ++q) {
+      const int idx = pair0 + q * 128;
+      if (idx < NW) {
+        const int k = idx / C, c = idx - k * C;
+        float s = 0.f;
+        for (int pl = 32 * half; pl < 32 * half + 32; ++pl) s += dl[pl * kHeadMaxCls + k] * xs[pl * XS + c];
+        wacc[q] += s;
+      }
+    }
+    if (tid < n_cls) {
+      float s = 0.f;
+      for (int pl = 0; pl < 64; ++pl) s += dl[pl * kHeadMaxCls + tid];
+      bacc += s;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kMaxPairs; ++q) {
+    const int idx = pair0 + q * 128;
+    if (idx < NW) scratch[half * NW + idx] = wacc[q];
+  }
+  __syncthreads();
+  float* dst = partial + static_cast<long>(blockIdx.x) * (NW + n_cls);
+  for (int i = tid; i < NW; i += kThreads) dst[i] = scratch[i] + scratch[NW + i];
+  if (tid < n_cls) dst[NW + tid] = bacc;
 }
 
 __global__ void sum_partials_kernel(const float* __restrict__ partial, long n_blocks, long len, float* __restrict__ out) {
@@ -771,7 +884,8 @@ extern "C" int unetpp_head_fwd(const float* x, const float* weight, const float*
   if ((C & 3) == 0 && aligned16(x)) {
     const long tiles = (pixels + 63) / 64;
     const unsigned blocks = static_cast<unsigned>(tiles < 256 * 16 ? tiles : 256 * 16);
-    hipLaunchKernelGGL(head_fwd_tiled_kernel, dim3(blocks), dim3(64), 0, ST(stream), x, weight, bias, pixels, H * W, C,
+    hipLaunchKernelGGL(head_fwd_tiled_kernel, dim3(blocks), dim3(64), 64 * (C + 1) * sizeof(float), ST(stream), x, weight,
+                       bias, pixels, H * W, C,
                        n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, use_drop, out_nchw);
     return launch_status();
   }
@@ -794,6 +908,13 @@ extern "C" int unetpp_head_bwd(const float* d_out_nchw, const float* out_nchw, c
     return UNETPP_EINVAL;
   const long pixels = static_cast<long>(N) * H * W;
   const int use_drop = p_drop > 0.f;
+  if ((C & 3) == 0 && aligned16(x) && aligned16(dx)) {
+    const size_t lds = (64 * (C + 1) + 64 * kHeadMaxCls + kHeadMaxCls * C + 2 * n_cls * C) * sizeof(float);
+    hipLaunchKernelGGL(head_bwd_vec_kernel, dim3(static_cast<unsigned>(unetpp_head_bwd_blocks(pixels))), dim3(kThreads),
+                       lds, ST(stream), d_out_nchw, out_nchw, x, weight, pixels, H * W, C, n_cls, 1.0f / (1.0f - p_drop),
+                       keep_threshold(p_drop), seed, mask, use_drop, dx, accumulate, gate_x, partial);
+    return launch_status();
+  }
   hipLaunchKernelGGL(head_bwd_kernel, dim3(static_cast<unsigned>(unetpp_head_bwd_blocks(pixels))), dim3(kThreads), 0,
                      ST(stream), d_out_nchw, out_nchw, x, weight, pixels, H * W, C, n_cls, 1.0f / (1.0f - p_drop),
                      keep_threshold(p_drop), seed, mask, use_drop, dx, accumulate, gate_x, partial);
