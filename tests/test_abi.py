@@ -1,0 +1,107 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds for gfx950, loads without a GPU, and exports
+exactly the entry points include/unetpp_hip.h declares; the ctypes mirrors have the C structs' layout; the
+product refuses to run without the library or on CPU tensors (no fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "unetpp_hip.h")
+
+
+def _declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(unetpp_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    import __graft_entry__ as entry
+    entry.build()
+    from unet_nested4tiny_objects_keypoints_amd import _lib
+    return _lib
+
+
+def test_every_declared_symbol_is_exported(built_lib):
+    names = _declared_functions()
+    assert len(names) >= 25
+    handle = ctypes.CDLL(built_lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(handle, n)]
+    assert not missing, missing
+    # and the Python signature table covers exactly the header
+    assert sorted(built_lib.SIGNATURES) == names
+
+
+def test_exported_symbols_are_plain_c(built_lib):
+    out = subprocess.run(["nm", "-D", "--defined-only", built_lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    assert set(_declared_functions()) <= exported
+    assert built_lib.lib().unetpp_abi_version() == 1
+    assert built_lib.lib().unetpp_build_arch() == b"gfx950"
+
+
+def test_struct_layout_matches_header(built_lib, tmp_path):
+    """sizeof/offsetof from a C compile of the header vs the ctypes mirrors."""
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "unetpp_hip.h"\nint main(void){'
+                   'printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(unetpp_view), offsetof(unetpp_view, gate),'
+                   'offsetof(unetpp_view, gate_sum), sizeof(unetpp_gemm_desc), offsetof(unetpp_gemm_desc, out),'
+                   'offsetof(unetpp_gemm_desc, weight_image), sizeof(unetpp_wgrad_desc), offsetof(unetpp_wgrad_desc, dy),'
+                   'offsetof(unetpp_wgrad_desc, slabs));return 0;}')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    L = built_lib
+    want = [ctypes.sizeof(L.View), L.View.gate.offset, L.View.gate_sum.offset, ctypes.sizeof(L.GemmDesc),
+            L.GemmDesc.out.offset, L.GemmDesc.weight_image.offset, ctypes.sizeof(L.WgradDesc), L.WgradDesc.dy.offset,
+            L.WgradDesc.slabs.offset]
+    assert got == want
+
+
+def test_argument_validation_without_gpu(built_lib):
+    """Entry points that do not touch the device: size queries and argument checks (status codes, no throw)."""
+    lib = built_lib.lib()
+    assert lib.unetpp_gemm_pixel_blocks(32, 256, 256) == 32 * 32 * 8
+    assert lib.unetpp_gemm_pixel_blocks(0, 256, 256) == 0
+    assert lib.unetpp_wgrad_max_split(1, 8, 8) == 1
+    assert lib.unetpp_head_bwd_blocks(100) == 2
+    assert lib.unetpp_bn_bwd_blocks(32 * 256 * 256, 32) % 8 == 0
+    d = built_lib.GemmDesc()
+    assert lib.unetpp_gemm_fwd(ctypes.byref(d), None) == -1          # N = 0
+    assert lib.unetpp_gemm_weight_image_floats(ctypes.byref(d)) == 0
+    d.N, d.H, d.W, d.taps, d.n_in, d.n_out = 1, 8, 8, 5, 1, 1
+    assert lib.unetpp_gemm_fwd(ctypes.byref(d), None) == -1          # taps must be 1 or 9
+    w = built_lib.WgradDesc()
+    assert lib.unetpp_wgrad(ctypes.byref(w), None) == -1
+    assert lib.unetpp_pack_weight(None, None, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, None) == -1
+    assert lib.unetpp_head_fwd(None, None, None, 1, 8, 8, 32, 4, 0.4, 0, None, None, None) == -1
+
+
+def test_no_cpu_fallback():
+    from unet_nested4tiny_objects_keypoints_amd import UNet_Nested, ops
+    m = UNet_Nested(in_channels=1, feature_scale=8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.randn(1, 1, 16, 16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.nchw_to_nhwc(torch.randn(1, 3, 8, 8))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from unet_nested4tiny_objects_keypoints_amd import _lib
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_lib, "_LIB", None)
+    with pytest.raises(RuntimeError, match="not built"):
+        _lib.lib()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "unet_nested4tiny_objects_keypoints_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            text = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), fn

@@ -1,0 +1,105 @@
+"""Data-parallel path on CPU: two processes over gloo (world_size 2) drive the GradientAverager exactly as the
+engine's backward does (gradient-ready order, node by node) and must end with the average of the two ranks'
+gradients in every parameter's slot of the flat buffer; plus host-side checks of the ready order."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle.step_oracle import focal_bce_2d_oracle
+from oracle.unet_nested_oracle import UNetNestedOracle
+from unet_nested4tiny_objects_keypoints_amd import UNet_Nested, dp
+
+CTOR = dict(in_channels=1, n_classes=4, feature_scale=8)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _rank_grads(rank, state):
+    """Per-rank gradients from the CPU oracle on the rank's own shard of data (stands in for the HIP backward)."""
+    ref = UNetNestedOracle(**CTOR)
+    ref.load_state_dict(state)
+    ref.train()
+    ref.drop_out.eval()
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(2, 1, 16, 16, generator=g)
+    t = torch.rand(2, 4, 16, 16, generator=g)
+    outs = ref(x)
+    (sum(focal_bce_2d_oracle(o, t) for o in outs) / len(outs)).backward()
+    return {k: p.grad.clone() for k, p in ref.named_parameters()}
+
+
+def _worker(rank, world, port, state, bucket_bytes, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(rank)  # different initial weights per rank: the broadcast must fix that
+        model = UNet_Nested(**CTOR)
+        if rank == 0:
+            model.load_state_dict(state)
+        avg = dp.make_data_parallel(model, bucket_bytes=bucket_bytes)
+        for k, v in model.state_dict().items():
+            assert torch.equal(v, state[k]), "broadcast did not replicate %s" % k
+        grads = _rank_grads(rank, state)
+        named = dict(model.named_parameters())
+        names = {id(p): k for k, p in named.items()}
+        # play the engine's role: write every gradient into its flat-buffer slot, report node by node
+        order = dp.ready_order(model)
+        step = 4
+        for i in range(0, len(order), step):
+            fresh = []
+            for p in order[i:i + step]:
+                slot = model._grad_alloc(p)
+                slot.copy_(grads[names[id(p)]])
+                fresh.append((p, slot))
+            model._grad_sink(fresh)
+        model._grad_done()
+        out = {names[id(p)]: avg.alloc(p).clone() for p in order}
+        torch.save({"avg": out, "mine": grads, "buckets": avg.buckets_last_step}, os.path.join(result_dir, "r%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_bytes", [1 << 12, 1 << 30])
+def test_gradient_average_world2(tmp_path, bucket_bytes):
+    torch.manual_seed(0)
+    state = UNetNestedOracle(**CTOR).state_dict()
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, state, bucket_bytes, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "r0.pt")
+    r1 = torch.load(tmp_path / "r1.pt")
+    for k in r0["mine"]:
+        want = (r0["mine"][k] + r1["mine"][k]) / 2
+        assert torch.allclose(r0["avg"][k], want, rtol=1e-6, atol=1e-12), k
+        assert torch.equal(r0["avg"][k], r1["avg"][k]), k
+    n_buckets = len(r0["buckets"])
+    assert n_buckets == (1 if bucket_bytes == 1 << 30 else n_buckets) and n_buckets >= 1
+    if bucket_bytes == 1 << 12:
+        assert n_buckets > 3  # small buckets: several overlapped all-reduces
+    # buckets tile the flat buffer exactly once, in order
+    flat = sum(v.numel() for v in r0["mine"].values())
+    assert r0["buckets"][0][0] == 0 and r0["buckets"][-1][1] == flat
+    assert all(a[1] == b[0] for a, b in zip(r0["buckets"], r0["buckets"][1:]))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(depth=5, feature_scale=8), dict(is_deconv=False), dict(is_batchnorm=False),
+                                dict(depth=2)])
+def test_ready_order_covers_every_parameter_once(kw):
+    m = UNet_Nested(**kw)
+    order = dp.ready_order(m)
+    assert {id(p) for p in order} == {id(p) for p in m.parameters()}
+    names = {id(p): k for k, p in m.named_parameters()}
+    first = names[id(order[0])]
+    last = names[id(order[-1])]
+    assert first.startswith("final_%d" % (m.depth - 1))       # heads finish first ...
+    assert last.startswith("conv00.conv1")                    # ... the first encoder conv last
