@@ -75,20 +75,57 @@ __global__ void pack_image_kernel(const FastArgs a, float* __restrict__ img) {
   img[i] = v;
 }
 
-template <int TAPS>
+// A unit of work = (256-pixel patch, 32-column tile), column tile fastest.  Workgroups are PERSISTENT: the grid is
+// at most 3 per CU and every workgroup walks its units as one flat stream of K chunks, so the first chunk of the
+// next unit is prefetched under the last MFMA loop of the current one and the epilogue's stores drain under the next
+// unit's MFMAs.  (With one unit per workgroup the co-resident workgroups run in lockstep -- all load, all compute,
+// all store -- and a short-K unit spends 40 % of its time outside the MFMA loop.)
+struct UnitGeom {
+  int n, ty0, tx0;        // image, patch origin
+  int nt_global, nt, ov;  // column tile (global index; index inside its out view; the out view)
+  int n0, n_cnt;          // first GEMM column, valid columns
+  long patch;             // pixel-patch index (BatchNorm partial row)
+};
+
+template <int LOG2TW>
+__device__ __forceinline__ UnitGeom decode_unit(const FastArgs& a, long lb) {
+  constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;
+  UnitGeom g;
+  g.nt_global = static_cast<int>(lb % a.n_tiles);
+  long bid = lb / a.n_tiles;
+  g.patch = bid;
+  const int txi = static_cast<int>(bid % a.tiles_x);
+  bid /= a.tiles_x;
+  const int tyi = static_cast<int>(bid % a.tiles_y);
+  g.n = static_cast<int>(bid / a.tiles_y);
+  g.ty0 = tyi * TH;
+  g.tx0 = txi * TW;
+  int nt = g.nt_global, ov = 0, col_base = 0;
+  while (ov < a.d.n_out - 1) {
+    const int tiles_v = (a.d.out[ov].c_len + 31) >> 5;
+    if (nt < tiles_v) break;
+    nt -= tiles_v;
+    col_base += a.d.out[ov].c_len;
+    ++ov;
+  }
+  g.nt = nt;
+  g.ov = ov;
+  g.n0 = col_base + nt * 32;
+  g.n_cnt = min(32, a.d.out[ov].c_len - nt * 32);
+  return g;
+}
+
+template <int TAPS, int LOG2TW>
 __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a) {
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
+  constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;   // compile-time patch shape: every
+  constexpr int HWp = TW + 2 * HALO, HHp = TH + 2 * HALO;        // division below is by a constant
+  constexpr int NPIX = HWp * HHp;
   constexpr int MAXPIX = (TAPS == 9) ? kMaxHaloPixels : kBlockPixels;
-#ifdef UNETPP_A_SWIZZLE
-  constexpr int KCP = 16;
-#define A_ADDR(hp, slot) ((hp) * 16 + ((((slot)) ^ (((hp) >> 2) & 3)) << 2))
-#else
   constexpr int KCP = 20;  // input pixel stride in LDS (floats)
-#define A_ADDR(hp, slot) ((hp) * 20 + ((slot) << 2))
-#endif
   constexpr int IN_FLOATS = MAXPIX * KCP;
   constexpr int IMG = TAPS * 512;
-  constexpr int IN_ITEMS = (MAXPIX * 4 + kThreads - 1) / kThreads;
+  constexpr int IN_ITEMS = (NPIX * 4 + kThreads - 1) / kThreads;
   constexpr int W_ITEMS = (IMG / 4 + kThreads - 1) / kThreads;
   __shared__ __attribute__((aligned(16))) float smem[IN_FLOATS + IMG];
   float* in_tile = smem;
@@ -98,49 +135,31 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
 
-  // ---- which pixel patch, which 32 output columns (column tile fastest, XCD-contiguous) ----
-  const long lb = xcd_remap(blockIdx.x, a.total_blocks);
-  int nt = static_cast<int>(lb % a.n_tiles);
-  const int nt_global = nt;
-  long bid = lb / a.n_tiles;
-  const int txi = static_cast<int>(bid % a.tiles_x);
-  bid /= a.tiles_x;
-  const int tyi = static_cast<int>(bid % a.tiles_y);
-  const int n = static_cast<int>(bid / a.tiles_y);
-  const int TW = 1 << a.log2tw, TH = kBlockPixels >> a.log2tw;
-  const int ty0 = tyi * TH, tx0 = txi * TW;
-  const int HWp = TW + 2 * HALO, HHp = TH + 2 * HALO;
-  const int npix = HWp * HHp;
-
-  int ov = 0, col_base = 0;
-  while (ov < d.n_out - 1) {
-    const int tiles_v = (d.out[ov].c_len + 31) >> 5;
-    if (nt < tiles_v) break;
-    nt -= tiles_v;
-    col_base += d.out[ov].c_len;
-    ++ov;
+  // ---- this workgroup's units: XCD x = blockIdx & 7 owns a contiguous range of units (neighbouring patches
+  // share an L2), its workgroups take them round-robin ----
+  const long W8 = gridDim.x >> 3;  // workgroups per XCD label (the launcher makes gridDim.x a multiple of 8
+                                   // whenever a workgroup has more than one unit)
+  long first_unit, unit_step, my_units;
+  if (gridDim.x >= a.total_blocks) {
+    first_unit = xcd_remap(blockIdx.x, a.total_blocks);
+    unit_step = 0;
+    my_units = 1;
+  } else {
+    const long q = a.total_blocks >> 3, r = a.total_blocks & 7;
+    const long xcd = blockIdx.x & 7, widx = blockIdx.x >> 3;
+    const long start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const long cnt = q + (xcd < r ? 1 : 0);
+    first_unit = start + widx;
+    unit_step = W8;
+    my_units = widx < cnt ? (cnt - widx + W8 - 1) / W8 : 0;
   }
-  const unetpp_view& O = d.out[ov];
-  const int n0 = col_base + nt * 32;
-  const int n_cnt = min(32, O.c_len - nt * 32);
+  if (my_units == 0) return;
 
-  // ---- per-thread staging items.  Kept in registers across the K loop: one 32-bit element offset per item and
-  // one bit per item (pixel inside the image); everything else is recomputed from tid where it is needed, so
-  // the MFMA loop keeps enough registers to software-pipeline its LDS reads. ----
-  unsigned in_mask = 0;
-#pragma unroll
-  for (int q = 0; q < IN_ITEMS; ++q) {
-    const int it = tid + q * kThreads;
-    const int hp = it >> 2;
-    const int hy = hp / HWp, hx = hp - hy * HWp;
-    const int y = ty0 + hy - HALO, x = tx0 + hx - HALO;
-    if ((it < npix * 4) && y >= 0 && y < d.H && x >= 0 && x < d.W) in_mask |= 1u << q;
-  }
   int apix[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int p = 64 * wave + 32 * mt + j;
-    apix[mt] = (p >> a.log2tw) * HWp + (p & (TW - 1));
+    apix[mt] = (p >> LOG2TW) * HWp + (p & (TW - 1));
   }
   const int wb = j * 8 + ((h ^ ((j >> 3) & 1)) << 2);
 
@@ -150,37 +169,55 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
+  // ---- prefetch side: the chunk that is loaded next.  Per-thread state: one 32-bit element offset per staging
+  // item and one in-image bit per item; everything else is recomputed from tid where needed. ----
   f32x4 reg_in[IN_ITEMS], reg_w[W_ITEMS];
-  // element offsets, unsigned 32-bit so the loads use the scalar-base + vector-offset form (no 64-bit address
-  // register pairs); the launcher only takes this path for tensors below 2^31 elements
-  unsigned voff[IN_ITEMS];
-  int pf_cnt = 0;      // valid channels of the chunk currently held in reg_in
-  const float* wimg = d.weight_image + static_cast<long>(nt_global) * a.n_chunks * IMG;
+  unsigned voff[IN_ITEMS];   // element offsets (the launcher only takes this path for tensors < 2^31 elements)
+  unsigned in_mask = 0;
+  int pf_cnt = 0;            // valid channels of the chunk held in reg_in
+  long p_unit = 0;           // index into this workgroup's units
+  int p_s = 0, p_c0 = 0, p_chunk = 0;
+  int p_n = 0, p_ty0 = 0, p_tx0 = 0;
+  const float* p_wimg = nullptr;
 
-  // chunk cursor
-  int s = 0, c0 = 0;
-  // The prefetch is straight-line code: every item loads from a VALID address (out-of-image halo pixels and
-  // padding items are clamped into the image, channels past the view to channel 0) and the zeroing happens
-  // at the LDS write.  Conditional loads would put the loads under divergent branches, where hipcc drains
-  // vmcnt at every join and the prefetch stops overlapping the MFMA loop.
+  auto prefetch_unit = [&](long k) {  // geometry of unit k for the loads
+    const UnitGeom g = decode_unit<LOG2TW>(a, first_unit + k * unit_step);
+    p_n = g.n;
+    p_ty0 = g.ty0;
+    p_tx0 = g.tx0;
+    p_wimg = d.weight_image + static_cast<long>(g.nt_global) * a.n_chunks * IMG;
+    in_mask = 0;
+#pragma unroll
+    for (int q = 0; q < IN_ITEMS; ++q) {
+      const int it = tid + q * kThreads;
+      const int hp = it >> 2;
+      const int hy = hp / HWp, hx = hp - hy * HWp;
+      const int y = p_ty0 + hy - HALO, x = p_tx0 + hx - HALO;
+      if ((it < NPIX * 4) && y >= 0 && y < d.H && x >= 0 && x < d.W) in_mask |= 1u << q;
+    }
+  };
+  // The loads are straight-line code: every item loads from a VALID address (out-of-image halo pixels and padding
+  // items are clamped into the image, channels past the view to channel 0) and the zeroing happens at the LDS
+  // write.  Conditional loads would sit under divergent branches, where hipcc drains vmcnt at every join.
   auto view_offsets = [&](const unetpp_view& V) {
 #pragma unroll
     for (int q = 0; q < IN_ITEMS; ++q) {
-      const int hp = (tid + q * kThreads) >> 2;
+      const int hp = min((tid + q * kThreads) >> 2, NPIX - 1);
       const int hy = hp / HWp, hx = hp - hy * HWp;
-      const int yy = min(max(ty0 + hy - HALO, 0), d.H - 1), xx = min(max(tx0 + hx - HALO, 0), d.W - 1);
-      voff[q] = static_cast<unsigned>(view_pixel_offset(V, n, yy, xx));
+      const int yy = min(max(p_ty0 + hy - HALO, 0), d.H - 1), xx = min(max(p_tx0 + hx - HALO, 0), d.W - 1);
+      voff[q] = static_cast<unsigned>(view_pixel_offset(V, p_n, yy, xx));
     }
   };
-  auto load_chunk = [&](const unetpp_view& V, int cbeg, int chunk_idx) {
-    pf_cnt = min(KC, V.c_len - cbeg);
+  auto load_chunk = [&]() {
+    const unetpp_view& V = d.in[p_s];
+    pf_cnt = min(KC, V.c_len - p_c0);
 #pragma unroll
     for (int q = 0; q < IN_ITEMS; ++q) {
       const int cc = ((tid + q * kThreads) & 3) << 2;
-      const unsigned off = voff[q] + static_cast<unsigned>(cbeg + (cc < pf_cnt ? cc : 0));
+      const unsigned off = voff[q] + static_cast<unsigned>(p_c0 + (cc < pf_cnt ? cc : 0));
       reg_in[q] = *reinterpret_cast<const f32x4*>(V.ptr + off);
     }
-    const float* wp = wimg + static_cast<long>(chunk_idx) * IMG;
+    const float* wp = p_wimg + static_cast<long>(p_chunk) * IMG;
 #pragma unroll
     for (int q = 0; q < W_ITEMS; ++q) {
       const unsigned it = min(tid + q * kThreads, IMG / 4 - 1);
@@ -196,7 +233,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
       f32x4 v = reg_in[q];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0.f;
-      if (it < npix * 4) *reinterpret_cast<f32x4*>(&in_tile[A_ADDR(hp, q4)]) = v;
+      if (it < NPIX * 4) *reinterpret_cast<f32x4*>(&in_tile[hp * KCP + (q4 << 2)]) = v;
     }
 #pragma unroll
     for (int q = 0; q < W_ITEMS; ++q) {
@@ -213,29 +250,105 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
     const int tpix = (TAPS == 9) ? (tap / 3) * HWp + (tap % 3) : 0;
     Frag f;
     f.b = *reinterpret_cast<const f32x4*>(&w_tile[step * 256 + wb]);
-    const int hp0 = apix[0] + tpix, hp1 = apix[1] + tpix;
-    f.a0 = *reinterpret_cast<const f32x4*>(&in_tile[A_ADDR(hp0, 2 * g + h)]);
-    f.a1 = *reinterpret_cast<const f32x4*>(&in_tile[A_ADDR(hp1, 2 * g + h)]);
+    f.a0 = *reinterpret_cast<const f32x4*>(&in_tile[(apix[0] + tpix) * KCP + ((2 * g + h) << 2)]);
+    f.a1 = *reinterpret_cast<const f32x4*>(&in_tile[(apix[1] + tpix) * KCP + ((2 * g + h) << 2)]);
     return f;
   };
+  // epilogue of the unit whose K loop just finished: bias, ReLU, gate, store / accumulate, optional BatchNorm
+  // partial sums.  Accumulator register r of lane (j, h) is pixel p = 64*wave + 32*mt + 4h + c(r),
+  // c(r) = (r&3) + 8*(r>>2); with the compile-time patch shape its offset is
+  // lane_base + (c >> LOG2TW)*row_stride + (c & (TW-1))*col_stride.
+  auto epilogue = [&](long k) {
+    const UnitGeom g = decode_unit<LOG2TW>(a, first_unit + k * unit_step);
+    const unetpp_view& O = d.out[g.ov];
+    const bool col_ok = j < g.n_cnt;
+    const float bj = (d.bias != nullptr && col_ok) ? d.bias[g.n0 + j] : 0.f;
+    const long row_stride = static_cast<long>(O.sy) * O.Ws * O.C, col_stride = static_cast<long>(O.sx) * O.C;
+    const long tile_base = view_pixel_offset(O, g.n, g.ty0, g.tx0) + g.nt * 32 + j;
+    const bool interior = (g.ty0 + TH <= d.H) && (g.tx0 + TW <= d.W);
+    float s1 = 0.f, s2sum = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int prow = (64 * wave + 32 * mt) >> LOG2TW;  // first patch row of this MFMA tile
+      const long lane_base = tile_base + prow * row_stride + (4 * h) * col_stride;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int c = (r & 3) + 8 * (r >> 2);
+        const int dy = c >> LOG2TW, dx = c & (TW - 1);
+        const bool ok = col_ok && (interior || ((g.ty0 + prow + dy < d.H) && (g.tx0 + 4 * h + dx < d.W)));
+        if (ok) {
+          float v = acc[mt][r] + bj;
+          if (O.relu) v = fmaxf(v, 0.f);
+          s1 += v;
+          s2sum += v * v;
+          const long off = lane_base + dy * row_stride + dx * col_stride;
+          if (O.gate != nullptr && !O.gate_sum) v = (O.gate[off] > 0.f) ? v : 0.f;
+          if (O.accumulate) v += O.ptr[off];
+          if (O.gate != nullptr && O.gate_sum) v = (O.gate[off] > 0.f) ? v : 0.f;
+          O.ptr[off] = v;
+        }
+        acc[mt][r] = 0.f;
+      }
+    }
+    if (d.stats_partial != nullptr) {  // the LDS tiles are free here (barrier after the MFMA loop)
+      s1 += __shfl_xor(s1, 32);
+      s2sum += __shfl_xor(s2sum, 32);
+      if (h == 0) {
+        smem[(wave * 32 + j) * 2 + 0] = s1;
+        smem[(wave * 32 + j) * 2 + 1] = s2sum;
+      }
+      __syncthreads();
+      if (tid < g.n_cnt) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          t1 += smem[(w * 32 + tid) * 2 + 0];
+          t2 += smem[(w * 32 + tid) * 2 + 1];
+        }
+        float* dst = d.stats_partial + (g.patch * a.Ncols + g.n0 + tid) * 2;
+        dst[0] = t1;
+        dst[1] = t2;
+      }
+      __syncthreads();  // before the next chunk overwrites the scratch
+    }
+  };
 
+  prefetch_unit(0);
   view_offsets(d.in[0]);
-  load_chunk(d.in[0], 0, 0);
+  load_chunk();
   store_chunk();
   __syncthreads();
 
-  for (int chunk = 0; chunk < a.n_chunks; ++chunk) {
-    // advance the cursor and prefetch the next chunk into registers
-    int s2 = s, c2 = c0 + KC;
-    if (c2 >= d.in[s].c_len) {
-      ++s2;
-      c2 = 0;
+  long c_unit = 0;   // compute side: unit and chunk currently in LDS
+  int c_chunk = 0;
+  while (true) {
+    // ---- advance the prefetch cursor: next chunk of this unit, or chunk 0 of the next unit ----
+    bool more = true;
+    {
+      int s2 = p_s, c2 = p_c0 + KC;
+      if (c2 >= d.in[p_s].c_len) {
+        ++s2;
+        c2 = 0;
+      }
+      if (p_chunk + 1 < a.n_chunks) {
+        ++p_chunk;
+        if (s2 != p_s) {
+          p_s = s2;
+          view_offsets(d.in[p_s]);
+        }
+        p_c0 = c2;
+      } else if (p_unit + 1 < my_units) {
+        ++p_unit;
+        p_chunk = 0;
+        p_s = 0;
+        p_c0 = 0;
+        prefetch_unit(p_unit);
+        view_offsets(d.in[0]);
+      } else {
+        more = false;
+      }
     }
-    const bool more = chunk + 1 < a.n_chunks;
-    if (more) {
-      if (s2 != s) view_offsets(d.in[s2]);
-      load_chunk(d.in[s2], c2, chunk + 1);
-    }
+    if (more) load_chunk();
     // ---- LDS -> MFMA for the current chunk: the fragments of step k+1 are read while the 8 MFMAs of step k
     // issue (both 8-channel groups always run; a short last chunk is zero-padded in LDS) ----
     Frag cur = read_frag(0);
@@ -250,58 +363,16 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
       cur = nxt;
     }
     __syncthreads();
-    if (more) {
-      store_chunk();
-      __syncthreads();
+    if (c_chunk + 1 == a.n_chunks) {
+      epilogue(c_unit);  // stores drain while the next unit computes; the next chunk's loads are already in flight
+      ++c_unit;
+      c_chunk = 0;
+    } else {
+      ++c_chunk;
     }
-    s = s2;
-    c0 = c2;
-  }
-
-  // ---- epilogue: bias, ReLU, gate, store / accumulate, optional BatchNorm partial sums ----
-  const bool col_ok = j < n_cnt;
-  const float bj = (d.bias != nullptr && col_ok) ? d.bias[n0 + j] : 0.f;
-  float s1 = 0.f, s2sum = 0.f;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const int p = 64 * wave + 32 * mt + i;
-      const int y = ty0 + (p >> a.log2tw), x = tx0 + (p & (TW - 1));
-      if (col_ok && y < d.H && x < d.W) {
-        float v = acc[mt][r] + bj;
-        if (O.relu) v = fmaxf(v, 0.f);
-        s1 += v;
-        s2sum += v * v;
-        const long off = view_pixel_offset(O, n, y, x) + nt * 32 + j;
-        if (O.gate != nullptr && !O.gate_sum) v = (O.gate[off] > 0.f) ? v : 0.f;
-        if (O.accumulate) v += O.ptr[off];
-        if (O.gate != nullptr && O.gate_sum) v = (O.gate[off] > 0.f) ? v : 0.f;
-        O.ptr[off] = v;
-      }
-    }
-  }
-  if (d.stats_partial != nullptr) {
-    s1 += __shfl_xor(s1, 32);
-    s2sum += __shfl_xor(s2sum, 32);
-    if (h == 0) {
-      smem[(wave * 32 + j) * 2 + 0] = s1;
-      smem[(wave * 32 + j) * 2 + 1] = s2sum;
-    }
+    if (!more) break;
+    store_chunk();
     __syncthreads();
-    if (tid < n_cnt) {
-      float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        t1 += smem[(w * 32 + tid) * 2 + 0];
-        t2 += smem[(w * 32 + tid) * 2 + 1];
-      }
-      // partial rows are indexed by the pixel patch (not by the remapped block id)
-      float* dst = d.stats_partial + ((lb / a.n_tiles) * a.Ncols + n0 + tid) * 2;
-      dst[0] = t1;
-      dst[1] = t2;
-    }
   }
 }
 
@@ -339,11 +410,23 @@ int launch_gemm_fast(const unetpp_gemm_desc* d, hipStream_t st) {
   FastArgs a;
   if (!fast_args(d, a) || d->weight_image == nullptr) return UNETPP_EINVAL;
   if (d->stats_partial != nullptr && d->n_out != 1) return UNETPP_EINVAL;
-  const dim3 grid(static_cast<unsigned>(a.total_blocks));
-  if (d->taps == 9)
-    hipLaunchKernelGGL(gemm_fast_kernel<9>, grid, dim3(kThreads), 0, st, a);
-  else
-    hipLaunchKernelGGL(gemm_fast_kernel<1>, grid, dim3(kThreads), 0, st, a);
+  // persistent grid: at most 3 workgroups per CU (the kernel's LDS/VGPR budget), a multiple of 8
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return UNETPP_ELAUNCH;
+  long workers = (3L * cus) & ~7L;
+  if (workers < 8) workers = 8;
+  const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(kThreads);
+  if (d->taps == 9) {
+    if (a.log2tw == 5) hipLaunchKernelGGL((gemm_fast_kernel<9, 5>), grid, block, 0, st, a);
+    else if (a.log2tw == 4) hipLaunchKernelGGL((gemm_fast_kernel<9, 4>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((gemm_fast_kernel<9, 3>), grid, block, 0, st, a);
+  } else {
+    if (a.log2tw == 5) hipLaunchKernelGGL((gemm_fast_kernel<1, 5>), grid, block, 0, st, a);
+    else if (a.log2tw == 4) hipLaunchKernelGGL((gemm_fast_kernel<1, 4>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((gemm_fast_kernel<1, 3>), grid, block, 0, st, a);
+  }
   return launch_status();
 }
 

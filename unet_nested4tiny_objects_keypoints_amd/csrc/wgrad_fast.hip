@@ -3,11 +3,15 @@
 //
 //   * 512 threads = 8 waves per workgroup, one workgroup per CU (2 waves per SIMD); every wave owns 32 of the
 //     tile's 256 pixels and keeps 9 taps x 16 accumulator registers live across the whole pixel loop;
-//   * two LDS buffers (x patch with halo 43.5 KB + dy patch 32 KB each, 151 KB in all): while the MFMAs of
-//     tile t read buffer t&1, the registers holding tile t+1 are written to the other buffer and the global
-//     loads of tile t+2 are issued -- one barrier per tile, HBM/L2 latency and the LDS fill hide under
-//     ~9 k cycles of MFMA work;
-//   * staging geometry (halo position of every item) is computed once per workgroup.
+//   * two LDS buffers (x patch with halo 43.5 KB + dy patch 32 KB each, 151 KB in all).  The next tile is staged
+//     into the buffer the MFMAs are NOT reading, in FOUR slices interleaved with the four quarters of the MFMA
+//     loop: a slice's global loads are issued before a quarter (36 MFMAs, ~2.3 k cycles) and written to LDS
+//     after it, so only 12 staging registers are live instead of 40 and the MFMA loop keeps room to
+//     software-pipeline its operands (the 10 LDS reads of pixel pair p+1 are issued before the 9 MFMAs of pair p).
+//     One barrier per tile.  (LDS-DMA was tried: hipcc drains vmcnt before every ds_read while a DMA is in
+//     flight, which serialises the tile pipeline.)
+//   * the tile shape (TW = 8/16/32) is a template parameter: every LDS address of the MFMA loop is the lane's base
+//     plus an immediate, no address registers.
 // The 8 waves are summed through LDS in fixed order; one slab per workgroup (bitwise reproducible).
 #include "common.h"
 
@@ -18,21 +22,26 @@ constexpr int kWThreads = 512;
 
 struct WFastArgs {
   unetpp_wgrad_desc d;
-  int log2tw, tiles_x, tiles_y;
+  int tiles_x, tiles_y;
   int Ktot, Ncols, n_tiles_cols;
   long n_pix_tiles;
 };
 
-template <int TAPS>
+template <int TAPS, int LOG2TW>
 __global__ __launch_bounds__(kWThreads, 2) void wgrad_fast_kernel(const WFastArgs a) {
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
+  constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;
+  constexpr int HWp = TW + 2 * HALO, HHp = TH + 2 * HALO;
+  constexpr int NPIX = HWp * HHp;
   constexpr int XPIX = (TAPS == 9) ? kMaxHaloPixels : kBlockPixels;
   constexpr int X_FLOATS = XPIX * 32;
   constexpr int DY_FLOATS = kBlockPixels * 32;
   constexpr int BUF = X_FLOATS + DY_FLOATS;
-  constexpr int X_ITEMS = (XPIX * 8 + kWThreads - 1) / kWThreads;
-  constexpr int DY_ITEMS = (kBlockPixels * 8) / kWThreads;
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // 2 * BUF floats
+  constexpr int X_ITEMS = (NPIX * 8 + kWThreads - 1) / kWThreads;   // <= 6
+  constexpr int DY_ITEMS = (kBlockPixels * 8) / kWThreads;          // 4
+  constexpr int N_ITEMS = X_ITEMS + DY_ITEMS;
+  constexpr int SLICE = (N_ITEMS + 3) / 4;                          // items per pipeline slice (<= 3)
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // 2 * BUF floats
 
   const unetpp_wgrad_desc& d = a.d;
   const int tid = threadIdx.x;
@@ -65,66 +74,57 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_fast_kernel(const WFastArg
   const int n_cnt = min(32, DY.c_len - nc0);
   const bool want_db = (blockIdx.y / a.n_tiles_cols) == 0;
 
-  const int TW = 1 << a.log2tw, TH = kBlockPixels >> a.log2tw;
-  const int HWp = TW + 2 * HALO, HHp = TH + 2 * HALO;
-  const int npix = HWp * HHp;
-
-  // ---- staging items, geometry relative to the tile origin (tile-invariant) ----
-  int xi_dy[X_ITEMS], xi_dx[X_ITEMS], xi_lds[X_ITEMS];
-#pragma unroll
-  for (int q = 0; q < X_ITEMS; ++q) {
-    const int it = tid + q * kWThreads;
-    const int hp = it >> 3, cc = (it & 7) << 2;
-    const int hy = hp / HWp;
-    xi_dy[q] = hy - HALO;
-    xi_dx[q] = hp - hy * HWp - HALO;
-    xi_lds[q] = (it < npix * 8 && cc < k_cnt) ? hp * 32 + cc : -1;
+  // columns / channels that are never staged must read as zero in both buffers (full 32x32 tiles stage everything)
+  if (k_cnt < 32 || n_cnt < 32) {
+    for (int i = tid; i < 2 * BUF; i += kWThreads) smem[i] = 0.f;
+    __syncthreads();
   }
-  int di_dy[DY_ITEMS], di_dx[DY_ITEMS], di_lds[DY_ITEMS];
-#pragma unroll
-  for (int q = 0; q < DY_ITEMS; ++q) {
-    const int it = tid + q * kWThreads;
-    const int p = it >> 3, cc = (it & 7) << 2;
-    di_dy[q] = p >> a.log2tw;
-    di_dx[q] = p & (TW - 1);
-    di_lds[q] = (cc < n_cnt) ? p * 32 + cc : -1;
-  }
-  // columns / channels that are never staged must read as zero in both buffers
-  for (int i = tid; i < 2 * BUF; i += kWThreads) smem[i] = 0.f;
-  __syncthreads();
 
-  f32x4 rx[X_ITEMS], rdy[DY_ITEMS];
-  auto load_tile = [&](long tile) {
+  // ---- staging items 0..X_ITEMS-1: x patch, X_ITEMS..N_ITEMS-1: dy patch.  Item geometry is recomputed from
+  // tid (compile-time patch shape: the divisions are by constants). ----
+  int ty0 = 0, tx0 = 0, img = 0;  // tile being staged
+  auto set_tile = [&](long tile) {
     long b = tile;
     const int txi = static_cast<int>(b % a.tiles_x);
     b /= a.tiles_x;
     const int tyi = static_cast<int>(b % a.tiles_y);
-    const int n = static_cast<int>(b / a.tiles_y);
-    const int ty0 = tyi * TH, tx0 = txi * TW;
-#pragma unroll
-    for (int q = 0; q < X_ITEMS; ++q) {
-      const int y = ty0 + xi_dy[q], x = tx0 + xi_dx[q];
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (xi_lds[q] >= 0 && y >= 0 && y < d.H && x >= 0 && x < d.W)
-        v = *reinterpret_cast<const f32x4*>(X.ptr + view_pixel_offset(X, n, y, x) + c0 + ((xi_lds[q] & 31)));
-      rx[q] = v;
-    }
-#pragma unroll
-    for (int q = 0; q < DY_ITEMS; ++q) {
-      const int y = ty0 + di_dy[q], x = tx0 + di_dx[q];
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (di_lds[q] >= 0 && y < d.H && x < d.W)
-        v = *reinterpret_cast<const f32x4*>(DY.ptr + view_pixel_offset(DY, n, y, x) + nc0 + (di_lds[q] & 31));
-      rdy[q] = v;
-    }
+    img = static_cast<int>(b / a.tiles_y);
+    ty0 = tyi * TH;
+    tx0 = txi * TW;
   };
-  auto store_tile = [&](float* buf) {
+  // Loads are branch-free (coordinates clamped into the image, channels past the tile clamped to 0) so that
+  // hipcc keeps them in flight across the MFMA quarter; the zeroing happens at the LDS write.
+  auto load_item = [&](int q) -> f32x4 {
+    if (q < X_ITEMS) {
+      const int it = tid + q * kWThreads;
+      const int hp = min(it >> 3, NPIX - 1), cc = (it & 7) << 2;
+      const int hy = hp / HWp, hx = hp - hy * HWp;
+      const int y = min(max(ty0 + hy - HALO, 0), d.H - 1), x = min(max(tx0 + hx - HALO, 0), d.W - 1);
+      return *reinterpret_cast<const f32x4*>(X.ptr + view_pixel_offset(X, img, y, x) + c0 + (cc < k_cnt ? cc : 0));
+    }
+    const int it = tid + (q - X_ITEMS) * kWThreads;
+    const int p = it >> 3, cc = (it & 7) << 2;
+    const int y = min(ty0 + (p >> LOG2TW), d.H - 1), x = min(tx0 + (p & (TW - 1)), d.W - 1);
+    return *reinterpret_cast<const f32x4*>(DY.ptr + view_pixel_offset(DY, img, y, x) + nc0 + (cc < n_cnt ? cc : 0));
+  };
+  auto store_item = [&](int q, float* buf, f32x4 v) {
+    if (q < X_ITEMS) {
+      const int it = tid + q * kWThreads;
+      const int hp = it >> 3;
+      const int hy = hp / HWp, hx = hp - hy * HWp;
+      const int y = ty0 + hy - HALO, x = tx0 + hx - HALO;
+      const bool keep = y >= 0 && y < d.H && x >= 0 && x < d.W;
 #pragma unroll
-    for (int q = 0; q < X_ITEMS; ++q)
-      if (xi_lds[q] >= 0) *reinterpret_cast<f32x4*>(&buf[xi_lds[q]]) = rx[q];
+      for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0.f;
+      if (it < NPIX * 8 && ((it & 7) << 2) < k_cnt) *reinterpret_cast<f32x4*>(&buf[it * 4]) = v;
+    } else {
+      const int it = tid + (q - X_ITEMS) * kWThreads;
+      const int p = it >> 3;
+      const bool keep = ty0 + (p >> LOG2TW) < d.H && tx0 + (p & (TW - 1)) < d.W;
 #pragma unroll
-    for (int q = 0; q < DY_ITEMS; ++q)
-      if (di_lds[q] >= 0) *reinterpret_cast<f32x4*>(&buf[X_FLOATS + di_lds[q]]) = rdy[q];
+      for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0.f;
+      if (((it & 7) << 2) < n_cnt) *reinterpret_cast<f32x4*>(&buf[X_FLOATS + it * 4]) = v;
+    }
   };
 
   f32x16 acc[TAPS];
@@ -134,35 +134,62 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_fast_kernel(const WFastArg
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   float dbsum = 0.f;
 
+  // operands of one pixel pair: B = dy[p][col j], A[t] = x[p (+) tap t][channel j]; p = 32*wave + 2*pp + h
+  struct Ops {
+    float b;
+    float a[TAPS];
+  };
+  const int p_base = 32 * wave + h;
+  auto read_ops = [&](const float* buf, int pp) {
+    const int p = p_base + 2 * pp;
+    Ops o;
+    o.b = buf[X_FLOATS + p * 32 + j];
+    const int xb = ((p >> LOG2TW) * HWp + (p & (TW - 1))) * 32 + j;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) o.a[t] = buf[xb + ((TAPS == 9) ? ((t / 3) * HWp + (t % 3)) * 32 : 0)];
+    return o;
+  };
+
   // tiles of this workgroup: blockIdx.x, +gridDim.x, ...
   const long stride = gridDim.x;
-  long t0 = blockIdx.x;
-  long n_my = (t0 < a.n_pix_tiles) ? (a.n_pix_tiles - t0 + stride - 1) / stride : 0;
+  const long t0 = blockIdx.x;
+  const long n_my = (t0 < a.n_pix_tiles) ? (a.n_pix_tiles - t0 + stride - 1) / stride : 0;
   if (n_my > 0) {
-    load_tile(t0);
-    store_tile(smem);
-    if (n_my > 1) load_tile(t0 + stride);
+    set_tile(t0);
+#pragma unroll
+    for (int q = 0; q < N_ITEMS; ++q) store_item(q, smem, load_item(q));
   }
   __syncthreads();
   for (long i = 0; i < n_my; ++i) {
-    float* cur = smem + (i & 1) * BUF;
-    float* nxt = smem + ((i + 1) & 1) * BUF;
-    if (i + 1 < n_my) {
-      store_tile(nxt);  // registers hold tile i+1; `nxt` was last read in iteration i-1 (barrier below)
-      if (i + 2 < n_my) load_tile(t0 + (i + 2) * stride);
-    }
-    const float* x_tile = cur;
-    const float* dy_tile = cur + X_FLOATS;
-#pragma unroll 4
-    for (int pp = 0; pp < 16; ++pp) {
-      const int p = 32 * wave + 2 * pp + h;
-      const float bv = dy_tile[p * 32 + j];
-      dbsum += bv;
-      const int xb = ((p >> a.log2tw) * HWp + (p & (TW - 1))) * 32 + j;
+    const float* cur = smem + (i & 1) * BUF;
+    float* nxt = smem + ((i + 1) & 1) * BUF;  // last read in iteration i-1 (barrier at its end)
+    const bool more = i + 1 < n_my;
+    if (more) set_tile(t0 + (i + 1) * stride);
+    Ops o = read_ops(cur, 0);
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        const int toff = (TAPS == 9) ? ((t / 3) * HWp + (t % 3)) * 32 : 0;
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(x_tile[xb + toff], bv, acc[t], 0, 0, 0);
+    for (int quarter = 0; quarter < 4; ++quarter) {
+      f32x4 stage[SLICE];
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < SLICE; ++u)
+          if (quarter * SLICE + u < N_ITEMS) stage[u] = load_item(quarter * SLICE + u);
+      }
+#pragma unroll
+      for (int pq = 0; pq < 4; ++pq) {
+        const int pp = quarter * 4 + pq;
+        Ops nx = o;
+        if (pp + 1 < 16) nx = read_ops(cur, pp + 1);
+        // (pinning "next pair's reads before this pair's MFMAs" with sched_barrier measured 2 % slower than
+        // hipcc's own order: with two waves per SIMD the LDS latency is already covered)
+        dbsum += o.b;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[t], o.b, acc[t], 0, 0, 0);
+        o = nx;
+      }
+      if (more) {
+#pragma unroll
+        for (int u = 0; u < SLICE; ++u)
+          if (quarter * SLICE + u < N_ITEMS) store_item(quarter * SLICE + u, nxt, stage[u]);
       }
     }
     __syncthreads();
@@ -210,6 +237,18 @@ bool plain_aligned(const unetpp_view& v) {
          (reinterpret_cast<uintptr_t>(v.ptr) & 15) == 0;
 }
 
+template <int TAPS, int LOG2TW>
+int launch_one(const WFastArgs& a, dim3 grid, hipStream_t st) {
+  constexpr size_t lds =
+      2 * (((TAPS == 9) ? kMaxHaloPixels : kBlockPixels) * 32 + kBlockPixels * 32) * sizeof(float);
+  // > 64 KB of dynamic LDS needs the per-function opt-in; it is idempotent and keeps the ABI stateless
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_fast_kernel<TAPS, LOG2TW>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
+    return UNETPP_ELAUNCH;
+  hipLaunchKernelGGL((wgrad_fast_kernel<TAPS, LOG2TW>), grid, dim3(kWThreads), lds, st, a);
+  return launch_status();
+}
+
 }  // namespace
 
 // returns UNETPP_OK after launching, or 1 when the descriptor needs the generic kernel
@@ -224,26 +263,18 @@ int launch_wgrad_fast(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_til
   a.Ncols = Ncols;
   a.n_tiles_cols = n_tiles_cols;
   const TileGeom g = tile_geom(d->H, d->W);
-  a.log2tw = g.log2tw;
   a.tiles_x = g.tiles_x;
   a.tiles_y = g.tiles_y;
   a.n_pix_tiles = static_cast<long>(d->N) * g.tiles_y * g.tiles_x;
   const dim3 grid(static_cast<unsigned>(d->n_split), static_cast<unsigned>(static_cast<long>(k_tiles) * n_tiles_cols));
-  // > 64 KB of dynamic LDS needs the per-function opt-in; it is idempotent and keeps the ABI stateless
   if (d->taps == 9) {
-    constexpr size_t lds = 2 * (kMaxHaloPixels * 32 + kBlockPixels * 32) * sizeof(float);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_fast_kernel<9>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
-      return UNETPP_ELAUNCH;
-    hipLaunchKernelGGL(wgrad_fast_kernel<9>, grid, dim3(kWThreads), lds, st, a);
-  } else {
-    constexpr size_t lds = 2 * (kBlockPixels * 32 + kBlockPixels * 32) * sizeof(float);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_fast_kernel<1>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
-      return UNETPP_ELAUNCH;
-    hipLaunchKernelGGL(wgrad_fast_kernel<1>, grid, dim3(kWThreads), lds, st, a);
+    if (g.log2tw == 5) return launch_one<9, 5>(a, grid, st);
+    if (g.log2tw == 4) return launch_one<9, 4>(a, grid, st);
+    return launch_one<9, 3>(a, grid, st);
   }
-  return launch_status();
+  if (g.log2tw == 5) return launch_one<1, 5>(a, grid, st);
+  if (g.log2tw == 4) return launch_one<1, 4>(a, grid, st);
+  return launch_one<1, 3>(a, grid, st);
 }
 
 }  // namespace unetpp

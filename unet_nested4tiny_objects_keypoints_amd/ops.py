@@ -187,7 +187,7 @@ def pack_weight(dst: torch.Tensor, src: torch.Tensor, t: int, k: int, n: int, ds
 
 
 def wgrad(n: int, h: int, w: int, taps: int, xs: Sequence[V], dys: Sequence[V], dw: Optional[torch.Tensor],
-          dw_strides, db: Optional[torch.Tensor], n_inner: Optional[int] = None, target_blocks: int = 512) -> None:
+          dw_strides, db: Optional[torch.Tensor], n_inner: Optional[int] = None, target_blocks: int = 256) -> None:
     """dw / db are written (not accumulated).  dw_strides = (d_t, d_k, d_n, d_o) into the torch-layout gradient."""
     lib = _lib.lib()
     d = WgradDesc()
