@@ -38,6 +38,9 @@ def nchw(t):  # NHWC gpu -> NCHW cpu
     (2, 8, 8, [16, 8, 8], 40),    # odd column tile
     (1, 4, 4, [5, 3], 7),         # scalar-load path, tile much larger than the image
     (1, 16, 48, [1], 33),
+    (2, 32, 64, [1], 32),         # first-layer VALU kernel (1 -> 32 channels)
+    (1, 24, 40, [3], 8),          # first-layer VALU kernel, rgb, ragged patches
+    (1, 16, 16, [4], 64),
 ])
 def test_conv3x3_fwd_multiview(dev, shape):
     from unet_nested4tiny_objects_keypoints_amd import engine, ops
@@ -94,7 +97,7 @@ def test_conv3x3_load_transform_and_slices(dev):
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 32, [32], 32), (1, 64, 64, [32, 32, 32, 32], 32), (2, 8, 8, [16, 8, 8], 40),
-                                   (1, 24, 40, [4], 4), (3, 16, 16, [64, 32], 96)])
+                                   (1, 24, 40, [8], 4), (3, 16, 16, [64, 32], 96)])
 def test_fast_and_generic_gemm_agree(dev, shape):
     """The register-prefetched kernel and the generic kernel are the same function of their inputs (bitwise:
     same MFMA order), including the BatchNorm partial sums."""
@@ -163,7 +166,8 @@ def test_deconv2x2_fwd_dgrad_wgrad(dev, shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 16, 16, [8], 8), (1, 32, 32, [32, 32, 32], 32), (2, 24, 40, [3], 4),
-                                   (1, 8, 8, [40, 5], 33), (3, 64, 64, [16], 16)])
+                                   (1, 8, 8, [40, 5], 33), (3, 64, 64, [16], 16), (2, 32, 64, [1], 32),
+                                   (1, 24, 40, [3], 8)])
 def test_conv3x3_wgrad(dev, shape):
     from unet_nested4tiny_objects_keypoints_amd import ops
     from unet_nested4tiny_objects_keypoints_amd.ops import V
@@ -183,6 +187,25 @@ def test_conv3x3_wgrad(dev, shape):
                   dw, (1, 9, ci * 9, 0), db, target_blocks=target_blocks)
         assert rel_err(dw.cpu(), wt.grad.float()) < TOL
         assert rel_err(db.cpu(), bias.grad.float()) < TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 64, 1, 32), (1, 24, 40, 3, 8), (3, 16, 16, 4, 128), (2, 8, 8, 2, 4)])
+def test_first_layer_wgrad(dev, shape):
+    """The 1..4-channel first convolution's dedicated weight-gradient kernel (plain dy, no gate)."""
+    from unet_nested4tiny_objects_keypoints_amd import ops
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    b, h, w, ci, co = shape
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(b, ci, h, w, generator=g, dtype=torch.float64)
+    wt = torch.randn(co, ci, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(co, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(b, co, h, w, generator=g, dtype=torch.float64)
+    F.conv2d(x, wt, bias, padding=1).backward(dy)
+    dw = torch.empty(co, ci, 3, 3, device=dev)
+    db = torch.empty(co, device=dev)
+    ops.wgrad(b, h, w, 9, [V(nhwc(x.float()))], [V(nhwc(dy.float()))], dw, (1, 9, ci * 9, 0), db)
+    assert rel_err(dw.cpu(), wt.grad.float()) < TOL
+    assert rel_err(db.cpu(), bias.grad.float()) < TOL
 
 
 @pytest.mark.parametrize("c", [32, 8, 3])

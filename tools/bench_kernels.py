@@ -72,3 +72,26 @@ for name, hw, cins, co in CONVS:
 for k in tot_ms:
     if tot_ms[k] > 0:
         print("TOTAL %-6s %8.3f ms  %7.1f TF/s" % (k, tot_ms[k], tot_fl[k] / tot_ms[k] / 1e9))
+
+# ---- 2x2 stride-2 transposed convolutions (pointwise GEMM + pixel phases) ----
+print("%-14s %5s %5s %5s | %9s %7s %7s | %9s %7s | %9s %7s" % ("deconv", "hw_lo", "cin", "cout", "fwd ms", "TF/s", "GB/s",
+                                                               "dgrad ms", "TF/s", "wgrad ms", "TF/s"))
+for i in range(3):
+    if only and "deconv" not in only:
+        break
+    hw = 128 >> i
+    ci, co = f[i + 1], f[i]
+    x = rnd(B, hw, hw, ci)
+    up = rnd(B, 2 * hw, 2 * hw, co)
+    w = rnd(ci, co, 2, 2) * 0.05
+    bias = rnd(co)
+    wf, wd, b4 = engine.pack_deconv_fwd(w), engine.pack_deconv_dgrad(w), engine.tile_bias4(bias)
+    flops = 2.0 * B * hw * hw * ci * 4 * co
+    byts = 4.0 * B * hw * hw * (ci + 4 * co)
+    t_f = timeit(lambda: ops.gemm_fwd(B, hw, hw, 1, [V(x)], engine._phase_views(up), wf, b4))
+    dx = torch.empty_like(x)
+    t_d = timeit(lambda: ops.gemm_fwd(B, hw, hw, 1, engine._phase_views(up), [V(dx)], wd))
+    dw, db = torch.empty_like(w), torch.empty_like(bias)
+    t_w = timeit(lambda: ops.wgrad(B, hw, hw, 1, [V(x)], engine._phase_views(up), dw, (0, 4 * co, 4, 1), db, n_inner=co))
+    print("%-14s %5d %5d %5d | %9.3f %7.1f %7.0f | %9.3f %7.1f | %9.3f %7.1f" % (
+        "deconv%d" % i, hw, ci, co, t_f, flops / t_f / 1e9, byts / t_f / 1e6, t_d, flops / t_d / 1e9, t_w, flops / t_w / 1e9))

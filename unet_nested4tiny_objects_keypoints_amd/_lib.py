@@ -15,7 +15,7 @@ _REPO = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.environ.get("UNETPP_LIB", os.path.join(_PKG_DIR, "libunetpp_hip.so"))  # override: kernel A/B runs
 CSRC = os.path.join(_PKG_DIR, "csrc")
 INCLUDE = os.path.join(_REPO, "include")
-SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "wgrad.hip", "wgrad_fast.hip", "pointwise.hip")
+SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "wgrad.hip", "wgrad_fast.hip", "first_layer.hip", "pointwise.hip")
 MAX_VIEWS = 8
 
 

@@ -1,0 +1,253 @@
+// The network's first convolution (models/unet.py:220, conv00.conv1): 1..4 input channels -> f0 output channels.
+// K = 9*Cin <= 36 is far too short for the MFMA tile (the generic kernel pads it to 72 and spends 8x the work), and
+// the layer is HBM-bound anyway: forward writes 32 channels per pixel from 1-3 read, the weight gradient reads them.
+// Plain VALU kernels, one 256-pixel patch at a time (the same patch geometry as the MFMA kernels, so the BatchNorm
+// partial rows line up):
+//   forward : input patch + halo and the 9*Cin*Cout weights in LDS; thread = (pixel, 4 output channels), so a wave
+//             stores whole 128-byte pixel rows; fused bias, ReLU, BatchNorm partial sums
+//   wgrad   : thread = (pixel stripe, 4 output channels) keeps 9*Cin float4 accumulators in registers over a
+//             grid-stride loop of patches; fixed-order LDS reduction; one slab per workgroup (wgrad_finish sums them)
+#include "common.h"
+
+namespace unetpp {
+namespace {
+
+constexpr int kMaxCout = 128;
+
+struct SmallArgs {
+  const float* x;      // [N, H, W, CIN]
+  const float* w;      // packed [9][CIN][COUT]
+  const float* bias;   // [COUT] or null
+  float* y;            // forward: out tensor base (+ c_off), pixel stride yC
+  const float* dy;     // wgrad: dy tensor base (+ c_off), pixel stride yC
+  float* stats;        // forward: [patches][COUT][2] or null
+  float* slabs;        // wgrad: [n_split][9*CIN + 1][COUT]
+  int N, H, W, COUT, yC, relu;
+  int log2tw, tiles_x, tiles_y;
+  long n_patches;
+};
+
+template <int CIN>
+__device__ __forceinline__ void stage_patch(const SmallArgs& a, float* xs, int n, int ty0, int tx0, int TW, int TH) {
+  const int HWp = TW + 2, npix = HWp * (TH + 2);
+  for (int it = threadIdx.x; it < npix * CIN; it += kThreads) {
+    const int hp = it / CIN, ci = it - hp * CIN;
+    const int hy = hp / HWp, hx = hp - hy * HWp;
+    const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+    float v = 0.f;
+    if (y >= 0 && y < a.H && x >= 0 && x < a.W) v = a.x[((static_cast<long>(n) * a.H + y) * a.W + x) * CIN + ci];
+    xs[it] = v;
+  }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(kThreads) void small_cin_fwd_kernel(const SmallArgs a) {
+  __shared__ float xs[kMaxHaloPixels * CIN];
+  __shared__ __attribute__((aligned(16))) float ws[9 * CIN * kMaxCout];
+  __shared__ float red[kThreads][8];
+  const int tid = threadIdx.x;
+  const int TW = 1 << a.log2tw, TH = kBlockPixels >> a.log2tw, HWp = TW + 2;
+  long b = blockIdx.x;
+  const int txi = static_cast<int>(b % a.tiles_x);
+  b /= a.tiles_x;
+  const int tyi = static_cast<int>(b % a.tiles_y);
+  const int n = static_cast<int>(b / a.tiles_y);
+  const int ty0 = tyi * TH, tx0 = txi * TW;
+  stage_patch<CIN>(a, xs, n, ty0, tx0, TW, TH);
+  for (int i = tid; i < 9 * CIN * a.COUT; i += kThreads) ws[i] = a.w[i];
+  __syncthreads();
+
+  const int QN = a.COUT >> 2;             // 4-channel groups; the launcher guarantees 256 % QN == 0
+  const int quad = tid % QN, psub = tid / QN, pstep = kThreads / QN;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias != nullptr) bias4 = *reinterpret_cast<const f32x4*>(a.bias + 4 * quad);
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  for (int p = psub; p < kBlockPixels; p += pstep) {
+    const int py = p >> a.log2tw, px = p & (TW - 1);
+    const int y = ty0 + py, x = tx0 + px;
+    if (y < a.H && x < a.W) {
+      f32x4 acc = bias4;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const float* xp = &xs[((py + tap / 3) * HWp + px + tap % 3) * CIN];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+          const float xv = xp[ci];
+          const f32x4 w4 = *reinterpret_cast<const f32x4*>(&ws[(tap * CIN + ci) * a.COUT + 4 * quad]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv, w4[e], acc[e]);
+        }
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s1[e] += acc[e];
+        s2[e] += acc[e] * acc[e];
+      }
+      *reinterpret_cast<f32x4*>(a.y + ((static_cast<long>(n) * a.H + y) * a.W + x) * a.yC + 4 * quad) = acc;
+    }
+  }
+  if (a.stats != nullptr) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[tid][e] = s1[e];
+      red[tid][4 + e] = s2[e];
+    }
+    __syncthreads();
+    for (int c = tid; c < a.COUT; c += kThreads) {
+      const int q = c >> 2, e = c & 3;
+      float t1 = 0.f, t2 = 0.f;
+      for (int t = q; t < kThreads; t += QN) {  // fixed order
+        t1 += red[t][e];
+        t2 += red[t][4 + e];
+      }
+      float* dst = a.stats + (static_cast<long>(blockIdx.x) * a.COUT + c) * 2;
+      dst[0] = t1;
+      dst[1] = t2;
+    }
+  }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(kThreads) void small_cin_wgrad_kernel(const SmallArgs a) {
+  __shared__ float xs[kMaxHaloPixels * CIN];
+  __shared__ float red[kThreads][4];
+  const int tid = threadIdx.x;
+  const int TW = 1 << a.log2tw, TH = kBlockPixels >> a.log2tw, HWp = TW + 2;
+  const int QN = a.COUT >> 2;
+  const int quad = tid % QN, psub = tid / QN, pstep = kThreads / QN;
+  f32x4 acc[9 * CIN];
+#pragma unroll
+  for (int i = 0; i < 9 * CIN; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 db = {0.f, 0.f, 0.f, 0.f};
+  for (long patch = blockIdx.x; patch < a.n_patches; patch += gridDim.x) {
+    long b = patch;
+    const int txi = static_cast<int>(b % a.tiles_x);
+    b /= a.tiles_x;
+    const int tyi = static_cast<int>(b % a.tiles_y);
+    const int n = static_cast<int>(b / a.tiles_y);
+    const int ty0 = tyi * TH, tx0 = txi * TW;
+    __syncthreads();
+    stage_patch<CIN>(a, xs, n, ty0, tx0, TW, TH);
+    __syncthreads();
+    for (int p = psub; p < kBlockPixels; p += pstep) {
+      const int py = p >> a.log2tw, px = p & (TW - 1);
+      const int y = ty0 + py, x = tx0 + px;
+      if (y < a.H && x < a.W) {
+        const f32x4 g =
+            *reinterpret_cast<const f32x4*>(a.dy + ((static_cast<long>(n) * a.H + y) * a.W + x) * a.yC + 4 * quad);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) db[e] += g[e];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const float* xp = &xs[((py + tap / 3) * HWp + px + tap % 3) * CIN];
+#pragma unroll
+          for (int ci = 0; ci < CIN; ++ci) {
+            const float xv = xp[ci];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[tap * CIN + ci][e] = fmaf(xv, g[e], acc[tap * CIN + ci][e]);
+          }
+        }
+      }
+    }
+  }
+  // fixed-order reduction over the threads that share an output-channel group, one slab row at a time
+  float* slab = a.slabs + static_cast<long>(blockIdx.x) * (9 * CIN + 1) * a.COUT;
+#pragma unroll
+  for (int row = 0; row <= 9 * CIN; ++row) {
+    const f32x4 v = (row < 9 * CIN) ? acc[row < 9 * CIN ? row : 0] : db;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[tid][e] = v[e];
+    __syncthreads();
+    for (int c = tid; c < a.COUT; c += kThreads) {
+      const int q = c >> 2, e = c & 3;
+      float t = 0.f;
+      for (int k = q; k < kThreads; k += QN) t += red[k][e];
+      slab[row * a.COUT + c] = t;
+    }
+  }
+}
+
+bool plain_view(const unetpp_view& v) {
+  return v.scale == nullptr && v.gate == nullptr && !v.relu && v.sy == 1 && v.sx == 1 && v.oy == 0 && v.ox == 0;
+}
+
+bool small_shape_ok(const unetpp_view& x, const unetpp_view& y, int H, int W) {
+  if (!plain_view(x) || x.C > 4 || x.c_off != 0 || x.c_len != x.C || x.Hs != H || x.Ws != W) return false;
+  if (y.sy != 1 || y.sx != 1 || y.oy != 0 || y.ox != 0 || y.Hs != H || y.Ws != W) return false;
+  const int co = y.c_len;
+  if ((co & 3) || co > kMaxCout || (kThreads % (co >> 2)) != 0) return false;
+  if (((y.C | y.c_off) & 3) || (reinterpret_cast<uintptr_t>(y.ptr) & 15)) return false;
+  return true;
+}
+
+void fill_geom(SmallArgs& a, int N, int H, int W) {
+  const TileGeom g = tile_geom(H, W);
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  a.log2tw = g.log2tw;
+  a.tiles_x = g.tiles_x;
+  a.tiles_y = g.tiles_y;
+  a.n_patches = static_cast<long>(N) * g.tiles_y * g.tiles_x;
+}
+
+}  // namespace
+
+// 3x3 forward for <= 4 input channels.  Returns 1 when the descriptor does not fit this path.
+int launch_small_cin_fwd(const unetpp_gemm_desc* d, hipStream_t st) {
+  if (d->taps != 9 || d->n_in != 1 || d->n_out != 1) return 1;
+  const unetpp_view& X = d->in[0];
+  const unetpp_view& Y = d->out[0];
+  if (!small_shape_ok(X, Y, d->H, d->W) || Y.gate != nullptr || Y.accumulate) return 1;
+  if (d->bias != nullptr && (reinterpret_cast<uintptr_t>(d->bias) & 15)) return 1;
+  SmallArgs a = {};
+  fill_geom(a, d->N, d->H, d->W);
+  if (a.n_patches > 0x7fffffffL) return 1;
+  a.x = X.ptr;
+  a.w = d->weight;
+  a.bias = d->bias;
+  a.y = Y.ptr + Y.c_off;
+  a.stats = d->stats_partial;
+  a.COUT = Y.c_len;
+  a.yC = Y.C;
+  a.relu = Y.relu;
+  const dim3 grid(static_cast<unsigned>(a.n_patches)), block(kThreads);
+  switch (X.C) {
+    case 1: hipLaunchKernelGGL(small_cin_fwd_kernel<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(small_cin_fwd_kernel<2>, grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL(small_cin_fwd_kernel<3>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(small_cin_fwd_kernel<4>, grid, block, 0, st, a); break;
+  }
+  return launch_status();
+}
+
+// weight gradient of the same layer.  Returns 1 when the descriptor does not fit this path.
+int launch_small_cin_wgrad(const unetpp_wgrad_desc* d, hipStream_t st) {
+  if (d->taps != 9 || d->n_x != 1 || d->n_dy != 1) return 1;
+  const unetpp_view& X = d->x[0];
+  const unetpp_view& DY = d->dy[0];
+  if (!small_shape_ok(X, DY, d->H, d->W) || DY.gate != nullptr || DY.scale != nullptr || DY.relu) return 1;
+  SmallArgs a = {};
+  fill_geom(a, d->N, d->H, d->W);
+  if (d->n_split < 1 || d->n_split > a.n_patches) return 1;
+  a.x = X.ptr;
+  a.dy = DY.ptr + DY.c_off;
+  a.slabs = d->slabs;
+  a.COUT = DY.c_len;
+  a.yC = DY.C;
+  const dim3 grid(static_cast<unsigned>(d->n_split)), block(kThreads);
+  switch (X.C) {
+    case 1: hipLaunchKernelGGL(small_cin_wgrad_kernel<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(small_cin_wgrad_kernel<2>, grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL(small_cin_wgrad_kernel<3>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(small_cin_wgrad_kernel<4>, grid, block, 0, st, a); break;
+  }
+  return launch_status();
+}
+
+}  // namespace unetpp

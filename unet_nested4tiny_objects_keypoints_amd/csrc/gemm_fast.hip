@@ -26,6 +26,7 @@ struct FastArgs {
   unetpp_gemm_desc d;
   int log2tw, tiles_x, tiles_y;
   int Ktot, Ncols, n_tiles, n_chunks;
+  int nt_unit, n_groups;  // column tiles per unit of work, units per pixel patch (n_tiles / nt_unit)
   long total_blocks;
 };
 
@@ -81,26 +82,17 @@ __global__ void pack_image_kernel(const FastArgs a, float* __restrict__ img) {
 // unit's MFMAs.  (With one unit per workgroup the co-resident workgroups run in lockstep -- all load, all compute,
 // all store -- and a short-K unit spends 40 % of its time outside the MFMA loop.)
 struct UnitGeom {
-  int n, ty0, tx0;        // image, patch origin
-  int nt_global, nt, ov;  // column tile (global index; index inside its out view; the out view)
-  int n0, n_cnt;          // first GEMM column, valid columns
-  long patch;             // pixel-patch index (BatchNorm partial row)
+  int n, ty0, tx0;  // image, patch origin
+  int group;        // first column tile = group * nt_unit
+  long patch;       // pixel-patch index (BatchNorm partial row)
+};
+struct TileCols {
+  int nt, ov;     // tile index inside its out view; the out view
+  int n0, n_cnt;  // first GEMM column, valid columns
 };
 
-template <int LOG2TW>
-__device__ __forceinline__ UnitGeom decode_unit(const FastArgs& a, long lb) {
-  constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;
-  UnitGeom g;
-  g.nt_global = static_cast<int>(lb % a.n_tiles);
-  long bid = lb / a.n_tiles;
-  g.patch = bid;
-  const int txi = static_cast<int>(bid % a.tiles_x);
-  bid /= a.tiles_x;
-  const int tyi = static_cast<int>(bid % a.tiles_y);
-  g.n = static_cast<int>(bid / a.tiles_y);
-  g.ty0 = tyi * TH;
-  g.tx0 = txi * TW;
-  int nt = g.nt_global, ov = 0, col_base = 0;
+__device__ __forceinline__ TileCols decode_tile(const FastArgs& a, int nt_global) {
+  int nt = nt_global, ov = 0, col_base = 0;
   while (ov < a.d.n_out - 1) {
     const int tiles_v = (a.d.out[ov].c_len + 31) >> 5;
     if (nt < tiles_v) break;
@@ -108,15 +100,34 @@ __device__ __forceinline__ UnitGeom decode_unit(const FastArgs& a, long lb) {
     col_base += a.d.out[ov].c_len;
     ++ov;
   }
-  g.nt = nt;
-  g.ov = ov;
-  g.n0 = col_base + nt * 32;
-  g.n_cnt = min(32, a.d.out[ov].c_len - nt * 32);
+  TileCols t;
+  t.nt = nt;
+  t.ov = ov;
+  t.n0 = col_base + nt * 32;
+  t.n_cnt = min(32, a.d.out[ov].c_len - nt * 32);
+  return t;
+}
+
+template <int LOG2TW>
+__device__ __forceinline__ UnitGeom decode_unit(const FastArgs& a, long lb) {
+  constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;
+  UnitGeom g;
+  g.group = static_cast<int>(lb % a.n_groups);
+  long bid = lb / a.n_groups;
+  g.patch = bid;
+  const int txi = static_cast<int>(bid % a.tiles_x);
+  bid /= a.tiles_x;
+  const int tyi = static_cast<int>(bid % a.tiles_y);
+  g.n = static_cast<int>(bid / a.tiles_y);
+  g.ty0 = tyi * TH;
+  g.tx0 = txi * TW;
   return g;
 }
 
-template <int TAPS, int LOG2TW>
-__global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a) {
+// NT = column tiles per unit.  3x3 convolutions use NT = 1 (3 workgroups per CU); the pointwise GEMMs of the 2x2
+// deconvolution (K = Cin only, N = 4*Cout) use NT = 2/4 so that one staged input patch feeds 64/128 columns.
+template <int TAPS, int LOG2TW, int NT>
+__global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : (NT == 2 ? 3 : 2)) : 3)) void gemm_fast_kernel(const FastArgs a) {
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
   constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;   // compile-time patch shape: every
   constexpr int HWp = TW + 2 * HALO, HHp = TH + 2 * HALO;        // division below is by a constant
@@ -126,8 +137,8 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
   constexpr int IN_FLOATS = MAXPIX * KCP;
   constexpr int IMG = TAPS * 512;
   constexpr int IN_ITEMS = (NPIX * 4 + kThreads - 1) / kThreads;
-  constexpr int W_ITEMS = (IMG / 4 + kThreads - 1) / kThreads;
-  __shared__ __attribute__((aligned(16))) float smem[IN_FLOATS + IMG];
+  constexpr int W_ITEMS = (NT * IMG / 4 + kThreads - 1) / kThreads;
+  __shared__ __attribute__((aligned(16))) float smem[IN_FLOATS + NT * IMG];
   float* in_tile = smem;
   float* w_tile = smem + IN_FLOATS;
 
@@ -163,11 +174,13 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
   }
   const int wb = j * 8 + ((h ^ ((j >> 3) & 1)) << 2);
 
-  f32x16 acc[2];
+  f32x16 acc[NT][2];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][mt][r] = 0.f;
 
   // ---- prefetch side: the chunk that is loaded next.  Per-thread state: one 32-bit element offset per staging
   // item and one in-image bit per item; everything else is recomputed from tid where needed. ----
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
     p_n = g.n;
     p_ty0 = g.ty0;
     p_tx0 = g.tx0;
-    p_wimg = d.weight_image + static_cast<long>(g.nt_global) * a.n_chunks * IMG;
+    p_wimg = d.weight_image + static_cast<long>(g.group) * NT * a.n_chunks * IMG;
     in_mask = 0;
 #pragma unroll
     for (int q = 0; q < IN_ITEMS; ++q) {
@@ -220,8 +233,9 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
     const float* wp = p_wimg + static_cast<long>(p_chunk) * IMG;
 #pragma unroll
     for (int q = 0; q < W_ITEMS; ++q) {
-      const unsigned it = min(tid + q * kThreads, IMG / 4 - 1);
-      reg_w[q] = *reinterpret_cast<const f32x4*>(wp + it * 4u);
+      const unsigned it = min(tid + q * kThreads, NT * IMG / 4 - 1);
+      const unsigned t = it / (IMG / 4), r = it - t * (IMG / 4);  // image of column tile t, float4 r
+      reg_w[q] = *reinterpret_cast<const f32x4*>(wp + static_cast<long>(t) * a.n_chunks * IMG + r * 4u);
     }
   };
   auto store_chunk = [&]() {
@@ -238,18 +252,19 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
 #pragma unroll
     for (int q = 0; q < W_ITEMS; ++q) {
       const int it = tid + q * kThreads;
-      if (it < IMG / 4) *reinterpret_cast<f32x4*>(&w_tile[it * 4]) = reg_w[q];
+      if (it < NT * IMG / 4) *reinterpret_cast<f32x4*>(&w_tile[it * 4]) = reg_w[q];
     }
   };
   // one (tap, 8-channel group) step of LDS fragments: B for the 32 columns, A for both pixel tiles
   struct Frag {
-    f32x4 b, a0, a1;
+    f32x4 b[NT], a0, a1;
   };
   auto read_frag = [&](int step) {
     const int tap = step >> 1, g = step & 1;
     const int tpix = (TAPS == 9) ? (tap / 3) * HWp + (tap % 3) : 0;
     Frag f;
-    f.b = *reinterpret_cast<const f32x4*>(&w_tile[step * 256 + wb]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) f.b[t] = *reinterpret_cast<const f32x4*>(&w_tile[t * IMG + step * 256 + wb]);
     f.a0 = *reinterpret_cast<const f32x4*>(&in_tile[(apix[0] + tpix) * KCP + ((2 * g + h) << 2)]);
     f.a1 = *reinterpret_cast<const f32x4*>(&in_tile[(apix[1] + tpix) * KCP + ((2 * g + h) << 2)]);
     return f;
@@ -260,12 +275,15 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
   // lane_base + (c >> LOG2TW)*row_stride + (c & (TW-1))*col_stride.
   auto epilogue = [&](long k) {
     const UnitGeom g = decode_unit<LOG2TW>(a, first_unit + k * unit_step);
-    const unetpp_view& O = d.out[g.ov];
-    const bool col_ok = j < g.n_cnt;
-    const float bj = (d.bias != nullptr && col_ok) ? d.bias[g.n0 + j] : 0.f;
-    const long row_stride = static_cast<long>(O.sy) * O.Ws * O.C, col_stride = static_cast<long>(O.sx) * O.C;
-    const long tile_base = view_pixel_offset(O, g.n, g.ty0, g.tx0) + g.nt * 32 + j;
     const bool interior = (g.ty0 + TH <= d.H) && (g.tx0 + TW <= d.W);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+    const TileCols tc = decode_tile(a, g.group * NT + t);
+    const unetpp_view& O = d.out[tc.ov];
+    const bool col_ok = j < tc.n_cnt;
+    const float bj = (d.bias != nullptr && col_ok) ? d.bias[tc.n0 + j] : 0.f;
+    const long row_stride = static_cast<long>(O.sy) * O.Ws * O.C, col_stride = static_cast<long>(O.sx) * O.C;
+    const long tile_base = view_pixel_offset(O, g.n, g.ty0, g.tx0) + tc.nt * 32 + j;
     float s1 = 0.f, s2sum = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -277,7 +295,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
         const int dy = c >> LOG2TW, dx = c & (TW - 1);
         const bool ok = col_ok && (interior || ((g.ty0 + prow + dy < d.H) && (g.tx0 + 4 * h + dx < d.W)));
         if (ok) {
-          float v = acc[mt][r] + bj;
+          float v = acc[t][mt][r] + bj;
           if (O.relu) v = fmaxf(v, 0.f);
           s1 += v;
           s2sum += v * v;
@@ -287,7 +305,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
           if (O.gate != nullptr && O.gate_sum) v = (O.gate[off] > 0.f) ? v : 0.f;
           O.ptr[off] = v;
         }
-        acc[mt][r] = 0.f;
+        acc[t][mt][r] = 0.f;
       }
     }
     if (d.stats_partial != nullptr) {  // the LDS tiles are free here (barrier after the MFMA loop)
@@ -298,19 +316,20 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
         smem[(wave * 32 + j) * 2 + 1] = s2sum;
       }
       __syncthreads();
-      if (tid < g.n_cnt) {
+      if (tid < tc.n_cnt) {
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           t1 += smem[(w * 32 + tid) * 2 + 0];
           t2 += smem[(w * 32 + tid) * 2 + 1];
         }
-        float* dst = d.stats_partial + (g.patch * a.Ncols + g.n0 + tid) * 2;
+        float* dst = d.stats_partial + (g.patch * a.Ncols + tc.n0 + tid) * 2;
         dst[0] = t1;
         dst[1] = t2;
       }
       __syncthreads();  // before the next chunk overwrites the scratch
     }
+    }  // column tiles of the unit
   };
 
   prefetch_unit(0);
@@ -357,9 +376,14 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_fast_kernel(const FastArgs a
       Frag nxt = cur;
       if (step + 1 < TAPS * 2) nxt = read_frag(step + 1);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a0[t], cur.b[t], acc[0], 0, 0, 0);
+      for (int ct = 0; ct < NT; ++ct) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a1[t], cur.b[t], acc[1], 0, 0, 0);
+        for (int t = 0; t < 4; ++t)
+          acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a0[t], cur.b[ct][t], acc[ct][0], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[ct][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a1[t], cur.b[ct][t], acc[ct][1], 0, 0, 0);
+      }
       cur = nxt;
     }
     __syncthreads();
@@ -400,7 +424,12 @@ bool fast_args(const unetpp_gemm_desc* d, FastArgs& a) {
   a.log2tw = g.log2tw;
   a.tiles_x = g.tiles_x;
   a.tiles_y = g.tiles_y;
-  a.total_blocks = static_cast<long>(d->N) * g.tiles_y * g.tiles_x * a.n_tiles;
+  // column tiles per unit: pointwise GEMMs (deconvolution phases) without a statistics epilogue take 4 or 2
+  a.nt_unit = 1;
+  if (d->taps == 1 && d->stats_partial == nullptr) a.nt_unit = (a.n_tiles % 4 == 0) ? 4 : ((a.n_tiles % 2 == 0) ? 2 : 1);
+  if (a.nt_unit > 2) a.nt_unit = 2;  // measured: 2 tiles x 3 workgroups per CU beats 4 tiles x 2 on the deconvolutions
+  a.n_groups = a.n_tiles / a.nt_unit;
+  a.total_blocks = static_cast<long>(d->N) * g.tiles_y * g.tiles_x * a.n_groups;
   return a.total_blocks <= 0x7fffffffL;
 }
 
@@ -415,18 +444,21 @@ int launch_gemm_fast(const unetpp_gemm_desc* d, hipStream_t st) {
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     return UNETPP_ELAUNCH;
-  long workers = (3L * cus) & ~7L;
+  const long per_cu = (d->taps == 1) ? (a.nt_unit == 1 ? 4 : (a.nt_unit == 2 ? 3 : 2)) : 3;  // = the kernel's launch bounds
+  long workers = (per_cu * cus) & ~7L;
   if (workers < 8) workers = 8;
   const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(kThreads);
-  if (d->taps == 9) {
-    if (a.log2tw == 5) hipLaunchKernelGGL((gemm_fast_kernel<9, 5>), grid, block, 0, st, a);
-    else if (a.log2tw == 4) hipLaunchKernelGGL((gemm_fast_kernel<9, 4>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((gemm_fast_kernel<9, 3>), grid, block, 0, st, a);
-  } else {
-    if (a.log2tw == 5) hipLaunchKernelGGL((gemm_fast_kernel<1, 5>), grid, block, 0, st, a);
-    else if (a.log2tw == 4) hipLaunchKernelGGL((gemm_fast_kernel<1, 4>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((gemm_fast_kernel<1, 3>), grid, block, 0, st, a);
-  }
+#define UNETPP_LAUNCH_FAST(T, NTU)                                                                      \
+  do {                                                                                                  \
+    if (a.log2tw == 5) hipLaunchKernelGGL((gemm_fast_kernel<T, 5, NTU>), grid, block, 0, st, a);        \
+    else if (a.log2tw == 4) hipLaunchKernelGGL((gemm_fast_kernel<T, 4, NTU>), grid, block, 0, st, a);   \
+    else hipLaunchKernelGGL((gemm_fast_kernel<T, 3, NTU>), grid, block, 0, st, a);                      \
+  } while (0)
+  if (d->taps == 9) UNETPP_LAUNCH_FAST(9, 1);
+  else if (a.nt_unit == 4) UNETPP_LAUNCH_FAST(1, 4);
+  else if (a.nt_unit == 2) UNETPP_LAUNCH_FAST(1, 2);
+  else UNETPP_LAUNCH_FAST(1, 1);
+#undef UNETPP_LAUNCH_FAST
   return launch_status();
 }
 

@@ -218,6 +218,10 @@ extern "C" int unetpp_gemm_fwd(const unetpp_gemm_desc* d, void* stream) {
   a.tiles_y = g.tiles_y;
   const int64_t pix_blocks = static_cast<int64_t>(d->N) * g.tiles_y * g.tiles_x;
   if (pix_blocks > 0x7fffffffLL || n_tiles > 65535) return UNETPP_EINVAL;
+  {
+    const int small = launch_small_cin_fwd(d, static_cast<hipStream_t>(stream));  // 1..4-channel first layer
+    if (small != 1) return small;
+  }
   const dim3 grid(static_cast<unsigned>(pix_blocks), static_cast<unsigned>(n_tiles));
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (d->taps == 9)

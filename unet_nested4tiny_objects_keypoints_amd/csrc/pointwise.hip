@@ -897,7 +897,7 @@ extern "C" int unetpp_head_fwd(const float* x, const float* weight, const float*
 extern "C" int64_t unetpp_head_bwd_blocks(int64_t pixels) {
   if (pixels < 1) return 0;
   const long tiles = (pixels + 63) / 64;
-  return tiles < 1024 ? tiles : 1024;
+  return tiles < 4096 ? tiles : 4096;  // 16 workgroups per CU: the tile loop is a chain of dependent loads, occupancy hides it
 }
 
 extern "C" int unetpp_head_bwd(const float* d_out_nchw, const float* out_nchw, const float* x, const float* weight,

@@ -259,6 +259,8 @@ extern "C" int unetpp_wgrad(const unetpp_wgrad_desc* d, void* stream) {
   if (pairs > 65535) return UNETPP_EINVAL;
   const dim3 grid(static_cast<unsigned>(d->n_split), static_cast<unsigned>(pairs));
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const int small = launch_small_cin_wgrad(d, st);  // 1..4-channel first layer
+  if (small != 1) return small;
   const int fast = launch_wgrad_fast(d, a.Ktot, a.Ncols, a.n_tiles_cols, k_tiles, st);
   if (fast != 1) return fast;  // launched (or failed to); 1 = views need the generic kernel
   if (d->taps == 9)

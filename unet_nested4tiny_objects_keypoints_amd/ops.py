@@ -196,6 +196,8 @@ def wgrad(n: int, h: int, w: int, taps: int, xs: Sequence[V], dys: Sequence[V], 
     k = sum(v.fill(d.x[i]) for i, v in enumerate(xs))
     nc = sum(v.fill(d.dy[i]) for i, v in enumerate(dys))
     pairs = sum((v.c_len + 31) // 32 for v in d.x[:len(xs)]) * sum((v.c_len + 31) // 32 for v in d.dy[:len(dys)])
+    if len(xs) == 1 and xs[0].t.shape[3] <= 4:
+        target_blocks = 2048  # the 1..4-channel first layer runs an HBM-bound VALU kernel: many small workgroups
     split = max(1, min(int(lib.unetpp_wgrad_max_split(n, h, w)), target_blocks // max(1, pairs)))
     slabs = torch.empty(split * (taps * k + 1) * nc, dtype=torch.float32, device=xs[0].t.device)
     d.n_split = split
