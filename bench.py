@@ -137,10 +137,18 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal knobs for a 1-GPU box (never set by the driver): every rank on cuda:0 and gloo instead of RCCL,
+    # which exercises the whole multi-process path (broadcast, bucketed all-reduce on the side stream, barriers).
+    one_dev = os.environ.get("UNETPP_BENCH_SINGLE_DEVICE") == "1"
+    backend = os.environ.get("UNETPP_BENCH_BACKEND", "nccl")
+    dev_index = 0 if one_dev else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if distributed:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as entry
     if rank == 0:

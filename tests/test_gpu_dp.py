@@ -1,0 +1,93 @@
+"""Data-parallel training step on the GPU: two ranks (both on cuda:0 of the 1-GPU test box, gloo transport -- the
+driver's multi-GPU runs use RCCL) run the HIP model with the bucketed gradient averager hooked into backward.
+After one step both ranks must hold the SAME parameters, equal to a single-process step on the averaged
+gradient of the two shards (computed with the CPU oracle)."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CTOR = dict(in_channels=1, n_classes=4, feature_scale=8)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, state, out_dir):
+    import torch.distributed as dist
+
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, UNet_Nested, dp, train_step
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        torch.manual_seed(50 + rank)              # ranks start from different weights: the broadcast must fix it
+        m = UNet_Nested(**CTOR)
+        if rank == 0:
+            m.load_state_dict(state)
+        m = m.to(dev).train()
+        m.drop_out.eval()
+        avg = dp.make_data_parallel(m, bucket_bytes=16 << 10)
+        g = torch.Generator().manual_seed(200 + rank)
+        x = torch.randn(2, 1, 32, 32, generator=g).to(dev)
+        t = torch.rand(2, 4, 32, 32, generator=g).to(dev)
+        opt = torch.optim.SGD(m.parameters(), lr=0.05)
+        train_step(m, opt, FocalLoss_BCE_2d(gamma=3, size_average=False), x, t)
+        torch.cuda.synchronize()
+        torch.save({"params": {k: p.detach().cpu() for k, p in m.named_parameters()},
+                    "buckets": len(avg.buckets_last_step)}, os.path.join(out_dir, "r%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_step_matches_averaged_oracle(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+
+    from oracle.step_oracle import focal_bce_2d_oracle
+    from oracle.unet_nested_oracle import UNetNestedOracle
+    from tests.helpers import is_pre_bn_bias
+    torch.manual_seed(7)
+    ref = UNetNestedOracle(**CTOR)
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    mp.spawn(_worker, args=(2, _free_port(), state, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "r0.pt")
+    r1 = torch.load(tmp_path / "r1.pt")
+    assert r0["buckets"] >= 2
+    for k in r0["params"]:
+        assert torch.equal(r0["params"][k], r1["params"][k]), k   # replicas stay bit-identical
+    # expected: SGD step on the mean of the two shards' gradients (BatchNorm statistics per shard, as under
+    # the reference's nn.DataParallel)
+    grads = []
+    for rank in range(2):
+        m = UNetNestedOracle(**CTOR)
+        m.load_state_dict(state)
+        m.train()
+        m.drop_out.eval()
+        g = torch.Generator().manual_seed(200 + rank)
+        x = torch.randn(2, 1, 32, 32, generator=g)
+        t = torch.rand(2, 4, 32, 32, generator=g)
+        outs = m(x)
+        (sum(focal_bce_2d_oracle(o, t) for o in outs) / len(outs)).backward()
+        grads.append({k: p.grad for k, p in m.named_parameters()})
+    for k, p0 in state.items():
+        if k not in grads[0]:
+            continue
+        want = p0 - 0.05 * (grads[0][k] + grads[1][k]) / 2
+        got = r0["params"][k]
+        if is_pre_bn_bias(k, CTOR):
+            continue
+        scale = float((0.05 * (grads[0][k] + grads[1][k]) / 2).abs().max()) + 1e-12
+        # ReLU gate flips (tests/helpers.py) can move an update by a few percent of its size; wiring errors
+        # (missing all-reduce, wrong averaging) would be O(1)
+        assert float((got - want).abs().max()) < 0.1 * scale + 1e-7, k

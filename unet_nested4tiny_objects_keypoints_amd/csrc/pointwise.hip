@@ -500,7 +500,9 @@ __global__ __launch_bounds__(kThreads) void head_bwd_kernel(const float* __restr
 //      the weight gradient, and dx = keep*scale * (W^T dlogit) (+ old dx, ReLU gate) written straight back
 //   3. dW[k, c] += sum_p dlogit[p, k] * xs[p, c]: all 256 threads, two pixel halves per (k, c)
 // Dynamic LDS: xs [64][C+1] | dlogit [64][8] | W [8][C] | scratch [2][n_cls*C].
-__global__ __launch_bounds__(kThreads) void head_bwd_vec_kernel(const float* __restrict__ d_out,
+// (launch bound of 4 waves per SIMD: left alone hipcc unrolls the reduction loops into 256 VGPRs and the kernel
+// runs at 2 workgroups per CU, latency-bound at 1 TB/s)
+__global__ __launch_bounds__(kThreads, 4) void head_bwd_vec_kernel(const float* __restrict__ d_out,
                                                                 const float* __restrict__ outp,
                                                                 const float* __restrict__ x,
                                                                 const float* __restrict__ weight, long pixels, int HW,
@@ -585,6 +587,7 @@ __global__ __launch_bounds__(kThreads) void head_bwd_vec_kernel(const float* __r
       if (idx < NW) {
         const int k = idx / C, c = idx - k * C;
         float s = 0.f;
+#pragma unroll 4
         for (int pl = 32 * half; pl < 32 * half + 32; ++pl) s += dl[pl * kHeadMaxCls + k] * xs[pl * XS + c];
         wacc[q] += s;
       }
@@ -608,16 +611,32 @@ __global__ __launch_bounds__(kThreads) void head_bwd_vec_kernel(const float* __r
 }
 
 __global__ void sum_partials_kernel(const float* __restrict__ partial, long n_blocks, long len, float* __restrict__ out) {
-  // 64 outputs x 4 row groups per workgroup; groups combined through LDS in fixed order
-  __shared__ double part[4][64];
+  // 64 outputs x 16 row groups per workgroup (1024 threads), 4 loads in flight per thread; the groups are
+  // combined through LDS in fixed order
+  __shared__ double part[16][64];
   const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
   const long i = blockIdx.x * 64L + e;
   double s = 0.0;
-  if (i < len)
-    for (long b = g; b < n_blocks; b += 4) s += static_cast<double>(partial[b * len + i]);
+  if (i < len) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    long b = g;
+    for (; b + 48 < n_blocks; b += 64) {
+      s0 += static_cast<double>(partial[b * len + i]);
+      s1 += static_cast<double>(partial[(b + 16) * len + i]);
+      s2 += static_cast<double>(partial[(b + 32) * len + i]);
+      s3 += static_cast<double>(partial[(b + 48) * len + i]);
+    }
+    for (; b < n_blocks; b += 16) s0 += static_cast<double>(partial[b * len + i]);
+    s = (s0 + s1) + (s2 + s3);
+  }
   part[g][e] = s;
   __syncthreads();
-  if (g == 0 && i < len) out[i] = static_cast<float>((part[0][e] + part[1][e]) + (part[2][e] + part[3][e]));
+  if (g == 0 && i < len) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][e];
+    out[i] = static_cast<float>(t);
+  }
 }
 
 // ------------------------------------------------------------------ bilinear x2, align_corners = True
@@ -923,7 +942,7 @@ extern "C" int unetpp_head_bwd(const float* d_out_nchw, const float* out_nchw, c
 
 extern "C" int unetpp_sum_partials(const float* partial, int64_t n_blocks, int64_t len, float* out, void* stream) {
   if (!partial || !out || n_blocks < 1 || len < 1) return UNETPP_EINVAL;
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(static_cast<unsigned>((len + 63) / 64)), dim3(256), 0, ST(stream),
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(static_cast<unsigned>((len + 63) / 64)), dim3(1024), 0, ST(stream),
                      partial, n_blocks, len, out);
   return launch_status();
 }
