@@ -66,28 +66,40 @@ def test_two_rank_step_matches_averaged_oracle(tmp_path):
     assert r0["buckets"] >= 2
     for k in r0["params"]:
         assert torch.equal(r0["params"][k], r1["params"][k]), k   # replicas stay bit-identical
-    # expected: SGD step on the mean of the two shards' gradients (BatchNorm statistics per shard, as under
-    # the reference's nn.DataParallel)
+    # expected: SGD step on the mean of the two shards' gradients (BatchNorm statistics per shard, as under the
+    # reference's nn.DataParallel).  The per-shard gradients come from the SAME HIP path run single-process here
+    # (its parity with the oracle is test_gpu_model's job), so the comparison is exact up to the order of one
+    # addition and is not disturbed by ReLU gate flips (tests/helpers.py).
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, UNet_Nested
+    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
     grads = []
     for rank in range(2):
-        m = UNetNestedOracle(**CTOR)
+        m = UNet_Nested(**CTOR)
         m.load_state_dict(state)
-        m.train()
+        m = m.cuda().train()
         m.drop_out.eval()
         g = torch.Generator().manual_seed(200 + rank)
-        x = torch.randn(2, 1, 32, 32, generator=g)
-        t = torch.rand(2, 4, 32, 32, generator=g)
+        x = torch.randn(2, 1, 32, 32, generator=g).cuda()
+        t = torch.rand(2, 4, 32, 32, generator=g).cuda()
         outs = m(x)
-        (sum(focal_bce_2d_oracle(o, t) for o in outs) / len(outs)).backward()
-        grads.append({k: p.grad for k, p in m.named_parameters()})
+        (sum(crit(o, t) for o in outs) / len(outs)).backward()
+        grads.append({k: p.grad.cpu() for k, p in m.named_parameters()})
     for k, p0 in state.items():
         if k not in grads[0]:
             continue
         want = p0 - 0.05 * (grads[0][k] + grads[1][k]) / 2
         got = r0["params"][k]
-        if is_pre_bn_bias(k, CTOR):
-            continue
         scale = float((0.05 * (grads[0][k] + grads[1][k]) / 2).abs().max()) + 1e-12
-        # ReLU gate flips (tests/helpers.py) can move an update by a few percent of its size; wiring errors
-        # (missing all-reduce, wrong averaging) would be O(1)
-        assert float((got - want).abs().max()) < 0.1 * scale + 1e-7, k
+        # one fp32 ulp of an O(1) parameter is 1.2e-7: (p - lr*g) is rounded once on each side
+        assert float((got - want).abs().max()) < 1e-5 * scale + 2.5e-7, k
+    # and the oracle agrees on the size of the step (coarse: gate flips allowed)
+    ref.train()
+    ref.drop_out.eval()
+    g = torch.Generator().manual_seed(200)
+    x = torch.randn(2, 1, 32, 32, generator=g)
+    t = torch.rand(2, 4, 32, 32, generator=g)
+    outs = ref(x)
+    (sum(focal_bce_2d_oracle(o, t) for o in outs) / len(outs)).backward()
+    k = "final_3.weight"
+    assert float((ref.final_3.weight.grad - grads[0][k]).abs().max()) < 1e-4 * float(grads[0][k].abs().max())
+    assert not is_pre_bn_bias(k, CTOR)

@@ -285,6 +285,62 @@ __global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : (NT == 2 ? 3 
     const long row_stride = static_cast<long>(O.sy) * O.Ws * O.C, col_stride = static_cast<long>(O.sx) * O.C;
     const long tile_base = view_pixel_offset(O, g.n, g.ty0, g.tx0) + tc.nt * 32 + j;
     float s1 = 0.f, s2sum = 0.f;
+    // 16-byte path: the accumulator tile (lane = one column, 16 pixels) is transposed through a per-wave 4 KB LDS
+    // scratch so that a lane owns 4 consecutive channels of one pixel and the tile leaves as 4 dwordx4 stores of
+    // whole 128-byte pixel rows instead of 16 dword stores (a dword-per-lane store tail is issue-bound: the 32
+    // stores of a unit cost about as much as a K chunk of MFMAs).
+    const bool vec_out = ((O.C | O.c_off | tc.n_cnt) & 3) == 0 && (reinterpret_cast<uintptr_t>(O.ptr) & 15) == 0 &&
+                         (O.gate == nullptr || (reinterpret_cast<uintptr_t>(O.gate) & 15) == 0);
+    if (vec_out) {
+      float* scratch = in_tile + wave * 1024;  // [32 pixels][32 columns]; in_tile is free between the barriers
+      const long tile_base4 = tile_base - j;   // column 0 of the tile
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int prow = (64 * wave + 32 * mt) >> LOG2TW;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          const int dy = c >> LOG2TW, dx = c & (TW - 1);
+          float v = acc[t][mt][r] + bj;
+          if (O.relu) v = fmaxf(v, 0.f);
+          const bool ok = col_ok && (interior || ((g.ty0 + prow + dy < d.H) && (g.tx0 + 4 * h + dx < d.W)));
+          if (ok) {
+            s1 += v;
+            s2sum = fmaf(v, v, s2sum);
+          }
+          scratch[(c + 4 * h) * 32 + j] = v;
+          acc[t][mt][r] = 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int pi = (lane >> 3) + 8 * pass, q4 = (lane & 7) << 2;  // pixel inside the MFMA tile, first column
+          const int p = 64 * wave + 32 * mt + pi;
+          const int py = p >> LOG2TW, px = p & (TW - 1);
+          f32x4 v = *reinterpret_cast<const f32x4*>(&scratch[pi * 32 + q4]);
+          if (q4 < tc.n_cnt && (interior || ((g.ty0 + py < d.H) && (g.tx0 + px < d.W)))) {
+            const long off = tile_base4 + py * row_stride + px * col_stride + q4;
+            f32x4 gt = {1.f, 1.f, 1.f, 1.f};
+            if (O.gate != nullptr) gt = *reinterpret_cast<const f32x4*>(O.gate + off);
+            if (O.gate != nullptr && !O.gate_sum) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (gt[e] > 0.f) ? v[e] : 0.f;
+            }
+            if (O.accumulate) {
+              const f32x4 old = *reinterpret_cast<const f32x4*>(O.ptr + off);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += old[e];
+            }
+            if (O.gate != nullptr && O.gate_sum) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (gt[e] > 0.f) ? v[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(O.ptr + off) = v;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       const int prow = (64 * wave + 32 * mt) >> LOG2TW;  // first patch row of this MFMA tile
@@ -298,7 +354,7 @@ __global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : (NT == 2 ? 3 
           float v = acc[t][mt][r] + bj;
           if (O.relu) v = fmaxf(v, 0.f);
           s1 += v;
-          s2sum += v * v;
+          s2sum = fmaf(v, v, s2sum);
           const long off = lane_base + dy * row_stride + dx * col_stride;
           if (O.gate != nullptr && !O.gate_sum) v = (O.gate[off] > 0.f) ? v : 0.f;
           if (O.accumulate) v += O.ptr[off];
@@ -308,20 +364,21 @@ __global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : (NT == 2 ? 3 
         acc[t][mt][r] = 0.f;
       }
     }
+    }
     if (d.stats_partial != nullptr) {  // the LDS tiles are free here (barrier after the MFMA loop)
       s1 += __shfl_xor(s1, 32);
       s2sum += __shfl_xor(s2sum, 32);
       if (h == 0) {
-        smem[(wave * 32 + j) * 2 + 0] = s1;
-        smem[(wave * 32 + j) * 2 + 1] = s2sum;
+        w_tile[(wave * 32 + j) * 2 + 0] = s1;  // weight tile as scratch: the input tile may still be another
+        w_tile[(wave * 32 + j) * 2 + 1] = s2sum;  // wave's transpose scratch
       }
       __syncthreads();
       if (tid < tc.n_cnt) {
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-          t1 += smem[(w * 32 + tid) * 2 + 0];
-          t2 += smem[(w * 32 + tid) * 2 + 1];
+          t1 += w_tile[(w * 32 + tid) * 2 + 0];
+          t2 += w_tile[(w * 32 + tid) * 2 + 1];
         }
         float* dst = d.stats_partial + (g.patch * a.Ncols + tc.n0 + tid) * 2;
         dst[0] = t1;
@@ -389,6 +446,7 @@ __global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : (NT == 2 ? 3 
     __syncthreads();
     if (c_chunk + 1 == a.n_chunks) {
       epilogue(c_unit);  // stores drain while the next unit computes; the next chunk's loads are already in flight
+      __syncthreads();   // the epilogue used the input tile as transpose scratch
       ++c_unit;
       c_chunk = 0;
     } else {

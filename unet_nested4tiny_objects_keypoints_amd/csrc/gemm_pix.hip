@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pix_kernel(const GemmArgs a)
         float v = acc[mt][r] + bj;
         if (O.relu) v = fmaxf(v, 0.f);
         s1 += v;
-        s2 += v * v;
+        s2 = fmaf(v, v, s2);  // explicit fma: the same rounding as the fast kernel's epilogue
         const long off = view_pixel_offset(O, n, y, x) + nt * 32 + j;
         if (O.gate != nullptr && !O.gate_sum) v = (O.gate[off] > 0.f) ? v : 0.f;
         if (O.accumulate) v += O.ptr[off];
