@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (configs[1]: 32)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--feature-scale", type=float, default=1)
+    ap.add_argument("--depth", type=int, default=4, help="resolution levels (reference: 4; configs[4]: 5)")
+    ap.add_argument("--in-channels", type=int, default=1)
+    ap.add_argument("--n-classes", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--no-launch-timing", action="store_true", help="skip per-launch HIP events (roofline = null)")
@@ -78,6 +81,23 @@ def usable_cores():
     return min(n, int(os.environ.get("UNETPP_CPU_THREADS", "16")))
 
 
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (counters cannot be read from
+    inside the process: tools/pmc_traffic.py makes the file from two rocprofv3 --pmc passes of this workload)."""
+    path = os.path.join(ROOT, "profiles", "pmc_hbm_traffic_latest.json")
+    try:
+        with open(path) as f:
+            rows = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    stem = kernel_label.rstrip(">")  # "gemm_fast_kernel<9" matches "gemm_fast_kernel<9, 5, 1>"
+    hits = [r for r in rows if r["kernel"].startswith(stem)]
+    n = sum(r["launches"] for r in hits)
+    if n == 0:
+        return None
+    return round(sum((r["fetch_bytes_x2_per_launch"] + r["write_bytes_per_launch"]) * r["launches"] for r in hits) / n)
+
+
 def cpu_baseline(args, n_cls):
     """The oracle's train step (trainer/trainer.py:114-136 restated) on the host cores, batch 4."""
     import torch
@@ -88,10 +108,10 @@ def cpu_baseline(args, n_cls):
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     fs = int(args.feature_scale) if float(args.feature_scale).is_integer() else args.feature_scale
-    model = UNetNestedOracle(in_channels=1, n_classes=n_cls, feature_scale=fs).train()
+    model = UNetNestedOracle(in_channels=args.in_channels, n_classes=n_cls, feature_scale=fs, depth=args.depth).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     b = 4
-    x = torch.randn(b, 1, args.size, args.size)
+    x = torch.randn(b, args.in_channels, args.size, args.size)
     target = torch.rand(b, n_cls, args.size, args.size)
 
     def step():
@@ -157,15 +177,15 @@ def main():
         dist.barrier()
     from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, UNet_Nested, dp, ops, train_step
 
-    n_cls = 4
+    n_cls = args.n_classes
     fs = int(args.feature_scale) if float(args.feature_scale).is_integer() else args.feature_scale
     torch.manual_seed(0)
-    model = UNet_Nested(in_channels=1, n_classes=n_cls, feature_scale=fs).to(dev).train()
+    model = UNet_Nested(in_channels=args.in_channels, n_classes=n_cls, feature_scale=fs, depth=args.depth).to(dev).train()
     averager = None
     if distributed:
         averager = dp.make_data_parallel(model)
     torch.manual_seed(1000 + rank)  # every rank its own shard of synthetic data
-    x = torch.randn(args.batch, 1, args.size, args.size, device=dev)
+    x = torch.randn(args.batch, args.in_channels, args.size, args.size, device=dev)
     target = torch.rand(args.batch, n_cls, args.size, args.size, device=dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
@@ -224,11 +244,14 @@ def main():
         dom = max(launches.items(), key=lambda kv: kv[1]["ms"])
         ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
         roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                    "traffic": pmc_traffic(dom[0]) if (args.size == 256 and fs == 1 and args.batch == 32 and args.depth == 4) else None,
+                    "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes "
+                                    "of this command; profiles/pmc_hbm_traffic_latest.json)",
                     "launches_per_step": dom[1]["launches"] / args.steps,
                     "avg_launch_ms": round(dom[1]["ms"] / dom[1]["launches"], 4),
                     "flop_per_launch_avg": dom[1]["flops"] / dom[1]["launches"]}
-        if "X00.fwd" in regions and args.size == 256 and fs == 1:
+        if "X00.fwd" in regions and args.size == 256 and fs == 1 and args.in_channels == 1:
             t_img_us = 1e3 * regions["X00.fwd"]["ms"] / regions["X00.fwd"]["count"] / args.batch
             floor_c = X00_GFLOP_PER_IMG * 1e9 / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e6
             floor_h = X00_MB_PER_IMG * 1e6 / (PEAK_HBM_TBS * 1e12) * 1e6
@@ -252,9 +275,10 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "UNet_Nested(in=1,n_classes=4,base=%d,depth=4) %dx%d train step, batch %d/GPU, "
-                               "FocalLoss_BCE_2d on 3 heads, Adam, dropout p=0.4 active"
-                               % (int(32 / args.feature_scale), args.size, args.size, args.batch),
+        "config": {"workload": "UNet_Nested(in=%d,n_classes=%d,base=%d,depth=%d) %dx%d train step, batch %d/GPU, "
+                               "FocalLoss_BCE_2d on %d heads, Adam, dropout p=0.4 active"
+                               % (args.in_channels, n_cls, int(32 / args.feature_scale), args.depth, args.size, args.size,
+                                  args.batch, args.depth - 1),
                    "global_batch": world * args.batch, "per_gpu_batch": args.batch,
                    "parallelism": "dp%d" % world if distributed else "single",
                    "grad_allreduce_buckets": None if averager is None else len(averager.buckets_last_step)},

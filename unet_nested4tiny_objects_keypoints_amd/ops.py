@@ -175,7 +175,14 @@ def gemm_fwd(n: int, h: int, w: int, taps: int, ins: Sequence[V], outs: Sequence
             image = torch.empty(n_img, dtype=torch.float32, device=weight.device)
             check(lib.unetpp_gemm_pack_weight_image(C.byref(d), _ptr(image), _stream()), "unetpp_gemm_pack_weight_image")
             d.weight_image = image.data_ptr()
-    _timed_call("gemm_pix_kernel<%d>" % taps, 2.0 * n * h * w * taps * k * nc,
+    # label = the device kernel that will run (matches the rocprofv3 kernel names up to template arguments)
+    if d.weight_image:
+        label = "gemm_fast_kernel<%d>" % taps
+    elif taps == 9 and len(ins) == 1 and ins[0].t.shape[3] <= 4:
+        label = "small_cin_fwd_kernel"
+    else:
+        label = "gemm_pix_kernel<%d>" % taps
+    _timed_call(label, 2.0 * n * h * w * taps * k * nc,
                 lambda: check(_lib.lib().unetpp_gemm_fwd(C.byref(d), _stream()), "unetpp_gemm_fwd"))
 
 
@@ -202,7 +209,8 @@ def wgrad(n: int, h: int, w: int, taps: int, xs: Sequence[V], dys: Sequence[V], 
     slabs = torch.empty(split * (taps * k + 1) * nc, dtype=torch.float32, device=xs[0].t.device)
     d.n_split = split
     d.slabs = slabs.data_ptr()
-    _timed_call("wgrad_kernel<%d>" % taps, 2.0 * n * h * w * taps * k * nc,
+    small = taps == 9 and len(xs) == 1 and xs[0].t.shape[3] <= 4
+    _timed_call("small_cin_wgrad_kernel" if small else "wgrad_fast_kernel<%d>" % taps, 2.0 * n * h * w * taps * k * nc,
                 lambda: check(lib.unetpp_wgrad(C.byref(d), _stream()), "unetpp_wgrad"))
     if n_inner is None:
         n_inner = nc
