@@ -102,7 +102,11 @@ def install_hip_gates(oracle_model, hip_saved):
     d = oracle_model.depth
     for (i, j), rec in hip_saved.pairs.items():
         pair = getattr(oracle_model, "conv%d0" % i) if j == 0 else getattr(oracle_model, "up_concat%d%d" % (i, j)).conv
-        for seq, act in ((pair.conv1, rec.a1), (pair.conv2, rec.out)):
+        a1 = rec.a1
+        if a1 is None:  # BatchNorm pairs fold BN1-apply + ReLU into the consumer's load: rebuild the gate from y1
+            scale, shift = rec.bn1[2].double(), rec.bn1[3].double()
+            a1 = (rec.y1.double() * scale + shift).float()  # only the sign is used
+        for seq, act in ((pair.conv1, a1), (pair.conv2, rec.out)):
             mod = GatedReLU(nchw_mask(act))
             seq[len(seq) - 1] = mod
             gated.append(mod)

@@ -239,12 +239,31 @@ __global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : (NT == 2 ? 3 
     }
   };
   auto store_chunk = [&]() {
+    // optional load transform of the view (BatchNorm apply + ReLU folded into the consumer: the normalised
+    // activation is never materialised).  All items of a thread share one channel quad, so the coefficients are
+    // one float4 pair per chunk; zero padding stays zero because it is applied after the transform.
+    const unetpp_view& V = d.in[p_s];
+    const bool affine = V.scale != nullptr;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (affine) {
+      const int ch = p_c0 + (((tid & 3) << 2) < pf_cnt ? ((tid & 3) << 2) : 0);
+      sc = *reinterpret_cast<const f32x4*>(V.scale + ch);
+      sh = *reinterpret_cast<const f32x4*>(V.shift + ch);
+    }
 #pragma unroll
     for (int q = 0; q < IN_ITEMS; ++q) {
       const int it = tid + q * kThreads;
       const int hp = it >> 2, q4 = it & 3;
       const bool keep = ((in_mask >> q) & 1u) && (q4 << 2) < pf_cnt;
       f32x4 v = reg_in[q];
+      if (affine) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+      }
+      if (V.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0.f;
       if (it < NPIX * 4) *reinterpret_cast<f32x4*>(&in_tile[hp * KCP + (q4 << 2)]) = v;
@@ -467,7 +486,9 @@ bool fast_args(const unetpp_gemm_desc* d, FastArgs& a) {
   for (int i = 0; i < d->n_in; ++i) {
     const unetpp_view& v = d->in[i];
     if (!view_ok(v) || !view_covers(v, d->H, d->W)) return false;
-    if (v.scale != nullptr || v.gate != nullptr || v.relu) return false;
+    if (v.gate != nullptr) return false;  // ReLU gates on load go through the generic kernel
+    if (v.scale != nullptr && ((reinterpret_cast<uintptr_t>(v.scale) | reinterpret_cast<uintptr_t>(v.shift)) & 15) != 0)
+      return false;
     if (((v.C | v.c_off | v.c_len) & 3) != 0 || (reinterpret_cast<uintptr_t>(v.ptr) & 15) != 0) return false;
     if (static_cast<long>(d->N) * v.Hs * v.Ws * v.C >= 0x7fffffffL) return false;  // 32-bit element offsets
     a.Ktot += v.c_len;

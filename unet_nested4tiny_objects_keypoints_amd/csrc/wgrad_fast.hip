@@ -79,6 +79,17 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_fast_kernel(const WFastArg
     for (int i = tid; i < 2 * BUF; i += kWThreads) smem[i] = 0.f;
     __syncthreads();
   }
+  // optional load transform of the x view (BatchNorm apply + ReLU folded into the consumer): this workgroup's 32
+  // channels' coefficients live in 64 floats of LDS behind the tile buffers
+  float* coef = smem + 2 * BUF;  // [scale 32][shift 32]
+  const bool x_affine = X.scale != nullptr;
+  if (x_affine) {
+    if (tid < 32) {
+      coef[tid] = tid < k_cnt ? X.scale[c0 + tid] : 1.f;
+      coef[32 + tid] = tid < k_cnt ? X.shift[c0 + tid] : 0.f;
+    }
+    __syncthreads();
+  }
 
   // ---- staging items 0..X_ITEMS-1: x patch, X_ITEMS..N_ITEMS-1: dy patch.  Item geometry is recomputed from
   // tid (compile-time patch shape: the divisions are by constants). ----
@@ -114,6 +125,16 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_fast_kernel(const WFastArg
       const int hy = hp / HWp, hx = hp - hy * HWp;
       const int y = ty0 + hy - HALO, x = tx0 + hx - HALO;
       const bool keep = y >= 0 && y < d.H && x >= 0 && x < d.W;
+      if (x_affine) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(&coef[(it & 7) << 2]);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(&coef[32 + ((it & 7) << 2)]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+      }
+      if (X.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0.f;
       if (it < NPIX * 8 && ((it & 7) << 2) < k_cnt) *reinterpret_cast<f32x4*>(&buf[it * 4]) = v;
@@ -232,15 +253,17 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_fast_kernel(const WFastArg
   }
 }
 
-bool plain_aligned(const unetpp_view& v) {
-  return v.scale == nullptr && v.gate == nullptr && !v.relu && ((v.C | v.c_off | v.c_len) & 3) == 0 &&
-         (reinterpret_cast<uintptr_t>(v.ptr) & 15) == 0;
+// x views may carry an affine + ReLU load transform (folded BatchNorm); ReLU gates need the generic kernel
+bool aligned_view(const unetpp_view& v, bool allow_affine) {
+  if (v.gate != nullptr) return false;
+  if (!allow_affine && (v.scale != nullptr || v.relu)) return false;
+  return ((v.C | v.c_off | v.c_len) & 3) == 0 && (reinterpret_cast<uintptr_t>(v.ptr) & 15) == 0;
 }
 
 template <int TAPS, int LOG2TW>
 int launch_one(const WFastArgs& a, dim3 grid, hipStream_t st) {
   constexpr size_t lds =
-      2 * (((TAPS == 9) ? kMaxHaloPixels : kBlockPixels) * 32 + kBlockPixels * 32) * sizeof(float);
+      (2 * (((TAPS == 9) ? kMaxHaloPixels : kBlockPixels) * 32 + kBlockPixels * 32) + 64) * sizeof(float);
   // > 64 KB of dynamic LDS needs the per-function opt-in; it is idempotent and keeps the ABI stateless
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_fast_kernel<TAPS, LOG2TW>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
@@ -254,9 +277,9 @@ int launch_one(const WFastArgs& a, dim3 grid, hipStream_t st) {
 // returns UNETPP_OK after launching, or 1 when the descriptor needs the generic kernel
 int launch_wgrad_fast(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_tiles_cols, int k_tiles, hipStream_t st) {
   for (int i = 0; i < d->n_x; ++i)
-    if (!plain_aligned(d->x[i])) return 1;
+    if (!aligned_view(d->x[i], true)) return 1;
   for (int i = 0; i < d->n_dy; ++i)
-    if (!plain_aligned(d->dy[i])) return 1;
+    if (!aligned_view(d->dy[i], false)) return 1;
   WFastArgs a;
   a.d = *d;
   a.Ktot = Ktot;

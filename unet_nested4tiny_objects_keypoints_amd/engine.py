@@ -124,10 +124,10 @@ def _pair_fwd(blk, ins: List[V], b, h, w, training, pool) -> _PairRec:
         bn1, bn2 = getattr(blk.conv1, "1"), getattr(blk.conv2, "1")
         r.y1 = new()
         r.bn1 = _conv_bn_fwd(ins, conv1, bn1, r.y1, b, h, w, training)
-        r.a1 = new()
-        ops.affine_relu_pool(r.y1, r.bn1[2], r.bn1[3], True, r.a1, None, None)
+        # BatchNorm-apply + ReLU of the first stage is folded into the second convolution's operand load: the
+        # normalised activation a1 = relu(y1*scale + shift) is never written (r.a1 stays None)
         r.y2 = new()
-        r.bn2 = _conv_bn_fwd([V(r.a1)], conv2, bn2, r.y2, b, h, w, training)
+        r.bn2 = _conv_bn_fwd([V(r.y1, scale=r.bn1[2], shift=r.bn1[3], relu=True)], conv2, bn2, r.y2, b, h, w, training)
         r.out = new()
         ops.affine_relu_pool(r.y2, r.bn2[2], r.bn2[3], True, r.out, r.pooled, r.pool_idx)
     else:
@@ -299,10 +299,10 @@ def _pair_bwd(blk, r: _PairRec, d_out, in_targets: Optional[List[V]], b, grads, 
                                   _new_grad(bn2.weight), _new_grad(bn2.bias))
         grads[bn2.weight], grads[bn2.bias] = dg, dbt
         dy2 = V(d_out)
-        _conv_wgrad(conv2, [V(r.a1)], [dy2], b, h, w, grads)
-        d_a1 = torch.empty_like(r.a1)
-        ops.gemm_fwd(b, h, w, 9, [dy2], [V(d_a1)], pack_conv_dgrad(conv2.weight.detach()))
         mean, invstd, scale, shift = r.bn1
+        _conv_wgrad(conv2, [V(r.y1, scale=scale, shift=shift, relu=True)], [dy2], b, h, w, grads)  # a1 on the fly
+        d_a1 = torch.empty_like(r.y1)
+        ops.gemm_fwd(b, h, w, 9, [dy2], [V(d_a1)], pack_conv_dgrad(conv2.weight.detach()))
         dg, dbt = ops.bn_backward(d_a1, r.y1, scale, shift, mean, invstd, bn1.weight.detach(), d_a1,
                                   _new_grad(bn1.weight), _new_grad(bn1.bias))
         grads[bn1.weight], grads[bn1.bias] = dg, dbt
