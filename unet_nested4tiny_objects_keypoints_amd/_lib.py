@@ -15,7 +15,8 @@ _REPO = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.environ.get("UNETPP_LIB", os.path.join(_PKG_DIR, "libunetpp_hip.so"))  # override: kernel A/B runs
 CSRC = os.path.join(_PKG_DIR, "csrc")
 INCLUDE = os.path.join(_REPO, "include")
-SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "wgrad.hip", "wgrad_fast.hip", "first_layer.hip", "pointwise.hip")
+SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "first_layer.hip", "pointwise.hip")
+HEADERS = ("common.h", "wgrad_reduce.h")
 MAX_VIEWS = 8
 
 
@@ -91,7 +92,7 @@ _LIB = None
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into the in-tree shared object (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "unetpp_hip.h")]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "unetpp_hip.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -89,6 +89,8 @@ inline int launch_status() { return hipGetLastError() == hipSuccess ? UNETPP_OK 
 int launch_gemm_fast(const unetpp_gemm_desc* d, hipStream_t st);
 // wgrad_fast.hip: 8-wave double-buffered kernel for plain aligned views; returns 1 when it does not apply
 int launch_wgrad_fast(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_tiles_cols, int k_tiles, hipStream_t st);
+// wgrad_dma.hip: LDS-DMA staged kernel for views without load transforms; returns 1 when it does not apply
+int launch_wgrad_dma(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_tiles_cols, int k_tiles, hipStream_t st);
 // first_layer.hip: VALU kernels for the 1..4-channel first convolution; return 1 when they do not apply
 int launch_small_cin_fwd(const unetpp_gemm_desc* d, hipStream_t st);
 int launch_small_cin_wgrad(const unetpp_wgrad_desc* d, hipStream_t st);

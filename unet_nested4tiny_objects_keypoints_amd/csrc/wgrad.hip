@@ -261,6 +261,10 @@ extern "C" int unetpp_wgrad(const unetpp_wgrad_desc* d, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int small = launch_small_cin_wgrad(d, st);  // 1..4-channel first layer
   if (small != 1) return small;
+  if (getenv("UNETPP_NO_WGRAD_DMA") == nullptr) {  // (knob for A/B runs)
+    const int dma = launch_wgrad_dma(d, a.Ktot, a.Ncols, a.n_tiles_cols, k_tiles, st);
+    if (dma != 1) return dma;
+  }
   const int fast = launch_wgrad_fast(d, a.Ktot, a.Ncols, a.n_tiles_cols, k_tiles, st);
   if (fast != 1) return fast;  // launched (or failed to); 1 = views need the generic kernel
   if (d->taps == 9)

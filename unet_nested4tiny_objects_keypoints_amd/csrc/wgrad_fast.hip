@@ -14,6 +14,7 @@
 //     plus an immediate, no address registers.
 // The 8 waves are summed through LDS in fixed order; one slab per workgroup (bitwise reproducible).
 #include "common.h"
+#include "wgrad_reduce.h"
 
 namespace unetpp {
 namespace {
@@ -216,28 +217,11 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_fast_kernel(const WFastArg
     __syncthreads();
   }
 
-  // ---- fixed-order sum of the 8 waves through LDS, then one slab per workgroup ----
-  float* red = smem;  // [TAPS][32 k][32 n]
-  for (int w = 0; w < 8; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int idx = (t * 32 + row) * 32 + j;
-          red[idx] = (w == 0) ? acc[t][r] : red[idx] + acc[t][r];
-        }
-    }
-    __syncthreads();
-  }
+  // ---- fixed-order tree sum of the 8 waves through LDS, then one slab per workgroup ----
+  tree_sum_waves<TAPS>(acc, smem, smem + 2 * TAPS * 1024, wave, lane);
   const long slab_stride = (static_cast<long>(TAPS) * a.Ktot + 1) * a.Ncols;
   float* slab = d.slabs + blockIdx.x * slab_stride;
-  for (int it = tid; it < TAPS * 32 * 32; it += kWThreads) {
-    const int col = it & 31, row = (it >> 5) & 31, t = it >> 10;
-    if (row < k_cnt && col < n_cnt)
-      slab[(static_cast<long>(t) * a.Ktot + kbase + c0 + row) * a.Ncols + n0 + col] = red[it];
-  }
+  if (wave == 0) store_slab_block<TAPS>(acc, slab, a.Ktot, a.Ncols, kbase + c0, k_cnt, n0, n_cnt, j, h);
   if (want_db) {
     dbsum += __shfl_xor(dbsum, 32);
     float* dbs = smem + TAPS * 1024;
