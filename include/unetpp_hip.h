@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNETPP_ABI_VERSION 1
+#define UNETPP_ABI_VERSION 2
 #define UNETPP_MAX_VIEWS 8
 
 #define UNETPP_OK 0
@@ -59,11 +59,16 @@ typedef struct unetpp_view {
  * taps = 9: 3x3 window, zero padding 1 (padding is applied AFTER the per-view load transform);
  * taps = 1: pointwise.  Replaces nn.Conv2d(.,.,3,1,1) (models/unet.py:132,140), its input
  * gradient, nn.ConvTranspose2d(.,.,2,2,0) (:187) forward and input gradient, nn.Conv2d(.,.,1) (:191). */
+#define UNETPP_GEMM_DIRECT 1 /* flags: direct summation only.  Without it 3x3 launches on the fast path use the
+                              * Winograd F(2x2,3x3) form: same fp32 result up to rounding (~1e-7 relative), 2.25x
+                              * fewer multiplies.  The flag must be the same when the weight image is packed. */
 typedef struct unetpp_gemm_desc {
   int32_t N, H, W;
   int32_t taps;
   int32_t n_in;
   int32_t n_out;
+  int32_t flags;    /* UNETPP_GEMM_* */
+  int32_t reserved; /* 0 */
   unetpp_view in[UNETPP_MAX_VIEWS];
   unetpp_view out[UNETPP_MAX_VIEWS];
   const float* weight; /* packed [taps][K][Ncols] (see unetpp_pack_weight) */
@@ -94,12 +99,18 @@ typedef struct unetpp_wgrad_desc {
 int unetpp_abi_version(void);
 const char* unetpp_build_arch(void); /* "gfx950" */
 
-/* ---- multi-view pixel GEMM on MFMA (v_mfma_f32_32x32x2_f32) ------------------------------ */
+/* Name of the device kernel the calling thread's most recent unetpp_gemm_fwd / unetpp_wgrad call launched
+ * (profiling labels; equals the rocprofv3 kernel name up to template arguments).  Static string, "" before the
+ * first call.  Diagnostic only: it is the one piece of (thread-local) state the library keeps. */
+const char* unetpp_last_kernel_name(void);
+
+/* ---- multi-view pixel GEMM on MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32) ------ */
 int64_t unetpp_gemm_pixel_blocks(int32_t N, int32_t H, int32_t W);
 int unetpp_gemm_fwd(const unetpp_gemm_desc* d, void* stream);
-/* Fast path (register-prefetched, swizzled-LDS kernel): applies when every input view is a plain 16-byte
- * aligned slice (no scale/gate/relu on load, C, c_off and c_len multiples of 4).  Returns the image size in
- * floats, or 0 when the descriptor must use the generic kernel. */
+/* Fast path (register-prefetched LDS-image kernels; Winograd F(2x2,3x3) for taps = 9 unless UNETPP_GEMM_DIRECT):
+ * applies when every input view is a 16-byte aligned slice without a ReLU gate on load (C, c_off and c_len
+ * multiples of 4; an affine + ReLU load transform is allowed).  Returns the image size in floats, or 0 when the
+ * descriptor must use the generic kernel. */
 int64_t unetpp_gemm_weight_image_floats(const unetpp_gemm_desc* d);
 int unetpp_gemm_pack_weight_image(const unetpp_gemm_desc* d, float* image, void* stream);
 

@@ -29,6 +29,16 @@ def nchw(t):  # NHWC gpu -> NCHW cpu
     return t.permute(0, 3, 1, 2).contiguous().cpu()
 
 
+@pytest.fixture(params=["winograd", "direct"])
+def conv_algo(request):
+    """3x3 fast path: Winograd F(2x2,3x3) (default) or direct summation (UNETPP_GEMM_DIRECT)."""
+    from unet_nested4tiny_objects_keypoints_amd import ops
+    old = ops.USE_WINOGRAD
+    ops.USE_WINOGRAD = request.param == "winograd"
+    yield request.param
+    ops.USE_WINOGRAD = old
+
+
 @pytest.mark.parametrize("shape", [
     # (B, H, W, [cin per source], cout)
     (2, 16, 16, [8], 8),
@@ -42,7 +52,7 @@ def nchw(t):  # NHWC gpu -> NCHW cpu
     (1, 24, 40, [3], 8),          # first-layer VALU kernel, rgb, ragged patches
     (1, 16, 16, [4], 64),
 ])
-def test_conv3x3_fwd_multiview(dev, shape):
+def test_conv3x3_fwd_multiview(dev, shape, conv_algo):
     from unet_nested4tiny_objects_keypoints_amd import engine, ops
     from unet_nested4tiny_objects_keypoints_amd.ops import V
     b, h, w, cins, co = shape
@@ -64,7 +74,7 @@ def test_conv3x3_fwd_multiview(dev, shape):
     assert rel_err(sums[:, 1], (ref.double() ** 2).sum((0, 2, 3))) < TOL
 
 
-def test_conv3x3_load_transform_and_slices(dev):
+def test_conv3x3_load_transform_and_slices(dev, conv_algo):
     """affine + ReLU applied on load (zero padding AFTER the transform), channel-sliced views, store gate/accumulate."""
     from unet_nested4tiny_objects_keypoints_amd import engine, ops
     from unet_nested4tiny_objects_keypoints_amd.ops import V
@@ -114,7 +124,7 @@ def test_fast_and_generic_gemm_agree(dev, shape):
         try:
             out = torch.empty(b, h, w, co, device=dev)
             part = torch.empty(ops.gemm_pixel_blocks(b, h, w) * co * 2, device=dev)
-            ops.gemm_fwd(b, h, w, 9, [V(s) for s in srcs], [V(out)], wp, bias, part)
+            ops.gemm_fwd(b, h, w, 9, [V(s) for s in srcs], [V(out)], wp, bias, part, direct=True)
         finally:
             ops.USE_FAST_GEMM = True
         res.append((out, part))
@@ -122,7 +132,34 @@ def test_fast_and_generic_gemm_agree(dev, shape):
     assert torch.equal(res[0][1], res[1][1])
 
 
-def test_conv3x3_dgrad_matches_autograd(dev):
+@pytest.mark.parametrize("shape", [(2, 32, 32, [32], 32), (1, 64, 64, [32, 32, 32, 32], 32), (2, 8, 8, [16, 8, 8], 40),
+                                   (1, 24, 40, [8], 4), (3, 16, 16, [64, 32], 96), (2, 3, 5, [12], 16),
+                                   (1, 37, 21, [20, 4], 36), (1, 128, 128, [64], 64)])
+def test_winograd_matches_direct(dev, shape):
+    """Winograd F(2x2,3x3) and direct summation are the same convolution up to fp32 rounding: outputs within 2e-6 of
+    the largest magnitude (odd image sizes, ragged patches, partial column tiles and K chunks included), BatchNorm
+    partial sums within 1e-5, and the library reports which kernel ran."""
+    from unet_nested4tiny_objects_keypoints_amd import _lib, engine, ops
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    b, h, w, cins, co = shape
+    g = torch.Generator().manual_seed(11)
+    srcs = [nhwc(torch.randn(b, c, h, w, generator=g)) for c in cins]
+    wp = engine.pack_conv_fwd((torch.randn(co, sum(cins), 3, 3, generator=g) * 0.2).cuda())
+    bias = torch.randn(co, generator=g).cuda()
+    res, names = [], []
+    for direct in (False, True):
+        out = torch.full((b, h, w, co), float("nan"), device=dev)
+        part = torch.empty(ops.gemm_pixel_blocks(b, h, w) * co * 2, device=dev)
+        ops.gemm_fwd(b, h, w, 9, [V(s) for s in srcs], [V(out, relu=True)], wp, bias, part, direct=direct)
+        names.append(_lib.lib().unetpp_last_kernel_name().decode())
+        res.append((out, part))
+    assert names == ["gemm_wino_kernel", "gemm_fast_kernel<9>"]
+    scale = res[1][0].abs().max().item()
+    assert (res[0][0] - res[1][0]).abs().max().item() <= 2e-6 * scale
+    assert rel_err(res[0][1].cpu(), res[1][1].cpu()) < 1e-5
+
+
+def test_conv3x3_dgrad_matches_autograd(dev, conv_algo):
     from unet_nested4tiny_objects_keypoints_amd import engine, ops
     from unet_nested4tiny_objects_keypoints_amd.ops import V
     b, h, w, ci, co = 2, 16, 24, 20, 12

@@ -15,9 +15,13 @@ _REPO = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.environ.get("UNETPP_LIB", os.path.join(_PKG_DIR, "libunetpp_hip.so"))  # override: kernel A/B runs
 CSRC = os.path.join(_PKG_DIR, "csrc")
 INCLUDE = os.path.join(_REPO, "include")
-SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "first_layer.hip", "pointwise.hip")
-HEADERS = ("common.h", "wgrad_reduce.h")
+SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_wino.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "first_layer.hip", "pointwise.hip")
+HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h")
 MAX_VIEWS = 8
+ABI_VERSION = 2
+# packed-f32 VALU (SLP-vectorised add pairs) costs issue slots beside MFMAs: keep the Winograd transforms scalar
+EXTRA_FLAGS = {"gemm_wino.hip": ("-fno-slp-vectorize",)}
+GEMM_DIRECT = 1  # unetpp_gemm_desc.flags: direct summation only (no Winograd)
 
 
 class View(C.Structure):
@@ -37,6 +41,7 @@ class GemmDesc(C.Structure):
     _fields_ = [
         ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
         ("taps", C.c_int32), ("n_in", C.c_int32), ("n_out", C.c_int32),
+        ("flags", C.c_int32), ("reserved", C.c_int32),
         ("inp", View * MAX_VIEWS), ("out", View * MAX_VIEWS),
         ("weight", C.c_void_p), ("bias", C.c_void_p), ("stats_partial", C.c_void_p),
         ("weight_image", C.c_void_p),
@@ -60,6 +65,7 @@ _P, _I32, _I64, _F, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint
 SIGNATURES = {
     "unetpp_abi_version": (C.c_int, []),
     "unetpp_build_arch": (C.c_char_p, []),
+    "unetpp_last_kernel_name": (C.c_char_p, []),
     "unetpp_gemm_pixel_blocks": (_I64, [_I32, _I32, _I32]),
     "unetpp_gemm_fwd": (C.c_int, [C.POINTER(GemmDesc), _P]),
     "unetpp_gemm_weight_image_floats": (_I64, [C.POINTER(GemmDesc)]),
@@ -96,11 +102,23 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC,
-           "-o", LIB_PATH] + srcs
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC]
+    obj_dir = os.path.join(_REPO, "build", "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    jobs = []
+    for src in SOURCES:  # one object per source, compiled concurrently; EXTRA_FLAGS are per kernel file
+        obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
+        cmd = common + list(EXTRA_FLAGS.get(src, ())) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((obj, cmd, subprocess.Popen(cmd)))
+    for obj, cmd, proc in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + [j[0] for j in jobs]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+        print(" ".join(link))
+    subprocess.run(link, check=True)
     global _LIB
     _LIB = None
     return LIB_PATH
@@ -119,7 +137,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if handle.unetpp_abi_version() != 1:
+        if handle.unetpp_abi_version() != ABI_VERSION:
             raise RuntimeError("unetpp HIP library ABI mismatch")
         _LIB = handle
     return _LIB

@@ -223,6 +223,7 @@ int launch_small_cin_fwd(const unetpp_gemm_desc* d, hipStream_t st) {
     case 3: hipLaunchKernelGGL(small_cin_fwd_kernel<3>, grid, block, 0, st, a); break;
     default: hipLaunchKernelGGL(small_cin_fwd_kernel<4>, grid, block, 0, st, a); break;
   }
+  note_kernel("small_cin_fwd_kernel");
   return launch_status();
 }
 
@@ -247,6 +248,7 @@ int launch_small_cin_wgrad(const unetpp_wgrad_desc* d, hipStream_t st) {
     case 3: hipLaunchKernelGGL(small_cin_wgrad_kernel<3>, grid, block, 0, st, a); break;
     default: hipLaunchKernelGGL(small_cin_wgrad_kernel<4>, grid, block, 0, st, a); break;
   }
+  note_kernel("small_cin_wgrad_kernel");
   return launch_status();
 }
 

@@ -16,25 +16,12 @@
 //   * one linear grid with the 32-column tile as the fastest index (consecutive workgroups re-read the
 //     same input patch from L2) and an XCD-aware bijective remap, so neighbouring patches share an L2.
 #include "common.h"
+#include "gemm_units.h"
 
 namespace unetpp {
 namespace {
 
 constexpr int KC = 16;
-
-struct FastArgs {
-  unetpp_gemm_desc d;
-  int log2tw, tiles_x, tiles_y;
-  int Ktot, Ncols, n_tiles, n_chunks;
-  int nt_unit, n_groups;  // column tiles per unit of work, units per pixel patch (n_tiles / nt_unit)
-  long total_blocks;
-};
-
-__device__ __forceinline__ long xcd_remap(long bid, long total) {
-  const long q = total >> 3, r = total & 7;
-  const long xcd = bid & 7, idx = bid >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
 
 // image of one (column tile, K chunk): [tap][g 2][col 32][half' 2][4] floats, half' = half ^ ((col>>3)&1)
 template <int TAPS>
@@ -74,54 +61,6 @@ __global__ void pack_image_kernel(const FastArgs a, float* __restrict__ img) {
   float v = 0.f;
   if (k_ok && n_ok) v = a.d.weight[(static_cast<long>(tap) * a.Ktot + kbase + kin) * a.Ncols + col_base + cin];
   img[i] = v;
-}
-
-// A unit of work = (256-pixel patch, 32-column tile), column tile fastest.  Workgroups are PERSISTENT: the grid is
-// at most 3 per CU and every workgroup walks its units as one flat stream of K chunks, so the first chunk of the
-// next unit is prefetched under the last MFMA loop of the current one and the epilogue's stores drain under the next
-// unit's MFMAs.  (With one unit per workgroup the co-resident workgroups run in lockstep -- all load, all compute,
-// all store -- and a short-K unit spends 40 % of its time outside the MFMA loop.)
-struct UnitGeom {
-  int n, ty0, tx0;  // image, patch origin
-  int group;        // first column tile = group * nt_unit
-  long patch;       // pixel-patch index (BatchNorm partial row)
-};
-struct TileCols {
-  int nt, ov;     // tile index inside its out view; the out view
-  int n0, n_cnt;  // first GEMM column, valid columns
-};
-
-__device__ __forceinline__ TileCols decode_tile(const FastArgs& a, int nt_global) {
-  int nt = nt_global, ov = 0, col_base = 0;
-  while (ov < a.d.n_out - 1) {
-    const int tiles_v = (a.d.out[ov].c_len + 31) >> 5;
-    if (nt < tiles_v) break;
-    nt -= tiles_v;
-    col_base += a.d.out[ov].c_len;
-    ++ov;
-  }
-  TileCols t;
-  t.nt = nt;
-  t.ov = ov;
-  t.n0 = col_base + nt * 32;
-  t.n_cnt = min(32, a.d.out[ov].c_len - nt * 32);
-  return t;
-}
-
-template <int LOG2TW>
-__device__ __forceinline__ UnitGeom decode_unit(const FastArgs& a, long lb) {
-  constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;
-  UnitGeom g;
-  g.group = static_cast<int>(lb % a.n_groups);
-  long bid = lb / a.n_groups;
-  g.patch = bid;
-  const int txi = static_cast<int>(bid % a.tiles_x);
-  bid /= a.tiles_x;
-  const int tyi = static_cast<int>(bid % a.tiles_y);
-  g.n = static_cast<int>(bid / a.tiles_y);
-  g.ty0 = tyi * TH;
-  g.tx0 = txi * TW;
-  return g;
 }
 
 // NT = column tiles per unit.  3x3 convolutions use NT = 1 (3 workgroups per CU); the pointwise GEMMs of the 2x2
@@ -477,46 +416,11 @@ __global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : (NT == 2 ? 3 
   }
 }
 
-bool fast_args(const unetpp_gemm_desc* d, FastArgs& a) {
-  if (d == nullptr || d->N <= 0 || d->H <= 0 || d->W <= 0) return false;
-  if (d->taps != 9 && d->taps != 1) return false;
-  if (d->n_in < 1 || d->n_in > UNETPP_MAX_VIEWS || d->n_out < 1 || d->n_out > UNETPP_MAX_VIEWS) return false;
-  a.d = *d;
-  a.Ktot = a.Ncols = a.n_tiles = a.n_chunks = 0;
-  for (int i = 0; i < d->n_in; ++i) {
-    const unetpp_view& v = d->in[i];
-    if (!view_ok(v) || !view_covers(v, d->H, d->W)) return false;
-    if (v.gate != nullptr) return false;  // ReLU gates on load go through the generic kernel
-    if (v.scale != nullptr && ((reinterpret_cast<uintptr_t>(v.scale) | reinterpret_cast<uintptr_t>(v.shift)) & 15) != 0)
-      return false;
-    if (((v.C | v.c_off | v.c_len) & 3) != 0 || (reinterpret_cast<uintptr_t>(v.ptr) & 15) != 0) return false;
-    if (static_cast<long>(d->N) * v.Hs * v.Ws * v.C >= 0x7fffffffL) return false;  // 32-bit element offsets
-    a.Ktot += v.c_len;
-    a.n_chunks += (v.c_len + KC - 1) / KC;
-  }
-  for (int i = 0; i < d->n_out; ++i) {
-    if (!view_ok(d->out[i]) || !view_covers(d->out[i], d->H, d->W)) return false;
-    a.Ncols += d->out[i].c_len;
-    a.n_tiles += (d->out[i].c_len + 31) / 32;
-  }
-  const TileGeom g = tile_geom(d->H, d->W);
-  a.log2tw = g.log2tw;
-  a.tiles_x = g.tiles_x;
-  a.tiles_y = g.tiles_y;
-  // column tiles per unit: pointwise GEMMs (deconvolution phases) without a statistics epilogue take 4 or 2
-  a.nt_unit = 1;
-  if (d->taps == 1 && d->stats_partial == nullptr) a.nt_unit = (a.n_tiles % 4 == 0) ? 4 : ((a.n_tiles % 2 == 0) ? 2 : 1);
-  if (a.nt_unit > 2) a.nt_unit = 2;  // measured: 2 tiles x 3 workgroups per CU beats 4 tiles x 2 on the deconvolutions
-  a.n_groups = a.n_tiles / a.nt_unit;
-  a.total_blocks = static_cast<long>(d->N) * g.tiles_y * g.tiles_x * a.n_groups;
-  return a.total_blocks <= 0x7fffffffL;
-}
-
 }  // namespace
 
 int launch_gemm_fast(const unetpp_gemm_desc* d, hipStream_t st) {
   FastArgs a;
-  if (!fast_args(d, a) || d->weight_image == nullptr) return UNETPP_EINVAL;
+  if (!fast_args(d, a, KC) || d->weight_image == nullptr) return UNETPP_EINVAL;
   if (d->stats_partial != nullptr && d->n_out != 1) return UNETPP_EINVAL;
   // persistent grid: at most 3 workgroups per CU (the kernel's LDS/VGPR budget), a multiple of 8
   int dev = 0, cus = 0;
@@ -538,6 +442,7 @@ int launch_gemm_fast(const unetpp_gemm_desc* d, hipStream_t st) {
   else if (a.nt_unit == 2) UNETPP_LAUNCH_FAST(1, 2);
   else UNETPP_LAUNCH_FAST(1, 1);
 #undef UNETPP_LAUNCH_FAST
+  note_kernel(d->taps == 9 ? "gemm_fast_kernel<9>" : "gemm_fast_kernel<1>");
   return launch_status();
 }
 
@@ -546,14 +451,16 @@ int launch_gemm_fast(const unetpp_gemm_desc* d, hipStream_t st) {
 using namespace unetpp;
 
 extern "C" int64_t unetpp_gemm_weight_image_floats(const unetpp_gemm_desc* d) {
+  if (wino_applies(d)) return wino_image_floats(d);
   FastArgs a;
-  if (!fast_args(d, a)) return 0;
+  if (!fast_args(d, a, KC)) return 0;
   return static_cast<int64_t>(a.n_tiles) * a.n_chunks * d->taps * 512;
 }
 
 extern "C" int unetpp_gemm_pack_weight_image(const unetpp_gemm_desc* d, float* image, void* stream) {
+  if (wino_applies(d)) return wino_pack_image(d, image, static_cast<hipStream_t>(stream));
   FastArgs a;
-  if (!fast_args(d, a) || image == nullptr || d->weight == nullptr) return UNETPP_EINVAL;
+  if (!fast_args(d, a, KC) || image == nullptr || d->weight == nullptr) return UNETPP_EINVAL;
   const long total = static_cast<long>(a.n_tiles) * a.n_chunks * d->taps * 512;
   const unsigned blocks = static_cast<unsigned>((total + 255) / 256);
   hipStream_t st = static_cast<hipStream_t>(stream);

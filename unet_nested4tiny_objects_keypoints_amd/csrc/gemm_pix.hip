@@ -183,7 +183,16 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pix_kernel(const GemmArgs a)
 }  // namespace
 }  // namespace unetpp
 
+namespace unetpp {
+namespace {
+thread_local const char* g_last_kernel = "";
+}
+void note_kernel(const char* name) { g_last_kernel = name; }
+}  // namespace unetpp
+
 using namespace unetpp;
+
+extern "C" const char* unetpp_last_kernel_name(void) { return g_last_kernel; }
 
 extern "C" int64_t unetpp_gemm_pixel_blocks(int32_t N, int32_t H, int32_t W) {
   if (N <= 0 || H <= 0 || W <= 0) return 0;
@@ -197,7 +206,9 @@ extern "C" int unetpp_gemm_fwd(const unetpp_gemm_desc* d, void* stream) {
   if (d->n_in < 1 || d->n_in > UNETPP_MAX_VIEWS || d->n_out < 1 || d->n_out > UNETPP_MAX_VIEWS) return UNETPP_EINVAL;
   if (d->weight == nullptr) return UNETPP_EINVAL;
   if (d->stats_partial != nullptr && d->n_out != 1) return UNETPP_EINVAL;
-  if (d->weight_image != nullptr) return launch_gemm_fast(d, static_cast<hipStream_t>(stream));
+  if (d->weight_image != nullptr)  // the image was packed for the algorithm the same descriptor selects
+    return wino_applies(d) ? launch_gemm_wino(d, static_cast<hipStream_t>(stream))
+                           : launch_gemm_fast(d, static_cast<hipStream_t>(stream));
   GemmArgs a;
   a.d = *d;
   a.Ktot = 0;
@@ -228,5 +239,6 @@ extern "C" int unetpp_gemm_fwd(const unetpp_gemm_desc* d, void* stream) {
     hipLaunchKernelGGL(gemm_pix_kernel<9>, grid, dim3(kThreads), 0, st, a);
   else
     hipLaunchKernelGGL(gemm_pix_kernel<1>, grid, dim3(kThreads), 0, st, a);
+  note_kernel(d->taps == 9 ? "gemm_pix_kernel<9>" : "gemm_pix_kernel<1>");
   return launch_status();
 }

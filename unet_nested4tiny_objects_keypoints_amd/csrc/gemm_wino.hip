@@ -1,0 +1,533 @@
+// Winograd F(2x2, 3x3) form of the 3x3 multi-view pixel GEMM (forward and input gradient of every 3x3 convolution
+// with 4-aligned channel slices): 16 multiplies per 2x2 output tile and (channel, column) pair instead of 36, i.e.
+// 2.25x fewer MFMA cycles than gemm_fast.hip for the same algorithmic FLOPs.  fp32 throughout; against a direct
+// fp32 convolution the result differs by rounding only (max error ~2x that of the direct sum).
+//
+//   Y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A        d = 4x4 input window, g = 3x3 filter, Y = 2x2 outputs
+//
+// Mapping onto v_mfma_f32_16x16x4_f32 (exact fp32, same FLOP rate as 32x32x2):
+//   * unit of work = 256-pixel patch (64 tiles of 2x2) x 32 columns, 4 waves; a wave owns 16 tiles;
+//   * MFMA row = tile, MFMA k = 4 channels, MFMA column = output column: for each of the 16 transform positions xi
+//     one accumulator pair (2 x 16 columns): acc[16][2] float4 = 128 VGPRs per lane;
+//   * A operand: lane (tile t, k-slot g) reads its 4x4 window for channels 2g, 2g+1 as 16 ds_read_b64, runs the input
+//     transform B^T d B IN REGISTERS (32 add/sub per channel) and feeds the 16 results straight to the MFMAs -- the
+//     transformed input never exists in memory;
+//   * B operand: the transformed weights U = G g G^T are precomputed per launch (pack_wino_kernel) as an LDS image
+//     [xi][k-slot][col][column half][channel] -- one conflict-free ds_read_b128 per xi feeds 4 MFMAs;
+//   * all 16 xi of a (tile, column) land in the same lane and register index, so the output transform A^T M A is
+//     lane-local (24 add/sub per 2x2 tile); bias/ReLU/gate/accumulate/BatchNorm partial sums and the 16-byte
+//     transposed stores then follow the direct kernel's epilogue.
+//   * K in chunks of 8 channels, staged global -> registers -> LDS one chunk ahead (same persistent, flattened
+//     (unit, chunk) stream as gemm_fast.hip); 32 KB LDS and <= 256 VGPRs: two workgroups per CU.
+#include "common.h"
+#include "gemm_units.h"
+
+namespace unetpp {
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int WKC = 8;      // channels per K chunk
+constexpr int WP = 10;      // LDS pixel stride of the input patch (floats): 8 channels + 2 pad -- the b64 window reads
+                            // of the 16 tiles x 2 k-slots of a half wave (stride 20 floats + 2) hit 64 distinct banks
+constexpr int WIMG = 4096;  // floats of one (column tile, chunk) weight image
+
+// image of one (column tile, chunk): [s 2][xi 16][g 4][col 16][nh 2],
+// value = U[xi][channel chunk*8 + 2g + s][column tile*32 + 16*nh + col],  U = G g G^T
+__global__ void pack_wino_kernel(const FastArgs a, float* __restrict__ img) {
+  const long total = static_cast<long>(a.n_tiles) * a.n_chunks * WIMG;
+  const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+  if (i >= total) return;
+  const int nh = i & 1, col = (i >> 1) & 15, g = (i >> 5) & 3, xi = (i >> 7) & 15, s = (i >> 11) & 1;
+  const long r = i >> 12;
+  int chunk = static_cast<int>(r % a.n_chunks);
+  int nt = static_cast<int>(r / a.n_chunks);
+  int kbase = 0, v = 0;
+  for (; v < a.d.n_in; ++v) {
+    const int ch = (a.d.in[v].c_len + WKC - 1) / WKC;
+    if (chunk < ch) break;
+    chunk -= ch;
+    kbase += a.d.in[v].c_len;
+  }
+  const int kin = chunk * WKC + 2 * g + s;
+  const bool k_ok = kin < a.d.in[v].c_len;
+  int col_base = 0, ov = 0;
+  for (; ov < a.d.n_out; ++ov) {
+    const int tv = (a.d.out[ov].c_len + 31) >> 5;
+    if (nt < tv) break;
+    nt -= tv;
+    col_base += a.d.out[ov].c_len;
+  }
+  const int cin = nt * 32 + 16 * nh + col;
+  const bool n_ok = cin < a.d.out[ov].c_len;
+  float u = 0.f;
+  if (k_ok && n_ok) {
+    const float* w = a.d.weight + static_cast<long>(kbase + kin) * a.Ncols + col_base + cin;
+    const long tap_stride = static_cast<long>(a.Ktot) * a.Ncols;
+    const int ra = xi >> 2, rb = xi & 3;
+    // row ra of G applied down the filter rows, then row rb of G along the filter columns
+    float t[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float w0 = w[(0 * 3 + c) * tap_stride], w1 = w[(1 * 3 + c) * tap_stride], w2 = w[(2 * 3 + c) * tap_stride];
+      t[c] = ra == 0 ? w0 : (ra == 1 ? 0.5f * (w0 + w1 + w2) : (ra == 2 ? 0.5f * (w0 - w1 + w2) : w2));
+    }
+    u = rb == 0 ? t[0] : (rb == 1 ? 0.5f * (t[0] + t[1] + t[2]) : (rb == 2 ? 0.5f * (t[0] - t[1] + t[2]) : t[2]));
+  }
+  img[i] = u;
+}
+
+template <int LOG2TW>
+__global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a) {
+  constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;
+  constexpr int HWp = TW + 2, HHp = TH + 2;
+  constexpr int NPIX = HWp * HHp;
+  constexpr int TXN = TW / 2;        // 2x2 tiles per patch row
+  constexpr int IN_FLOATS = 4096;    // >= kMaxHaloPixels * WP (4080); also the 4 x 4 KB transpose scratch of the epilogue
+  constexpr int IN_ITEMS = (NPIX * 2 + kThreads - 1) / kThreads;  // 16-byte items, 2 per pixel (<= 3)
+  constexpr int W_ITEMS = WIMG / 4 / kThreads;                    // 16-byte DMA pieces per thread: 4
+  static_assert(kMaxHaloPixels * WP <= IN_FLOATS, "input patch does not fit");
+  // The weight images go HBM/L2 -> LDS by DMA (global_load_lds, no staging registers: the accumulators leave none),
+  // double buffered.  The two buffers are DISTINCT static arrays and the chunk loop is unrolled by two: with one
+  // array and a runtime index hipcc must assume that the DMA in flight aliases the ds_reads of the buffer being
+  // computed and drains vmcnt before each of them.
+  __shared__ __attribute__((aligned(16))) float in_tile[IN_FLOATS];
+  __shared__ __attribute__((aligned(16))) float w_a[WIMG];
+  __shared__ __attribute__((aligned(16))) float w_b[WIMG];
+
+  const unetpp_gemm_desc& d = a.d;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, t16 = lane & 15, g = lane >> 4;
+
+  const UnitRange ur = my_unit_range(a.total_blocks);
+  if (ur.count == 0) return;
+
+  // compute side: this lane's tile (A operand / input transform) and weight-image slot (B operand)
+  const int my_tile = 16 * wave + t16;
+  const int a_base = ((2 * (my_tile / TXN)) * HWp + 2 * (my_tile % TXN)) * WP + 2 * g;
+  const int b_base = (g * 16 + t16) * 2;
+
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) acc[xi][nh] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- prefetch side (same scheme as gemm_fast.hip): the chunk that is loaded next ----
+  f32x4 reg_in[IN_ITEMS];
+  unsigned voff[IN_ITEMS];
+  unsigned in_mask = 0;
+  int pf_cnt = 0;
+  long p_unit = 0;
+  int p_s = 0, p_c0 = 0, p_chunk = 0;
+  int p_n = 0, p_ty0 = 0, p_tx0 = 0;
+  const float* p_wimg = nullptr;
+  const int cc = (tid & 1) << 2;  // channel quad of every staging item of this thread (kThreads is even)
+
+  auto prefetch_unit = [&](long k) {
+    const UnitGeom ug = decode_unit<LOG2TW>(a, ur.first + k * ur.step);
+    p_n = ug.n;
+    p_ty0 = ug.ty0;
+    p_tx0 = ug.tx0;
+    p_wimg = d.weight_image + static_cast<long>(ug.group) * a.n_chunks * WIMG;
+    in_mask = 0;
+#pragma unroll
+    for (int q = 0; q < IN_ITEMS; ++q) {
+      const int it = tid + q * kThreads;
+      const int hp = it >> 1;
+      const int hy = hp / HWp, hx = hp - hy * HWp;
+      const int y = p_ty0 + hy - 1, x = p_tx0 + hx - 1;
+      if ((it < NPIX * 2) && y >= 0 && y < d.H && x >= 0 && x < d.W) in_mask |= 1u << q;
+    }
+  };
+  auto view_offsets = [&](const unetpp_view& V) {  // clamped: every item loads from a valid address
+#pragma unroll
+    for (int q = 0; q < IN_ITEMS; ++q) {
+      const int hp = min((tid + q * kThreads) >> 1, NPIX - 1);
+      const int hy = hp / HWp, hx = hp - hy * HWp;
+      const int yy = min(max(p_ty0 + hy - 1, 0), d.H - 1), xx = min(max(p_tx0 + hx - 1, 0), d.W - 1);
+      voff[q] = view_pixel_offset32(V, p_n, yy, xx);
+    }
+  };
+  auto load_chunk = [&]() {
+    const unetpp_view& V = d.in[p_s];
+    pf_cnt = min(WKC, V.c_len - p_c0);
+#pragma unroll
+    for (int q = 0; q < IN_ITEMS; ++q) {
+      const unsigned off = voff[q] + static_cast<unsigned>(p_c0 + (cc < pf_cnt ? cc : 0));
+      reg_in[q] = *reinterpret_cast<const f32x4*>(V.ptr + off);
+    }
+  };
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto issue_weights = [&](float* buf) {  // image of the prefetch cursor's chunk -> buf (lane-linear 1 KB pieces)
+    const float* wp = p_wimg + static_cast<long>(p_chunk) * WIMG;
+#pragma unroll
+    for (int q = 0; q < W_ITEMS; ++q)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wp + (q * kThreads + tid) * 4), (lptr_t)(buf + (q * kThreads + wave * 64) * 4),
+                                       16, 0, 0);
+  };
+  auto store_chunk = [&]() {
+    const unetpp_view& V = d.in[p_s];
+    const bool affine = V.scale != nullptr;  // BatchNorm apply + ReLU folded into the operand load
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (affine) {
+      const int ch = p_c0 + (cc < pf_cnt ? cc : 0);
+      sc = *reinterpret_cast<const f32x4*>(V.scale + ch);
+      sh = *reinterpret_cast<const f32x4*>(V.shift + ch);
+    }
+#pragma unroll
+    for (int q = 0; q < IN_ITEMS; ++q) {
+      const int it = tid + q * kThreads;
+      const bool keep = ((in_mask >> q) & 1u) && cc < pf_cnt;
+      f32x4 v = reg_in[q];
+      if (affine) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+      }
+      if (V.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0.f;  // zero padding is applied after the transform
+      if (it < NPIX * 2) {  // 40-byte pixel rows: two 8-byte stores
+        *reinterpret_cast<f32x2*>(&in_tile[(it >> 1) * WP + cc]) = f32x2{v[0], v[1]};
+        *reinterpret_cast<f32x2*>(&in_tile[(it >> 1) * WP + cc + 2]) = f32x2{v[2], v[3]};
+      }
+    }
+  };
+
+  // ---- epilogue of a finished unit: output transform, bias / ReLU / gate / accumulate, BatchNorm partial sums ----
+  // Register rr of acc[xi][nh] of lane (t16, g) belongs to tile 16*wave + 4*g + rr and column t16 + 16*nh.
+  auto epilogue = [&](long k, float* w_tile) {  // w_tile: the weight buffer just computed from (free: stats scratch)
+    const UnitGeom ug = decode_unit<LOG2TW>(a, ur.first + k * ur.step);
+    const TileCols tc = decode_tile(a, ug.group);
+    const unetpp_view& O = d.out[tc.ov];
+    const bool interior = (ug.ty0 + TH <= d.H) && (ug.tx0 + TW <= d.W);
+    bool col_ok[2];
+    float bj[2], s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      col_ok[nh] = t16 + 16 * nh < tc.n_cnt;
+      bj[nh] = (d.bias != nullptr && col_ok[nh]) ? d.bias[tc.n0 + t16 + 16 * nh] : 0.f;
+    }
+    const long row_stride = static_cast<long>(O.sy) * O.Ws * O.C, col_stride = static_cast<long>(O.sx) * O.C;
+    const long tile_base4 = view_pixel_offset(O, ug.n, ug.ty0, ug.tx0) + tc.nt * 32;  // column 0 of the tile
+    const bool vec_out = ((O.C | O.c_off | tc.n_cnt) & 3) == 0 && (reinterpret_cast<uintptr_t>(O.ptr) & 15) == 0 &&
+                         (O.gate == nullptr || (reinterpret_cast<uintptr_t>(O.gate) & 15) == 0);
+    float* scratch = in_tile + wave * 1024;  // [32 pixels][32 columns]; in_tile is free between the barriers
+    const bool want_stats = d.stats_partial != nullptr;
+    if (interior && vec_out && tc.n_cnt == 32) {
+      // ---- lean path (whole patch inside the image, all 32 columns, 16-byte stores): no per-element predicates,
+      // 32-bit offsets from one scalar base, bias folded into M[1][1] (its weight is +1 in all four outputs) ----
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc[5][nh][rr] += bj[nh];
+      const float floor_v = O.relu ? 0.f : -__builtin_inff();
+      float* obase = O.ptr + tile_base4;
+      const float* gbase = O.gate != nullptr ? O.gate + tile_base4 : nullptr;
+      const unsigned rs = static_cast<unsigned>(row_stride), cs = static_cast<unsigned>(col_stride);
+      const int sw_col0 = t16 ^ ((g & 1) << 4);
+#pragma unroll
+      for (int ap = 0; ap < 2; ++ap) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh) {
+            float tb[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+              tb[b] = (ap == 0) ? (acc[b][nh][rr] + acc[4 + b][nh][rr]) + acc[8 + b][nh][rr]
+                                : (acc[4 + b][nh][rr] - acc[8 + b][nh][rr]) - acc[12 + b][nh][rr];
+            const float y0 = fmaxf((tb[0] + tb[1]) + tb[2], floor_v), y1 = fmaxf((tb[1] - tb[2]) - tb[3], floor_v);
+            if (want_stats) {
+              s1[nh] += y0 + y1;
+              s2[nh] = fmaf(y0, y0, fmaf(y1, y1, s2[nh]));
+            }
+            scratch[(2 * (4 * g + rr)) * 32 + (sw_col0 ^ (nh << 4))] = y0;
+            scratch[(2 * (4 * g + rr) + 1) * 32 + (sw_col0 ^ (nh << 4))] = y1;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int pi = (lane >> 3) + 8 * pass, q4 = (lane & 7) << 2;
+          const int tl = pi >> 1;
+          const int tile = 16 * wave + tl;
+          const unsigned py = 2 * (tile / TXN) + ap, px = 2 * (tile % TXN) + (pi & 1);
+          const unsigned off = py * rs + px * cs + q4;
+          f32x4 v = *reinterpret_cast<const f32x4*>(&scratch[pi * 32 + (q4 ^ (((tl >> 2) & 1) << 4))]);
+          if (gbase != nullptr) {
+            const f32x4 gt = *reinterpret_cast<const f32x4*>(gbase + off);
+            if (!O.gate_sum) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (gt[e] > 0.f) ? v[e] : 0.f;
+            }
+            if (O.accumulate) {
+              const f32x4 old = *reinterpret_cast<const f32x4*>(obase + off);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += old[e];
+            }
+            if (O.gate_sum) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (gt[e] > 0.f) ? v[e] : 0.f;
+            }
+          } else if (O.accumulate) {
+            const f32x4 old = *reinterpret_cast<const f32x4*>(obase + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += old[e];
+          }
+          *reinterpret_cast<f32x4*>(obase + off) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
+#pragma unroll
+    for (int ap = 0; ap < 2; ++ap) {  // output row inside the 2x2 tile
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int tl = 4 * g + rr;  // tile inside the wave
+        const int tile = 16 * wave + tl;
+        const int py = 2 * (tile / TXN) + ap, px0 = 2 * (tile % TXN);
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+          float tb[4];
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            tb[b] = (ap == 0) ? (acc[b][nh][rr] + acc[4 + b][nh][rr]) + acc[8 + b][nh][rr]
+                              : (acc[4 + b][nh][rr] - acc[8 + b][nh][rr]) - acc[12 + b][nh][rr];
+          float y[2] = {(tb[0] + tb[1]) + tb[2], (tb[1] - tb[2]) - tb[3]};
+#pragma unroll
+          for (int bp = 0; bp < 2; ++bp) {
+            float v = y[bp] + bj[nh];
+            if (O.relu) v = fmaxf(v, 0.f);
+            const bool ok = col_ok[nh] && (interior || ((ug.ty0 + py < d.H) && (ug.tx0 + px0 + bp < d.W)));
+            if (ok) {
+              s1[nh] += v;
+              s2[nh] = fmaf(v, v, s2[nh]);
+            }
+            if (vec_out) {
+              // XOR swizzle on the column half: the 4 k-slots of a store hit 2 bank groups instead of 1
+              scratch[(2 * tl + bp) * 32 + ((t16 + 16 * nh) ^ ((g & 1) << 4))] = v;
+            } else if (ok) {
+              const long off = tile_base4 + py * row_stride + (px0 + bp) * col_stride + t16 + 16 * nh;
+              if (O.gate != nullptr && !O.gate_sum) v = (O.gate[off] > 0.f) ? v : 0.f;
+              if (O.accumulate) v += O.ptr[off];
+              if (O.gate != nullptr && O.gate_sum) v = (O.gate[off] > 0.f) ? v : 0.f;
+              O.ptr[off] = v;
+            }
+          }
+        }
+      }
+      if (vec_out) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int pi = (lane >> 3) + 8 * pass, q4 = (lane & 7) << 2;  // pixel slot of the wave, first column
+          const int tl = pi >> 1, bp = pi & 1;
+          const int tile = 16 * wave + tl;
+          const int py = 2 * (tile / TXN) + ap, px = 2 * (tile % TXN) + bp;
+          f32x4 v = *reinterpret_cast<const f32x4*>(&scratch[pi * 32 + (q4 ^ (((tl >> 2) & 1) << 4))]);
+          if (q4 < tc.n_cnt && (interior || ((ug.ty0 + py < d.H) && (ug.tx0 + px < d.W)))) {
+            const long off = tile_base4 + py * row_stride + px * col_stride + q4;
+            f32x4 gt = {1.f, 1.f, 1.f, 1.f};
+            if (O.gate != nullptr) gt = *reinterpret_cast<const f32x4*>(O.gate + off);
+            if (O.gate != nullptr && !O.gate_sum) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (gt[e] > 0.f) ? v[e] : 0.f;
+            }
+            if (O.accumulate) {
+              const f32x4 old = *reinterpret_cast<const f32x4*>(O.ptr + off);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += old[e];
+            }
+            if (O.gate != nullptr && O.gate_sum) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (gt[e] > 0.f) ? v[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(O.ptr + off) = v;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    }  // general path
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) acc[xi][nh] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (want_stats) {  // the LDS tiles are free here (barrier after the MFMA loop)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        s1[nh] += __shfl_xor(s1[nh], 16);
+        s2[nh] += __shfl_xor(s2[nh], 16);
+        s1[nh] += __shfl_xor(s1[nh], 32);
+        s2[nh] += __shfl_xor(s2[nh], 32);
+        if (g == 0) {
+          w_tile[(wave * 32 + t16 + 16 * nh) * 2 + 0] = s1[nh];  // weight tile as scratch: the input tile may still
+          w_tile[(wave * 32 + t16 + 16 * nh) * 2 + 1] = s2[nh];  // be another wave's transpose scratch
+        }
+      }
+      __syncthreads();
+      if (tid < tc.n_cnt) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          t1 += w_tile[(w * 32 + tid) * 2 + 0];
+          t2 += w_tile[(w * 32 + tid) * 2 + 1];
+        }
+        float* dst = d.stats_partial + (ug.patch * a.Ncols + tc.n0 + tid) * 2;
+        dst[0] = t1;
+        dst[1] = t2;
+      }
+      __syncthreads();  // before the next chunk overwrites the scratch
+    }
+  };
+
+  prefetch_unit(0);
+  view_offsets(d.in[0]);
+  load_chunk();
+  issue_weights(w_a);
+  store_chunk();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  long c_unit = 0;  // compute side: unit and chunk currently in LDS
+  int c_chunk = 0;
+  // one K chunk: computes from (in_tile, w_tile) while the next chunk's patch (registers) and weight image (DMA into
+  // w_next) are in flight; returns false after the last chunk of the last unit
+  auto chunk_step = [&](const float* w_tile, float* w_next) -> bool {
+    // ---- advance the prefetch cursor: next chunk of this unit, or chunk 0 of the next unit ----
+    bool more = true;
+    {
+      int s2 = p_s, c2 = p_c0 + WKC;
+      if (c2 >= d.in[p_s].c_len) {
+        ++s2;
+        c2 = 0;
+      }
+      if (p_chunk + 1 < a.n_chunks) {
+        ++p_chunk;
+        if (s2 != p_s) {
+          p_s = s2;
+          view_offsets(d.in[p_s]);
+        }
+        p_c0 = c2;
+      } else if (p_unit + 1 < ur.count) {
+        ++p_unit;
+        p_chunk = 0;
+        p_s = 0;
+        p_c0 = 0;
+        prefetch_unit(p_unit);
+        view_offsets(d.in[0]);
+      } else {
+        more = false;
+      }
+    }
+    // Both loads are unconditional (the cursor stays on the last chunk when nothing is left): a conditional load sits
+    // under a branch and hipcc drains vmcnt at the join, which would expose the whole latency.
+    load_chunk();
+    issue_weights(w_next);
+    // ---- current chunk: 4x4 window (2 channels per lane) -> B^T d B in registers -> 64 MFMAs.  Per channel s the 16
+    // transformed values feed 32 MFMAs (every accumulator once: no back-to-back dependence); the weight fragments
+    // are read three MFMA pairs ahead of their use. ----
+    f32x2 dd[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dd[i][j] = *reinterpret_cast<const f32x2*>(&in_tile[a_base + (i * HWp + j) * WP]);
+    constexpr int AHEAD = 3;
+    f32x2 u[AHEAD + 1];
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q) u[q] = *reinterpret_cast<const f32x2*>(&w_tile[q * 128 + b_base]);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float t[4][4], V[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t[0][j] = dd[0][j][s] - dd[2][j][s];
+        t[1][j] = dd[1][j][s] + dd[2][j][s];
+        t[2][j] = dd[2][j][s] - dd[1][j][s];
+        t[3][j] = dd[1][j][s] - dd[3][j][s];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        V[4 * i + 0] = t[i][0] - t[i][2];
+        V[4 * i + 1] = t[i][1] + t[i][2];
+        V[4 * i + 2] = t[i][2] - t[i][1];
+        V[4 * i + 3] = t[i][1] - t[i][3];
+      }
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) {
+        const int step = s * 16 + xi;  // fragment index inside the image: [s][xi]
+        if (step + AHEAD < 32)
+          u[(step + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const f32x2*>(&w_tile[(step + AHEAD) * 128 + b_base]);
+        const f32x2 uc = u[step % (AHEAD + 1)];
+        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi], uc[0], acc[xi][0], 0, 0, 0);
+        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi], uc[1], acc[xi][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (c_chunk + 1 == a.n_chunks) {
+      epilogue(c_unit, const_cast<float*>(w_tile));  // stores drain while the next unit computes
+      __syncthreads();   // the epilogue used the input tile as transpose scratch
+      ++c_unit;
+      c_chunk = 0;
+    } else {
+      ++c_chunk;
+    }
+    if (!more) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may be in flight into LDS when the workgroup ends
+      return false;
+    }
+    store_chunk();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's DMA pieces have landed
+    __syncthreads();
+    return true;
+  };
+  while (true) {
+    if (!chunk_step(w_a, w_b)) break;
+    if (!chunk_step(w_b, w_a)) break;
+  }
+}
+
+}  // namespace
+
+bool wino_applies(const unetpp_gemm_desc* d) {
+  return d != nullptr && d->taps == 9 && (d->flags & UNETPP_GEMM_DIRECT) == 0;
+}
+
+long wino_image_floats(const unetpp_gemm_desc* d) {
+  FastArgs a;
+  if (!wino_applies(d) || !fast_args(d, a, WKC)) return 0;
+  return static_cast<long>(a.n_tiles) * a.n_chunks * WIMG;
+}
+
+int wino_pack_image(const unetpp_gemm_desc* d, float* image, hipStream_t st) {
+  FastArgs a;
+  if (!wino_applies(d) || !fast_args(d, a, WKC) || image == nullptr || d->weight == nullptr) return UNETPP_EINVAL;
+  const long total = static_cast<long>(a.n_tiles) * a.n_chunks * WIMG;
+  hipLaunchKernelGGL(pack_wino_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, a, image);
+  return launch_status();
+}
+
+int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
+  FastArgs a;
+  if (!wino_applies(d) || !fast_args(d, a, WKC) || d->weight_image == nullptr) return UNETPP_EINVAL;
+  if (d->stats_partial != nullptr && d->n_out != 1) return UNETPP_EINVAL;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return UNETPP_ELAUNCH;
+  long workers = (2L * cus) & ~7L;  // persistent grid: two workgroups per CU (= the kernel's launch bounds)
+  if (workers < 8) workers = 8;
+  const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(kThreads);
+  if (a.log2tw == 5) hipLaunchKernelGGL((gemm_wino_kernel<5>), grid, block, 0, st, a);
+  else if (a.log2tw == 4) hipLaunchKernelGGL((gemm_wino_kernel<4>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((gemm_wino_kernel<3>), grid, block, 0, st, a);
+  note_kernel("gemm_wino_kernel");
+  return launch_status();
+}
+
+}  // namespace unetpp

@@ -271,6 +271,7 @@ extern "C" int unetpp_wgrad(const unetpp_wgrad_desc* d, void* stream) {
     hipLaunchKernelGGL(wgrad_kernel<9>, grid, dim3(kThreads), 0, st, a);
   else
     hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(kThreads), 0, st, a);
+  note_kernel(d->taps == 9 ? "wgrad_kernel<9>" : "wgrad_kernel<1>");
   return launch_status();
 }
 

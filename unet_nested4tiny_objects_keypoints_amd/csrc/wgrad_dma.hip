@@ -269,6 +269,7 @@ int launch_wgrad_dma(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_tile
   if (d->taps == 9) UNETPP_LAUNCH_WDMA(9);
   else UNETPP_LAUNCH_WDMA(1);
 #undef UNETPP_LAUNCH_WDMA
+  note_kernel(d->taps == 9 ? "wgrad_dma_kernel<9>" : "wgrad_dma_kernel<1>");
   return launch_status();
 }
 

@@ -253,6 +253,7 @@ int launch_one(const WFastArgs& a, dim3 grid, hipStream_t st) {
                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
     return UNETPP_ELAUNCH;
   hipLaunchKernelGGL((wgrad_fast_kernel<TAPS, LOG2TW>), grid, dim3(kWThreads), lds, st, a);
+  note_kernel(TAPS == 9 ? "wgrad_fast_kernel<9>" : "wgrad_fast_kernel<1>");
   return launch_status();
 }
 

@@ -7,6 +7,7 @@ here is plumbing only: device memory and the stream.  Activations are NHWC ``[N,
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -75,12 +76,15 @@ class region:
 
 
 def _timed_call(kind, flops, fn):
+    """kind = label of the launch, or None to ask the library which kernel it picked (unetpp_last_kernel_name)."""
     if _TIMER is None:
         return fn()
     s, e = _TIMER._pair()
     s.record()
     r = fn()
     e.record()
+    if kind is None:
+        kind = _lib.lib().unetpp_last_kernel_name().decode()
     _TIMER.launches.append((kind, flops, s, e))
     return r
 
@@ -142,6 +146,7 @@ class V:
 
 
 USE_FAST_GEMM = True  # tests flip this to exercise the generic kernel on the same shapes
+USE_WINOGRAD = os.environ.get("UNETPP_NO_WINOGRAD") is None  # 3x3 fast path: Winograd F(2x2,3x3) unless disabled
 
 
 def gemm_pixel_blocks(n: int, h: int, w: int) -> int:
@@ -149,11 +154,14 @@ def gemm_pixel_blocks(n: int, h: int, w: int) -> int:
 
 
 def gemm_fwd(n: int, h: int, w: int, taps: int, ins: Sequence[V], outs: Sequence[V], weight: torch.Tensor,
-             bias: Optional[torch.Tensor] = None, stats_partial: Optional[torch.Tensor] = None) -> None:
+             bias: Optional[torch.Tensor] = None, stats_partial: Optional[torch.Tensor] = None,
+             direct: bool = False) -> None:
+    """direct=True forbids the Winograd form of the 3x3 fast path (bit-exact direct summation)."""
     if len(ins) > MAX_VIEWS or len(outs) > MAX_VIEWS:
         raise ValueError("too many views")
     d = GemmDesc()
     d.N, d.H, d.W, d.taps = n, h, w, taps
+    d.flags = _lib.GEMM_DIRECT if (direct or not USE_WINOGRAD) else 0
     d.n_in, d.n_out = len(ins), len(outs)
     k = sum(v.fill(d.inp[i]) for i, v in enumerate(ins))
     nc = sum(v.fill(d.out[i]) for i, v in enumerate(outs))
@@ -175,14 +183,7 @@ def gemm_fwd(n: int, h: int, w: int, taps: int, ins: Sequence[V], outs: Sequence
             image = torch.empty(n_img, dtype=torch.float32, device=weight.device)
             check(lib.unetpp_gemm_pack_weight_image(C.byref(d), _ptr(image), _stream()), "unetpp_gemm_pack_weight_image")
             d.weight_image = image.data_ptr()
-    # label = the device kernel that will run (matches the rocprofv3 kernel names up to template arguments)
-    if d.weight_image:
-        label = "gemm_fast_kernel<%d>" % taps
-    elif taps == 9 and len(ins) == 1 and ins[0].t.shape[3] <= 4:
-        label = "small_cin_fwd_kernel"
-    else:
-        label = "gemm_pix_kernel<%d>" % taps
-    _timed_call(label, 2.0 * n * h * w * taps * k * nc,
+    _timed_call(None, 2.0 * n * h * w * taps * k * nc,
                 lambda: check(_lib.lib().unetpp_gemm_fwd(C.byref(d), _stream()), "unetpp_gemm_fwd"))
 
 
@@ -209,8 +210,7 @@ def wgrad(n: int, h: int, w: int, taps: int, xs: Sequence[V], dys: Sequence[V], 
     slabs = torch.empty(split * (taps * k + 1) * nc, dtype=torch.float32, device=xs[0].t.device)
     d.n_split = split
     d.slabs = slabs.data_ptr()
-    small = taps == 9 and len(xs) == 1 and xs[0].t.shape[3] <= 4
-    _timed_call("small_cin_wgrad_kernel" if small else "wgrad_fast_kernel<%d>" % taps, 2.0 * n * h * w * taps * k * nc,
+    _timed_call(None, 2.0 * n * h * w * taps * k * nc,
                 lambda: check(lib.unetpp_wgrad(C.byref(d), _stream()), "unetpp_wgrad"))
     if n_inner is None:
         n_inner = nc
