@@ -38,10 +38,12 @@ struct TileCols {
   int n0, n_cnt;  // first GEMM column, valid columns
 };
 
+template <int LOG2N = 5>
 __device__ __forceinline__ TileCols decode_tile(const FastArgs& a, int nt_global) {
+  constexpr int NW = 1 << LOG2N;
   int nt = nt_global, ov = 0, col_base = 0;
   while (ov < a.d.n_out - 1) {
-    const int tiles_v = (a.d.out[ov].c_len + 31) >> 5;
+    const int tiles_v = (a.d.out[ov].c_len + NW - 1) >> LOG2N;
     if (nt < tiles_v) break;
     nt -= tiles_v;
     col_base += a.d.out[ov].c_len;
@@ -50,8 +52,8 @@ __device__ __forceinline__ TileCols decode_tile(const FastArgs& a, int nt_global
   TileCols t;
   t.nt = nt;
   t.ov = ov;
-  t.n0 = col_base + nt * 32;
-  t.n_cnt = min(32, a.d.out[ov].c_len - nt * 32);
+  t.n0 = col_base + nt * NW;
+  t.n_cnt = min(NW, a.d.out[ov].c_len - nt * NW);
   return t;
 }
 
@@ -72,8 +74,9 @@ __device__ __forceinline__ UnitGeom decode_unit(const FastArgs& a, long lb) {
   return g;
 }
 
-// Host side: validates a descriptor for the fast kernels and fills the unit geometry; kc = channels per K chunk.
-inline bool fast_args(const unetpp_gemm_desc* d, FastArgs& a, int kc) {
+// Host side: validates a descriptor for the fast kernels and fills the unit geometry; kc = channels per K chunk,
+// ncol = columns per tile.
+inline bool fast_args(const unetpp_gemm_desc* d, FastArgs& a, int kc, int ncol = 32) {
   if (d == nullptr || d->N <= 0 || d->H <= 0 || d->W <= 0) return false;
   if (d->taps != 9 && d->taps != 1) return false;
   if (d->n_in < 1 || d->n_in > UNETPP_MAX_VIEWS || d->n_out < 1 || d->n_out > UNETPP_MAX_VIEWS) return false;
@@ -94,7 +97,7 @@ inline bool fast_args(const unetpp_gemm_desc* d, FastArgs& a, int kc) {
     if (!view_ok(d->out[i]) || !view_covers(d->out[i], d->H, d->W)) return false;
     if (static_cast<long>(d->N) * d->out[i].Hs * d->out[i].Ws * d->out[i].C >= 0x7fffffffL) return false;
     a.Ncols += d->out[i].c_len;
-    a.n_tiles += (d->out[i].c_len + 31) / 32;
+    a.n_tiles += (d->out[i].c_len + ncol - 1) / ncol;
   }
   const TileGeom g = tile_geom(d->H, d->W);
   a.log2tw = g.log2tw;

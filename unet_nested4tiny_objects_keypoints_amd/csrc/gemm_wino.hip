@@ -7,18 +7,20 @@
 //
 // Mapping onto v_mfma_f32_16x16x4_f32 (exact fp32, same FLOP rate as 32x32x2):
 //   * unit of work = 256-pixel patch (64 tiles of 2x2) x 32 columns, 4 waves; a wave owns 16 tiles;
-//   * MFMA row = tile, MFMA k = 4 channels, MFMA column = output column: for each of the 16 transform positions xi
-//     one accumulator pair (2 x 16 columns): acc[16][2] float4 = 128 VGPRs per lane;
-//   * A operand: lane (tile t, k-slot g) reads its 4x4 window for channels 2g, 2g+1 as 16 ds_read_b64, runs the input
-//     transform B^T d B IN REGISTERS (32 add/sub per channel) and feeds the 16 results straight to the MFMAs -- the
+//   * MFMA row = tile, MFMA k = 4 channels, MFMA column = output column: per transform position xi one accumulator
+//     pair (2 x 16 columns), acc[16][2] float4 = 128 VGPRs per lane.  (16 columns per unit halve that, but the input
+//     transform and the epilogue then cost twice the VALU per MFMA, and VALU issue is what bounds this kernel.)
+//   * A operand: lane (tile t, k-slot g) reads its 4x4 window one channel at a time (16 ds_read_b32), runs the input
+//     transform B^T d B IN REGISTERS (32 add/sub per channel) and feeds the 16 results straight to 32 MFMAs -- the
 //     transformed input never exists in memory;
 //   * B operand: the transformed weights U = G g G^T are precomputed per launch (pack_wino_kernel) as an LDS image
-//     [xi][k-slot][col][column half][channel] -- one conflict-free ds_read_b128 per xi feeds 4 MFMAs;
+//     whose lane-linear 8-byte reads each feed two MFMAs;
 //   * all 16 xi of a (tile, column) land in the same lane and register index, so the output transform A^T M A is
-//     lane-local (24 add/sub per 2x2 tile); bias/ReLU/gate/accumulate/BatchNorm partial sums and the 16-byte
-//     transposed stores then follow the direct kernel's epilogue.
-//   * K in chunks of 8 channels, staged global -> registers -> LDS one chunk ahead (same persistent, flattened
-//     (unit, chunk) stream as gemm_fast.hip); 32 KB LDS and <= 256 VGPRs: two workgroups per CU.
+//     lane-local (24 add/sub per 2x2 tile); bias/ReLU/gate/accumulate/BatchNorm partial sums and 16-byte transposed
+//     stores follow as in the direct kernel;
+//   * K in chunks of 8 channels, staged global -> registers -> LDS one chunk ahead in a persistent, flattened
+//     (unit, chunk) stream; a workgroup walks a CONTIGUOUS run of units (column tile fastest), so the patch geometry
+//     (offsets, bounds mask) is only recomputed when the pixel patch changes; 30 KB LDS, two workgroups per CU.
 #include "common.h"
 #include "gemm_units.h"
 
@@ -28,8 +30,8 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int WKC = 8;      // channels per K chunk
-constexpr int WP = 10;      // LDS pixel stride of the input patch (floats): 8 channels + 2 pad -- the b64 window reads
-                            // of the 16 tiles x 2 k-slots of a half wave (stride 20 floats + 2) hit 64 distinct banks
+constexpr int WNC = 32;     // columns per unit
+constexpr int WP = 10;      // LDS pixel stride of the input patch (floats): 8 channels + 2 pad
 constexpr int WIMG = 4096;  // floats of one (column tile, chunk) weight image
 
 // image of one (column tile, chunk): [s 2][xi 16][g 4][col 16][nh 2],
@@ -53,12 +55,12 @@ __global__ void pack_wino_kernel(const FastArgs a, float* __restrict__ img) {
   const bool k_ok = kin < a.d.in[v].c_len;
   int col_base = 0, ov = 0;
   for (; ov < a.d.n_out; ++ov) {
-    const int tv = (a.d.out[ov].c_len + 31) >> 5;
+    const int tv = (a.d.out[ov].c_len + WNC - 1) / WNC;
     if (nt < tv) break;
     nt -= tv;
     col_base += a.d.out[ov].c_len;
   }
-  const int cin = nt * 32 + 16 * nh + col;
+  const int cin = nt * WNC + 16 * nh + col;
   const bool n_ok = cin < a.d.out[ov].c_len;
   float u = 0.f;
   if (k_ok && n_ok) {
@@ -82,29 +84,43 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;
   constexpr int HWp = TW + 2, HHp = TH + 2;
   constexpr int NPIX = HWp * HHp;
-  constexpr int TXN = TW / 2;        // 2x2 tiles per patch row
-  constexpr int IN_FLOATS = 4096;    // >= kMaxHaloPixels * WP (4080); also the 4 x 4 KB transpose scratch of the epilogue
+  constexpr int TXN = TW / 2;        // 2x2 tiles per patch row (a power of two)
+  constexpr int IN_FLOATS = 4096;    // >= kMaxHaloPixels * WP (3400); also the 4 x 4 KB transpose scratch of the epilogue
   constexpr int IN_ITEMS = (NPIX * 2 + kThreads - 1) / kThreads;  // 16-byte items, 2 per pixel (<= 3)
-  constexpr int W_ITEMS = WIMG / 4 / kThreads;                    // 16-byte DMA pieces per thread: 4
+  constexpr int W_ITEMS = WIMG / 4 / kThreads;                    // 4
   static_assert(kMaxHaloPixels * WP <= IN_FLOATS, "input patch does not fit");
-  // The weight images go HBM/L2 -> LDS by DMA (global_load_lds, no staging registers: the accumulators leave none),
-  // double buffered.  The two buffers are DISTINCT static arrays and the chunk loop is unrolled by two: with one
-  // array and a runtime index hipcc must assume that the DMA in flight aliases the ds_reads of the buffer being
-  // computed and drains vmcnt before each of them.
-  __shared__ __attribute__((aligned(16))) float in_tile[IN_FLOATS];
-  __shared__ __attribute__((aligned(16))) float w_a[WIMG];
-  __shared__ __attribute__((aligned(16))) float w_b[WIMG];
+  __shared__ __attribute__((aligned(16))) float smem[IN_FLOATS + WIMG];
+  float* in_tile = smem;
+  float* w_tile = smem + IN_FLOATS;
 
   const unetpp_gemm_desc& d = a.d;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, t16 = lane & 15, g = lane >> 4;
 
-  const UnitRange ur = my_unit_range(a.total_blocks);
+  // this workgroup's units: XCD x = blockIdx & 7 owns a contiguous range of units and each of its workgroups a
+  // CONTIGUOUS piece of it (unit order: column tile fastest), so successive units mostly share the pixel patch
+  UnitRange ur;
+  {
+    const long W8 = gridDim.x >> 3;
+    if (gridDim.x >= a.total_blocks) {
+      ur.first = xcd_remap(blockIdx.x, a.total_blocks);
+      ur.count = 1;
+    } else {
+      const long q = a.total_blocks >> 3, r = a.total_blocks & 7;
+      const long xcd = blockIdx.x & 7, widx = blockIdx.x >> 3;
+      const long start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+      const long cnt = q + (xcd < r ? 1 : 0);
+      const long per = cnt / W8, rem = cnt % W8;
+      ur.first = start + widx * per + (widx < rem ? widx : rem);
+      ur.count = per + (widx < rem ? 1 : 0);
+    }
+    ur.step = 1;
+  }
   if (ur.count == 0) return;
 
   // compute side: this lane's tile (A operand / input transform) and weight-image slot (B operand)
   const int my_tile = 16 * wave + t16;
-  const int a_base = ((2 * (my_tile / TXN)) * HWp + 2 * (my_tile % TXN)) * WP + 2 * g;
+  const int a_base = ((2 * (my_tile / TXN)) * HWp + 2 * (my_tile % TXN)) * WP + 2 * g;  // channel 2g (+s)
   const int b_base = (g * 16 + t16) * 2;
 
   f32x4 acc[16][2];
@@ -114,7 +130,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     for (int nh = 0; nh < 2; ++nh) acc[xi][nh] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- prefetch side (same scheme as gemm_fast.hip): the chunk that is loaded next ----
-  f32x4 reg_in[IN_ITEMS];
+  f32x4 reg_in[IN_ITEMS], reg_w[W_ITEMS];
   unsigned voff[IN_ITEMS];
   unsigned in_mask = 0;
   int pf_cnt = 0;
@@ -124,12 +140,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   const float* p_wimg = nullptr;
   const int cc = (tid & 1) << 2;  // channel quad of every staging item of this thread (kThreads is even)
 
-  auto prefetch_unit = [&](long k) {
-    const UnitGeom ug = decode_unit<LOG2TW>(a, ur.first + k * ur.step);
+  long p_patch = -1;
+  auto prefetch_unit = [&](long k) -> bool {  // returns true when the pixel patch is the previous unit's
+    const UnitGeom ug = decode_unit<LOG2TW>(a, ur.first + k);
+    p_wimg = d.weight_image + static_cast<long>(ug.group) * a.n_chunks * WIMG;
+    if (ug.patch == p_patch) return true;
+    p_patch = ug.patch;
     p_n = ug.n;
     p_ty0 = ug.ty0;
     p_tx0 = ug.tx0;
-    p_wimg = d.weight_image + static_cast<long>(ug.group) * a.n_chunks * WIMG;
     in_mask = 0;
 #pragma unroll
     for (int q = 0; q < IN_ITEMS; ++q) {
@@ -139,6 +158,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       const int y = p_ty0 + hy - 1, x = p_tx0 + hx - 1;
       if ((it < NPIX * 2) && y >= 0 && y < d.H && x >= 0 && x < d.W) in_mask |= 1u << q;
     }
+    return false;
   };
   auto view_offsets = [&](const unetpp_view& V) {  // clamped: every item loads from a valid address
 #pragma unroll
@@ -149,6 +169,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       voff[q] = view_pixel_offset32(V, p_n, yy, xx);
     }
   };
+  // Unconditional, straight-line loads (the cursor stays on the last chunk when nothing is left): a conditional load
+  // sits under a branch and hipcc drains vmcnt at the join, which would expose the whole latency.
   auto load_chunk = [&]() {
     const unetpp_view& V = d.in[p_s];
     pf_cnt = min(WKC, V.c_len - p_c0);
@@ -157,15 +179,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       const unsigned off = voff[q] + static_cast<unsigned>(p_c0 + (cc < pf_cnt ? cc : 0));
       reg_in[q] = *reinterpret_cast<const f32x4*>(V.ptr + off);
     }
-  };
-  typedef const __attribute__((address_space(1))) void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  auto issue_weights = [&](float* buf) {  // image of the prefetch cursor's chunk -> buf (lane-linear 1 KB pieces)
     const float* wp = p_wimg + static_cast<long>(p_chunk) * WIMG;
 #pragma unroll
-    for (int q = 0; q < W_ITEMS; ++q)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wp + (q * kThreads + tid) * 4), (lptr_t)(buf + (q * kThreads + wave * 64) * 4),
-                                       16, 0, 0);
+    for (int q = 0; q < W_ITEMS; ++q) reg_w[q] = *reinterpret_cast<const f32x4*>(wp + (tid + q * kThreads) * 4);
   };
   auto store_chunk = [&]() {
     const unetpp_view& V = d.in[p_s];
@@ -176,6 +192,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       sc = *reinterpret_cast<const f32x4*>(V.scale + ch);
       sh = *reinterpret_cast<const f32x4*>(V.shift + ch);
     }
+    const float floor_v = V.relu ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int q = 0; q < IN_ITEMS; ++q) {
       const int it = tid + q * kThreads;
@@ -185,53 +202,48 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
       }
-      if (V.relu) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0.f;  // zero padding is applied after the transform
+      for (int e = 0; e < 4; ++e) v[e] = keep ? fmaxf(v[e], floor_v) : 0.f;  // zero padding AFTER the transform
       if (it < NPIX * 2) {  // 40-byte pixel rows: two 8-byte stores
         *reinterpret_cast<f32x2*>(&in_tile[(it >> 1) * WP + cc]) = f32x2{v[0], v[1]};
         *reinterpret_cast<f32x2*>(&in_tile[(it >> 1) * WP + cc + 2]) = f32x2{v[2], v[3]};
       }
     }
+#pragma unroll
+    for (int q = 0; q < W_ITEMS; ++q) *reinterpret_cast<f32x4*>(&w_tile[(tid + q * kThreads) * 4]) = reg_w[q];
   };
 
   // ---- epilogue of a finished unit: output transform, bias / ReLU / gate / accumulate, BatchNorm partial sums ----
   // Register rr of acc[xi][nh] of lane (t16, g) belongs to tile 16*wave + 4*g + rr and column t16 + 16*nh.
-  auto epilogue = [&](long k, float* w_tile) {  // w_tile: the weight buffer just computed from (free: stats scratch)
-    const UnitGeom ug = decode_unit<LOG2TW>(a, ur.first + k * ur.step);
+  auto epilogue = [&](long k) {
+    const UnitGeom ug = decode_unit<LOG2TW>(a, ur.first + k);
     const TileCols tc = decode_tile(a, ug.group);
     const unetpp_view& O = d.out[tc.ov];
     const bool interior = (ug.ty0 + TH <= d.H) && (ug.tx0 + TW <= d.W);
-    bool col_ok[2];
-    float bj[2], s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-#pragma unroll
-    for (int nh = 0; nh < 2; ++nh) {
-      col_ok[nh] = t16 + 16 * nh < tc.n_cnt;
-      bj[nh] = (d.bias != nullptr && col_ok[nh]) ? d.bias[tc.n0 + t16 + 16 * nh] : 0.f;
-    }
-    const long row_stride = static_cast<long>(O.sy) * O.Ws * O.C, col_stride = static_cast<long>(O.sx) * O.C;
-    const long tile_base4 = view_pixel_offset(O, ug.n, ug.ty0, ug.tx0) + tc.nt * 32;  // column 0 of the tile
+    const unsigned rs = static_cast<unsigned>(O.sy) * O.Ws * O.C, cs = static_cast<unsigned>(O.sx) * O.C;
+    const unsigned tile_base = view_pixel_offset32(O, ug.n, ug.ty0, ug.tx0) + tc.nt * WNC;  // column 0 of the tile
+    float* obase = O.ptr + tile_base;
+    const float* gbase = O.gate != nullptr ? O.gate + tile_base : nullptr;
     const bool vec_out = ((O.C | O.c_off | tc.n_cnt) & 3) == 0 && (reinterpret_cast<uintptr_t>(O.ptr) & 15) == 0 &&
                          (O.gate == nullptr || (reinterpret_cast<uintptr_t>(O.gate) & 15) == 0);
-    float* scratch = in_tile + wave * 1024;  // [32 pixels][32 columns]; in_tile is free between the barriers
     const bool want_stats = d.stats_partial != nullptr;
-    if (interior && vec_out && tc.n_cnt == 32) {
-      // ---- lean path (whole patch inside the image, all 32 columns, 16-byte stores): no per-element predicates,
-      // 32-bit offsets from one scalar base, bias folded into M[1][1] (its weight is +1 in all four outputs) ----
+    const float floor_v = O.relu ? 0.f : -__builtin_inff();
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    // bias folded into M[1][1]: its weight is +1 in all four outputs
 #pragma unroll
-      for (int nh = 0; nh < 2; ++nh)
+    for (int nh = 0; nh < 2; ++nh) {
+      const float bj = (d.bias != nullptr && t16 + 16 * nh < tc.n_cnt) ? d.bias[tc.n0 + t16 + 16 * nh] : 0.f;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) acc[5][nh][rr] += bj[nh];
-      const float floor_v = O.relu ? 0.f : -__builtin_inff();
-      float* obase = O.ptr + tile_base4;
-      const float* gbase = O.gate != nullptr ? O.gate + tile_base4 : nullptr;
-      const unsigned rs = static_cast<unsigned>(row_stride), cs = static_cast<unsigned>(col_stride);
-      const int sw_col0 = t16 ^ ((g & 1) << 4);
+      for (int rr = 0; rr < 4; ++rr) acc[5][nh][rr] += bj;
+    }
+    if (interior && vec_out && tc.n_cnt == WNC) {
+      // ---- lean path (whole patch inside the image, all 32 columns, 16-byte stores): no per-element predicates.
+      // Transpose scratch per wave: [pixel slot (rr, bp, g)][32 columns], column half XOR (g>>1): the 64 lanes of a
+      // store hit 64 distinct banks. ----
+      float* scratch = in_tile + wave * 1024;  // in_tile is free between the barriers
+      const int sw_lane = g * 32 + (t16 ^ ((g >> 1) << 4));
 #pragma unroll
-      for (int ap = 0; ap < 2; ++ap) {
+      for (int ap = 0; ap < 2; ++ap) {  // output row inside the 2x2 tile
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
@@ -246,19 +258,19 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
               s1[nh] += y0 + y1;
               s2[nh] = fmaf(y0, y0, fmaf(y1, y1, s2[nh]));
             }
-            scratch[(2 * (4 * g + rr)) * 32 + (sw_col0 ^ (nh << 4))] = y0;
-            scratch[(2 * (4 * g + rr) + 1) * 32 + (sw_col0 ^ (nh << 4))] = y1;
+            scratch[(rr * 2 + 0) * 128 + (sw_lane ^ (nh << 4))] = y0;
+            scratch[(rr * 2 + 1) * 128 + (sw_lane ^ (nh << 4))] = y1;
           }
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
-          const int pi = (lane >> 3) + 8 * pass, q4 = (lane & 7) << 2;
-          const int tl = pi >> 1;
-          const int tile = 16 * wave + tl;
-          const unsigned py = 2 * (tile / TXN) + ap, px = 2 * (tile % TXN) + (pi & 1);
+          const int ps = (lane >> 3) + 8 * pass, q4 = (lane & 7) << 2;  // pixel slot (rr, bp, g), first column
+          const int gg = ps & 3;
+          const int tile = 16 * wave + 4 * gg + (ps >> 3);
+          const unsigned py = 2 * (tile / TXN) + ap, px = 2 * (tile % TXN) + ((ps >> 2) & 1);
           const unsigned off = py * rs + px * cs + q4;
-          f32x4 v = *reinterpret_cast<const f32x4*>(&scratch[pi * 32 + (q4 ^ (((tl >> 2) & 1) << 4))]);
+          f32x4 v = *reinterpret_cast<const f32x4*>(&scratch[ps * 32 + (q4 ^ ((gg >> 1) << 4))]);
           if (gbase != nullptr) {
             const f32x4 gt = *reinterpret_cast<const f32x4*>(gbase + off);
             if (!O.gate_sum) {
@@ -284,76 +296,38 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
         __builtin_amdgcn_wave_barrier();
       }
     } else {
+      // ---- general path (ragged patches, partial or unaligned column tiles): one predicated dword per value ----
 #pragma unroll
-    for (int ap = 0; ap < 2; ++ap) {  // output row inside the 2x2 tile
+      for (int ap = 0; ap < 2; ++ap) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int tl = 4 * g + rr;  // tile inside the wave
-        const int tile = 16 * wave + tl;
-        const int py = 2 * (tile / TXN) + ap, px0 = 2 * (tile % TXN);
+        for (int rr = 0; rr < 4; ++rr) {
+          const int tile = 16 * wave + 4 * g + rr;
+          const int py = 2 * (tile / TXN) + ap, px0 = 2 * (tile % TXN);
 #pragma unroll
-        for (int nh = 0; nh < 2; ++nh) {
-          float tb[4];
+          for (int nh = 0; nh < 2; ++nh) {
+            float tb[4];
 #pragma unroll
-          for (int b = 0; b < 4; ++b)
-            tb[b] = (ap == 0) ? (acc[b][nh][rr] + acc[4 + b][nh][rr]) + acc[8 + b][nh][rr]
-                              : (acc[4 + b][nh][rr] - acc[8 + b][nh][rr]) - acc[12 + b][nh][rr];
-          float y[2] = {(tb[0] + tb[1]) + tb[2], (tb[1] - tb[2]) - tb[3]};
+            for (int b = 0; b < 4; ++b)
+              tb[b] = (ap == 0) ? (acc[b][nh][rr] + acc[4 + b][nh][rr]) + acc[8 + b][nh][rr]
+                                : (acc[4 + b][nh][rr] - acc[8 + b][nh][rr]) - acc[12 + b][nh][rr];
+            const float y[2] = {fmaxf((tb[0] + tb[1]) + tb[2], floor_v), fmaxf((tb[1] - tb[2]) - tb[3], floor_v)};
 #pragma unroll
-          for (int bp = 0; bp < 2; ++bp) {
-            float v = y[bp] + bj[nh];
-            if (O.relu) v = fmaxf(v, 0.f);
-            const bool ok = col_ok[nh] && (interior || ((ug.ty0 + py < d.H) && (ug.tx0 + px0 + bp < d.W)));
-            if (ok) {
-              s1[nh] += v;
-              s2[nh] = fmaf(v, v, s2[nh]);
-            }
-            if (vec_out) {
-              // XOR swizzle on the column half: the 4 k-slots of a store hit 2 bank groups instead of 1
-              scratch[(2 * tl + bp) * 32 + ((t16 + 16 * nh) ^ ((g & 1) << 4))] = v;
-            } else if (ok) {
-              const long off = tile_base4 + py * row_stride + (px0 + bp) * col_stride + t16 + 16 * nh;
-              if (O.gate != nullptr && !O.gate_sum) v = (O.gate[off] > 0.f) ? v : 0.f;
-              if (O.accumulate) v += O.ptr[off];
-              if (O.gate != nullptr && O.gate_sum) v = (O.gate[off] > 0.f) ? v : 0.f;
-              O.ptr[off] = v;
+            for (int bp = 0; bp < 2; ++bp) {
+              float v = y[bp];
+              if ((t16 + 16 * nh < tc.n_cnt) && (ug.ty0 + py < d.H) && (ug.tx0 + px0 + bp < d.W)) {
+                s1[nh] += v;
+                s2[nh] = fmaf(v, v, s2[nh]);
+                const unsigned off = py * rs + (px0 + bp) * cs + t16 + 16 * nh;
+                if (gbase != nullptr && !O.gate_sum) v = (gbase[off] > 0.f) ? v : 0.f;
+                if (O.accumulate) v += obase[off];
+                if (gbase != nullptr && O.gate_sum) v = (gbase[off] > 0.f) ? v : 0.f;
+                obase[off] = v;
+              }
             }
           }
         }
-      }
-      if (vec_out) {
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-          const int pi = (lane >> 3) + 8 * pass, q4 = (lane & 7) << 2;  // pixel slot of the wave, first column
-          const int tl = pi >> 1, bp = pi & 1;
-          const int tile = 16 * wave + tl;
-          const int py = 2 * (tile / TXN) + ap, px = 2 * (tile % TXN) + bp;
-          f32x4 v = *reinterpret_cast<const f32x4*>(&scratch[pi * 32 + (q4 ^ (((tl >> 2) & 1) << 4))]);
-          if (q4 < tc.n_cnt && (interior || ((ug.ty0 + py < d.H) && (ug.tx0 + px < d.W)))) {
-            const long off = tile_base4 + py * row_stride + px * col_stride + q4;
-            f32x4 gt = {1.f, 1.f, 1.f, 1.f};
-            if (O.gate != nullptr) gt = *reinterpret_cast<const f32x4*>(O.gate + off);
-            if (O.gate != nullptr && !O.gate_sum) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = (gt[e] > 0.f) ? v[e] : 0.f;
-            }
-            if (O.accumulate) {
-              const f32x4 old = *reinterpret_cast<const f32x4*>(O.ptr + off);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += old[e];
-            }
-            if (O.gate != nullptr && O.gate_sum) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = (gt[e] > 0.f) ? v[e] : 0.f;
-            }
-            *reinterpret_cast<f32x4*>(O.ptr + off) = v;
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
       }
     }
-    }  // general path
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
@@ -389,16 +363,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   prefetch_unit(0);
   view_offsets(d.in[0]);
   load_chunk();
-  issue_weights(w_a);
   store_chunk();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   long c_unit = 0;  // compute side: unit and chunk currently in LDS
   int c_chunk = 0;
-  // one K chunk: computes from (in_tile, w_tile) while the next chunk's patch (registers) and weight image (DMA into
-  // w_next) are in flight; returns false after the last chunk of the last unit
-  auto chunk_step = [&](const float* w_tile, float* w_next) -> bool {
+  while (true) {
     // ---- advance the prefetch cursor: next chunk of this unit, or chunk 0 of the next unit ----
     bool more = true;
     {
@@ -417,39 +387,35 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       } else if (p_unit + 1 < ur.count) {
         ++p_unit;
         p_chunk = 0;
+        const bool same_view = p_s == 0;
         p_s = 0;
         p_c0 = 0;
-        prefetch_unit(p_unit);
-        view_offsets(d.in[0]);
+        if (!prefetch_unit(p_unit) || !same_view) view_offsets(d.in[0]);  // same patch and view: offsets still valid
       } else {
         more = false;
       }
     }
-    // Both loads are unconditional (the cursor stays on the last chunk when nothing is left): a conditional load sits
-    // under a branch and hipcc drains vmcnt at the join, which would expose the whole latency.
     load_chunk();
-    issue_weights(w_next);
-    // ---- current chunk: 4x4 window (2 channels per lane) -> B^T d B in registers -> 64 MFMAs.  Per channel s the 16
-    // transformed values feed 32 MFMAs (every accumulator once: no back-to-back dependence); the weight fragments
-    // are read three MFMA pairs ahead of their use. ----
-    f32x2 dd[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) dd[i][j] = *reinterpret_cast<const f32x2*>(&in_tile[a_base + (i * HWp + j) * WP]);
-    constexpr int AHEAD = 3;
+
+    // ---- current chunk: per channel s the 4x4 window -> B^T d B in registers -> 32 MFMAs; every accumulator is
+    // touched once per channel (no back-to-back dependence), the weight fragments are read AHEAD pairs early ----
+    constexpr int AHEAD = 2;
     f32x2 u[AHEAD + 1];
 #pragma unroll
     for (int q = 0; q < AHEAD; ++q) u[q] = *reinterpret_cast<const f32x2*>(&w_tile[q * 128 + b_base]);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      float t[4][4], V[16];
+      float dd[4][4], t[4][4], V[16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dd[i][j] = in_tile[a_base + (i * HWp + j) * WP + s];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        t[0][j] = dd[0][j][s] - dd[2][j][s];
-        t[1][j] = dd[1][j][s] + dd[2][j][s];
-        t[2][j] = dd[2][j][s] - dd[1][j][s];
-        t[3][j] = dd[1][j][s] - dd[3][j][s];
+        t[0][j] = dd[0][j] - dd[2][j];
+        t[1][j] = dd[1][j] + dd[2][j];
+        t[2][j] = dd[2][j] - dd[1][j];
+        t[3][j] = dd[1][j] - dd[3][j];
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -470,25 +436,16 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     }
     __syncthreads();
     if (c_chunk + 1 == a.n_chunks) {
-      epilogue(c_unit, const_cast<float*>(w_tile));  // stores drain while the next unit computes
+      epilogue(c_unit);  // stores drain while the next unit computes; the next chunk's loads are already in flight
       __syncthreads();   // the epilogue used the input tile as transpose scratch
       ++c_unit;
       c_chunk = 0;
     } else {
       ++c_chunk;
     }
-    if (!more) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may be in flight into LDS when the workgroup ends
-      return false;
-    }
+    if (!more) break;
     store_chunk();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's DMA pieces have landed
     __syncthreads();
-    return true;
-  };
-  while (true) {
-    if (!chunk_step(w_a, w_b)) break;
-    if (!chunk_step(w_b, w_a)) break;
   }
 }
 
@@ -500,13 +457,13 @@ bool wino_applies(const unetpp_gemm_desc* d) {
 
 long wino_image_floats(const unetpp_gemm_desc* d) {
   FastArgs a;
-  if (!wino_applies(d) || !fast_args(d, a, WKC)) return 0;
+  if (!wino_applies(d) || !fast_args(d, a, WKC, WNC)) return 0;
   return static_cast<long>(a.n_tiles) * a.n_chunks * WIMG;
 }
 
 int wino_pack_image(const unetpp_gemm_desc* d, float* image, hipStream_t st) {
   FastArgs a;
-  if (!wino_applies(d) || !fast_args(d, a, WKC) || image == nullptr || d->weight == nullptr) return UNETPP_EINVAL;
+  if (!wino_applies(d) || !fast_args(d, a, WKC, WNC) || image == nullptr || d->weight == nullptr) return UNETPP_EINVAL;
   const long total = static_cast<long>(a.n_tiles) * a.n_chunks * WIMG;
   hipLaunchKernelGGL(pack_wino_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, a, image);
   return launch_status();
@@ -514,7 +471,7 @@ int wino_pack_image(const unetpp_gemm_desc* d, float* image, hipStream_t st) {
 
 int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
   FastArgs a;
-  if (!wino_applies(d) || !fast_args(d, a, WKC) || d->weight_image == nullptr) return UNETPP_EINVAL;
+  if (!wino_applies(d) || !fast_args(d, a, WKC, WNC) || d->weight_image == nullptr) return UNETPP_EINVAL;
   if (d->stats_partial != nullptr && d->n_out != 1) return UNETPP_EINVAL;
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
