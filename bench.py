@@ -251,6 +251,12 @@ def main():
                     "launches_per_step": dom[1]["launches"] / args.steps,
                     "avg_launch_ms": round(dom[1]["ms"] / dom[1]["launches"], 4),
                     "flop_per_launch_avg": dom[1]["flops"] / dom[1]["launches"]}
+        if dom[0].startswith("gemm_wino"):
+            # `achieved` counts ALGORITHMIC FLOPs (2*9*Cin*Cout per pixel).  The Winograd F(2x2,3x3) kernel
+            # executes 16/36 of those multiply-adds on the MFMA pipe, so the pipe itself runs at achieved/2.25.
+            roofline["algorithm"] = "winograd F(2x2,3x3), fp32: 16 MFMA multiply-adds per 36 algorithmic ones"
+            roofline["mfma_executed_tflops"] = round(ach / 2.25, 2)
+            roofline["mfma_pipe_frac"] = round(ach / 2.25 / PEAK_F32_MFMA_TFLOPS, 4)
         if "X00.fwd" in regions and args.size == 256 and fs == 1 and args.in_channels == 1:
             t_img_us = 1e3 * regions["X00.fwd"]["ms"] / regions["X00.fwd"]["count"] / args.batch
             floor_c = X00_GFLOP_PER_IMG * 1e9 / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e6
