@@ -93,7 +93,8 @@ typedef struct unetpp_wgrad_desc {
   unetpp_view x[UNETPP_MAX_VIEWS];  /* K = sum c_len */
   unetpp_view dy[UNETPP_MAX_VIEWS]; /* Ncols = sum c_len (several views: the 4 pixel phases of a 2x2 deconv) */
   int32_t n_split;                  /* partial slabs (<= unetpp_wgrad_max_split) */
-  float* slabs;                    /* [n_split][taps*K + 1][Ncols]; row taps*K holds db */
+  int32_t flags;                    /* UNETPP_GEMM_DIRECT: direct summation only (no Winograd) */
+  float* slabs;                    /* [n_split][planes*K + 1][Ncols], planes = unetpp_wgrad_slab_planes(); last row = db */
 } unetpp_wgrad_desc;
 
 int unetpp_abi_version(void);
@@ -115,8 +116,12 @@ int64_t unetpp_gemm_weight_image_floats(const unetpp_gemm_desc* d);
 int unetpp_gemm_pack_weight_image(const unetpp_gemm_desc* d, float* image, void* stream);
 
 int32_t unetpp_wgrad_max_split(int32_t N, int32_t H, int32_t W);
+/* Planes per slab the kernel chosen for this descriptor writes: `taps` for direct summation, 16 for the Winograd
+ * F(2x2,3x3) kernel (3x3, plain 16-byte aligned views, images at least 17 wide, no UNETPP_GEMM_DIRECT in flags): it
+ * accumulates transform-domain products and unetpp_wgrad_finish(taps = 16) maps them back to the 9 taps. */
+int32_t unetpp_wgrad_slab_planes(const unetpp_wgrad_desc* d);
 int unetpp_wgrad(const unetpp_wgrad_desc* d, void* stream);
-/* column n = o*n_inner + i:  dw[t*d_t + k*d_k + i*d_n + o*d_o] = sum_s slabs[s][t*K + k][n];
+/* `taps` = planes per slab.  column n = o*n_inner + i:  dw[t*d_t + k*d_k + i*d_n + o*d_o] = sum_s slabs[s][t*K + k][n];
  * db[i] = sum_o sum_s slabs[s][taps*K][o*n_inner + i]   (n_inner = Ncols for a plain convolution) */
 int unetpp_wgrad_finish(const float* slabs, int32_t n_split, int32_t taps, int32_t K, int32_t Ncols, int32_t n_inner,
                         float* dw, int64_t d_t, int64_t d_k, int64_t d_n, int64_t d_o, float* db, void* stream);

@@ -226,6 +226,34 @@ def test_conv3x3_wgrad(dev, shape):
         assert rel_err(db.cpu(), bias.grad.float()) < TOL
 
 
+@pytest.mark.parametrize("shape", [(1, 32, 32, [32, 32, 32], 32), (3, 64, 64, [16], 16), (2, 24, 40, [8], 12),
+                                   (1, 37, 21, [20, 12], 36), (2, 16, 16, [8], 8), (1, 128, 128, [64], 64),
+                                   (2, 6, 18, [12], 40)])
+@pytest.mark.parametrize("direct", [False, True])
+def test_conv3x3_wgrad_plain_views(dev, shape, direct):
+    """Plain views: the LDS-DMA kernels.  Winograd F(2x2,3x3) weight gradient (images at least 17 wide) and the direct
+    sum both match autograd in fp64 within 1e-4 (observed ~1e-6), for many and for few slabs."""
+    from unet_nested4tiny_objects_keypoints_amd import _lib, ops
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    b, h, w, cins, co = shape
+    g = torch.Generator().manual_seed(6)
+    srcs = [torch.randn(b, c, h, w, generator=g, dtype=torch.float64) for c in cins]
+    wt = torch.randn(co, sum(cins), 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(co, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(b, co, h, w, generator=g, dtype=torch.float64)
+    F.conv2d(torch.cat(srcs, 1), wt, bias, padding=1).backward(dy)
+    ci = sum(cins)
+    for target_blocks in (1024, 3):
+        dw = torch.full((co, ci, 3, 3), float("nan"), device=dev)
+        db = torch.full((co,), float("nan"), device=dev)
+        ops.wgrad(b, h, w, 9, [V(nhwc(s.float())) for s in srcs], [V(nhwc(dy.float()))], dw, (1, 9, ci * 9, 0), db,
+                  target_blocks=target_blocks, direct=direct)
+        name = _lib.lib().unetpp_last_kernel_name().decode()
+        assert name == ("wgrad_wino_kernel" if (not direct and w > 16) else "wgrad_dma_kernel<9>")
+        assert rel_err(dw.cpu(), wt.grad.float()) < TOL
+        assert rel_err(db.cpu(), bias.grad.float()) < TOL
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 64, 1, 32), (1, 24, 40, 3, 8), (3, 16, 16, 4, 128), (2, 8, 8, 2, 4)])
 def test_first_layer_wgrad(dev, shape):
     """The 1..4-channel first convolution's dedicated weight-gradient kernel (plain dy, no gate)."""

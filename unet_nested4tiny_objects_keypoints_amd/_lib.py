@@ -15,12 +15,12 @@ _REPO = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.environ.get("UNETPP_LIB", os.path.join(_PKG_DIR, "libunetpp_hip.so"))  # override: kernel A/B runs
 CSRC = os.path.join(_PKG_DIR, "csrc")
 INCLUDE = os.path.join(_REPO, "include")
-SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_wino.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "first_layer.hip", "pointwise.hip")
+SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_wino.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "wgrad_wino.hip", "first_layer.hip", "pointwise.hip")
 HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h")
 MAX_VIEWS = 8
 ABI_VERSION = 2
 # packed-f32 VALU (SLP-vectorised add pairs) costs issue slots beside MFMAs: keep the Winograd transforms scalar
-EXTRA_FLAGS = {"gemm_wino.hip": ("-fno-slp-vectorize",)}
+EXTRA_FLAGS = {"gemm_wino.hip": ("-fno-slp-vectorize",), "wgrad_wino.hip": ("-fno-slp-vectorize",)}
 GEMM_DIRECT = 1  # unetpp_gemm_desc.flags: direct summation only (no Winograd)
 
 
@@ -54,7 +54,7 @@ class WgradDesc(C.Structure):
         ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
         ("taps", C.c_int32), ("n_x", C.c_int32), ("n_dy", C.c_int32),
         ("x", View * MAX_VIEWS), ("dy", View * MAX_VIEWS),
-        ("n_split", C.c_int32),
+        ("n_split", C.c_int32), ("flags", C.c_int32),
         ("slabs", C.c_void_p),
     ]
 
@@ -71,6 +71,7 @@ SIGNATURES = {
     "unetpp_gemm_weight_image_floats": (_I64, [C.POINTER(GemmDesc)]),
     "unetpp_gemm_pack_weight_image": (C.c_int, [C.POINTER(GemmDesc), _P, _P]),
     "unetpp_wgrad_max_split": (_I32, [_I32, _I32, _I32]),
+    "unetpp_wgrad_slab_planes": (_I32, [C.POINTER(WgradDesc)]),
     "unetpp_wgrad": (C.c_int, [C.POINTER(WgradDesc), _P]),
     "unetpp_wgrad_finish": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _I64, _I64, _I64, _I64, _P, _P]),
     "unetpp_pack_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _P]),

@@ -99,6 +99,12 @@ int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st);
 int launch_wgrad_fast(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_tiles_cols, int k_tiles, hipStream_t st);
 // wgrad_dma.hip: LDS-DMA staged kernel for views without load transforms; returns 1 when it does not apply
 int launch_wgrad_dma(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_tiles_cols, int k_tiles, hipStream_t st);
+// wgrad_wino.hip: Winograd F(2x2,3x3) weight gradient (16 transform-domain planes per slab); launch returns 1 when
+// it does not apply
+bool wgrad_wino_applies(const unetpp_wgrad_desc* d);
+int launch_wgrad_wino(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_tiles_cols, int k_tiles, hipStream_t st);
+int launch_wgrad_finish_wino(const float* slabs, int n_split, int K, int Ncols, float* dw, long d_t, long d_k, long d_n,
+                             float* db, hipStream_t st);
 // first_layer.hip: VALU kernels for the 1..4-channel first convolution; return 1 when they do not apply
 int launch_small_cin_fwd(const unetpp_gemm_desc* d, hipStream_t st);
 int launch_small_cin_wgrad(const unetpp_wgrad_desc* d, hipStream_t st);

@@ -228,6 +228,13 @@ extern "C" int32_t unetpp_wgrad_max_split(int32_t N, int32_t H, int32_t W) {
   return static_cast<int32_t>(t > 4096 ? 4096 : t);
 }
 
+extern "C" int32_t unetpp_wgrad_slab_planes(const unetpp_wgrad_desc* d) {
+  if (d == nullptr) return 0;
+  // the 1..4-channel first layer keeps its own kernel (tap slabs) whatever the flags say
+  const bool small = d->taps == 9 && d->n_x == 1 && d->x[0].c_len <= 4;
+  return (!small && wgrad_wino_applies(d)) ? 16 : d->taps;
+}
+
 extern "C" int unetpp_wgrad(const unetpp_wgrad_desc* d, void* stream) {
   if (d == nullptr || d->N <= 0 || d->H <= 0 || d->W <= 0) return UNETPP_EINVAL;
   if (d->taps != 9 && d->taps != 1) return UNETPP_EINVAL;
@@ -261,6 +268,10 @@ extern "C" int unetpp_wgrad(const unetpp_wgrad_desc* d, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int small = launch_small_cin_wgrad(d, st);  // 1..4-channel first layer
   if (small != 1) return small;
+  {
+    const int wino = launch_wgrad_wino(d, a.Ktot, a.Ncols, a.n_tiles_cols, k_tiles, st);  // 16-plane slabs
+    if (wino != 1) return wino;
+  }
   if (getenv("UNETPP_NO_WGRAD_DMA") == nullptr) {  // (knob for A/B runs)
     const int dma = launch_wgrad_dma(d, a.Ktot, a.Ncols, a.n_tiles_cols, k_tiles, st);
     if (dma != 1) return dma;
@@ -280,6 +291,10 @@ extern "C" int unetpp_wgrad_finish(const float* slabs, int32_t n_split, int32_t 
                                    float* db, void* stream) {
   if (slabs == nullptr || n_split < 1 || taps < 1 || K < 1 || Ncols < 1) return UNETPP_EINVAL;
   if (n_inner < 1 || Ncols % n_inner != 0) return UNETPP_EINVAL;
+  if (taps == 16) {  // Winograd-domain slabs (unetpp_wgrad_slab_planes() == 16): sum, then G^T . G -> 9 taps
+    if (n_inner != Ncols) return UNETPP_EINVAL;
+    return launch_wgrad_finish_wino(slabs, n_split, K, Ncols, dw, d_t, d_k, d_n, db, static_cast<hipStream_t>(stream));
+  }
   const long total = (static_cast<long>(taps) * K + 1) * Ncols;
   const unsigned blocks = static_cast<unsigned>((total + 63) / 64);
   hipLaunchKernelGGL(wgrad_finish_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), slabs,

@@ -1,0 +1,454 @@
+// Winograd F(2x2, 3x3) form of the 3x3 weight gradient (same split-K-over-pixel-patches scheme and slab protocol as
+// wgrad_dma.hip, 2.25x fewer MFMA cycles):
+//
+//   dg = G^T [ sum_tiles (B^T d B) (.) (A dY A^T) ] G      d = 4x4 window of x, dY = 2x2 tile of dy
+//
+// The kernel accumulates the transform-domain products dU[xi][c][n] (16 planes instead of 9 taps);
+// unetpp_wgrad_finish sums the slabs and applies G^T . G.  Mapping onto v_mfma_f32_16x16x4_f32:
+//   * MFMA row = input channel, MFMA column = output column, MFMA k = 4 TILES (the contraction runs over tiles);
+//   * 512 threads = 8 waves = 2 channel halves (16 of the 32 channels of the k-tile) x 4 tile groups; a wave owns
+//     4 of the 16 tile columns of the 256-pixel patch (4 MFMA k-steps) and the 16 x 32 block of all 16 dU planes:
+//     acc[16][2] float4 = 128 VGPRs;
+//   * A operand: lane (channel c, tile slot g) reads its tile's 4x4 window at channel c (16 ds_read_b32), runs
+//     B^T d B in registers (32 add/sub) -> 16 values; B operand: lane (column n, tile slot g) reads the 2x2 dy tile and
+//     runs A dY A^T without the sign flips of A's last row (12 add/sub; the finish kernel applies the signs);
+//   * patches go HBM/L2 -> LDS by global_load_lds (two distinct static buffers, loop unrolled by two, as in
+//     wgrad_dma.hip).  LDS image: 8-pixel groups of 1 KB (one DMA instruction each) separated by a small pad; the 4
+//     tile slots of an MFMA k-step are the 4 tile ROWS of the patch at one tile column, i.e. pixels a whole number of
+//     groups apart (x rows are 36 pixels in LDS), so every window address is a per-lane constant plus an immediate
+//     offset and the pads rotate the slots' banks apart (2-way conflicts at worst);
+//   * epilogue: the 4 tile groups are summed in a fixed-order tree through LDS, one slab per workgroup; db comes
+//     from the (1,1) element of A dY A^T, which is the plain sum of the 2x2 tile.
+#include "common.h"
+
+namespace unetpp {
+namespace {
+
+constexpr int kWThreads = 512;
+constexpr int kTW = 32, kTH = 8, kHWp = kTW + 2, kHHp = kTH + 2;
+constexpr int kXRow = 36;                          // LDS row stride of the x patch in pixels (34 + 2 unused): two rows
+                                                   // = 72 pixels = 9 whole groups
+constexpr int kNPix = kXRow * kHHp;                // 360 pixel slots
+constexpr int GX = 264;                            // floats per 8-pixel group of the x patch (256 + 8 pad)
+constexpr int GY = 260;                            // ... of the dy patch (256 + 4 pad)
+constexpr int XG = kNPix / 8;                      // 45 groups
+constexpr int YG = kBlockPixels / 8;               // 32 groups
+constexpr int X_FLOATS = XG * GX;                  // 11880
+constexpr int BUF = X_FLOATS + YG * GY;            // 20200 floats = 80800 B per buffer
+constexpr int X_ITEMS = (XG * 64 + kWThreads - 1) / kWThreads;  // 6
+constexpr int DY_ITEMS = YG * 64 / kWThreads;                   // 4
+
+struct WWinoArgs {
+  unetpp_wgrad_desc d;
+  int tiles_x, tiles_y;
+  int Ktot, Ncols, n_tiles_cols;
+  long n_pix_tiles;
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArgs a) {
+  __shared__ __attribute__((aligned(16))) float buf_a[BUF];
+  __shared__ __attribute__((aligned(16))) float buf_b[BUF];
+
+  const unetpp_wgrad_desc& d = a.d;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, t16 = lane & 15, g = lane >> 4;
+  const int ch = wave & 1;                                         // channel half
+  const int tg = wave >> 1;                                        // tile group: tile columns 4*tg .. 4*tg + 3
+
+  int nt = blockIdx.y % a.n_tiles_cols;
+  int kt = blockIdx.y / a.n_tiles_cols;
+  int dv = 0, col_base = 0;
+  while (dv < d.n_dy - 1) {
+    const int tiles_v = (d.dy[dv].c_len + 31) >> 5;
+    if (nt < tiles_v) break;
+    nt -= tiles_v;
+    col_base += d.dy[dv].c_len;
+    ++dv;
+  }
+  const unetpp_view& DY = d.dy[dv];
+  int xv = 0, kbase = 0;
+  while (xv < d.n_x - 1) {
+    const int tiles_v = (d.x[xv].c_len + 31) >> 5;
+    if (kt < tiles_v) break;
+    kt -= tiles_v;
+    kbase += d.x[xv].c_len;
+    ++xv;
+  }
+  const unetpp_view& X = d.x[xv];
+  const int c0 = kt * 32;
+  const int k_cnt = min(32, X.c_len - c0);
+  const int nc0 = nt * 32;
+  const int n0 = col_base + nc0;
+  const int n_cnt = min(32, DY.c_len - nc0);
+  const bool want_db = (blockIdx.y / a.n_tiles_cols) == 0;
+
+  // channels / columns that are never staged must read as zero in both buffers
+  if (k_cnt < 32 || n_cnt < 32) {
+    for (int i = tid; i < BUF; i += kWThreads) {
+      buf_a[i] = 0.f;
+      buf_b[i] = 0.f;
+    }
+    __syncthreads();
+  }
+
+  // ---- staging: item it = (group it>>6, pixel (it>>3)&7 of the group, channel quad it&7); the group is wave uniform
+  // per item, the quad and the pixel-in-group are the same for every item of a thread ----
+  const int cc = (tid & 7) << 2;
+  const bool kx_ok = cc < k_cnt, nx_ok = cc < n_cnt;
+  unsigned xdelta[X_ITEMS], ydelta[DY_ITEMS];
+#pragma unroll
+  for (int q = 0; q < X_ITEMS; ++q) {
+    const int hp = (tid >> 3) + q * (kWThreads >> 3);
+    const int hy = hp / kXRow, hx = min(hp - hy * kXRow, kHWp - 1);  // slots 34, 35 of a row are never loaded
+    xdelta[q] = static_cast<unsigned>(((hy * X.sy) * X.Ws + hx * X.sx) * X.C + cc) * 4u;
+  }
+#pragma unroll
+  for (int q = 0; q < DY_ITEMS; ++q) {
+    const int p = (tid >> 3) + q * (kWThreads >> 3);
+    ydelta[q] = static_cast<unsigned>((((p >> 5) * DY.sy) * DY.Ws + (p & 31) * DY.sx) * DY.C + cc) * 4u;
+  }
+  // Edge patches take two passes: zero fills of out-of-image pixels first (plain ds_writes), then the DMAs -- a
+  // ds_write into an array with a DMA in flight makes hipcc drain vmcnt first (see wgrad_dma.hip).
+  auto issue_tile = [&](long tile, float* buf) {
+    long b = tile;
+    const int txi = static_cast<int>(b % a.tiles_x);
+    b /= a.tiles_x;
+    const int tyi = static_cast<int>(b % a.tiles_y);
+    const int n = static_cast<int>(b / a.tiles_y);
+    const int ty0 = tyi * kTH, tx0 = txi * kTW;
+    const char* xb = reinterpret_cast<const char*>(X.ptr + view_pixel_offset(X, n, ty0 - 1, tx0 - 1) + c0);
+    const char* yb = reinterpret_cast<const char*>(DY.ptr + view_pixel_offset(DY, n, ty0, tx0) + nc0);
+    const bool interior = ty0 >= 1 && tx0 >= 1 && ty0 + kTH + 1 <= d.H && tx0 + kTW + 1 <= d.W;
+    const int lq = (tid & 63) * 4;  // float slot of this lane inside its 1 KB group
+    if (interior) {
+      if (kx_ok) {
+#pragma unroll
+        for (int q = 0; q < X_ITEMS; ++q) {
+          float* lbase = buf + (q * 8 + wave) * GX;  // wave-uniform; the DMA adds lane * 16 bytes
+          const int hp = (tid >> 3) + q * (kWThreads >> 3);
+          if (hp < kNPix && hp % kXRow < kHWp)
+            __builtin_amdgcn_global_load_lds((gptr_t)(xb + xdelta[q]), (lptr_t)lbase, 16, 0, 0);
+        }
+      }
+      if (nx_ok) {
+#pragma unroll
+        for (int q = 0; q < DY_ITEMS; ++q) {
+          float* lbase = buf + X_FLOATS + (q * 8 + wave) * GY;
+          __builtin_amdgcn_global_load_lds((gptr_t)(yb + ydelta[q]), (lptr_t)lbase, 16, 0, 0);
+        }
+      }
+    } else {
+      unsigned xin = 0, yin = 0;  // bit q: item q of this thread lies inside the image
+#pragma unroll
+      for (int q = 0; q < X_ITEMS; ++q) {
+        const int it = tid + q * kWThreads;
+        const int hp = it >> 3;
+        const int hy = hp / kXRow, hx = hp - hy * kXRow;
+        const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+        const bool valid = hp < kNPix && hx < kHWp && kx_ok;
+        const bool inimg = y >= 0 && y < d.H && x >= 0 && x < d.W;
+        if (valid && inimg) xin |= 1u << q;
+        if (valid && !inimg) *reinterpret_cast<f32x4*>(buf + (q * 8 + wave) * GX + lq) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int q = 0; q < DY_ITEMS; ++q) {
+        const int p = (tid + q * kWThreads) >> 3;
+        const bool inimg = ty0 + (p >> 5) < d.H && tx0 + (p & 31) < d.W;
+        if (nx_ok && inimg) yin |= 1u << q;
+        if (nx_ok && !inimg) *reinterpret_cast<f32x4*>(buf + X_FLOATS + (q * 8 + wave) * GY + lq) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int q = 0; q < X_ITEMS; ++q) {
+        float* lbase = buf + (q * 8 + wave) * GX;
+        if ((xin >> q) & 1u) __builtin_amdgcn_global_load_lds((gptr_t)(xb + xdelta[q]), (lptr_t)lbase, 16, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < DY_ITEMS; ++q) {
+        float* lbase = buf + X_FLOATS + (q * 8 + wave) * GY;
+        if ((yin >> q) & 1u) __builtin_amdgcn_global_load_lds((gptr_t)(yb + ydelta[q]), (lptr_t)lbase, 16, 0, 0);
+      }
+    }
+  };
+
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) acc[xi][nh] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbsum[2] = {0.f, 0.f};
+
+  // One staged patch: this wave's k-step r covers tile column 4*tg + r; MFMA k-slot g = tile row g.  Pixel slot of a
+  // window element = 72 g + 8 tg + (36 i + j + 2 r): whole groups for g and tg, a compile-time rest.
+  const int lane_x = (9 * g + tg) * GX + 16 * ch + t16;
+  const int lane_y = X_FLOATS + (8 * g + tg) * GY + t16;
+  auto compute = [&](const float* buf, int half) {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int r = 2 * half + rr;
+      float t[4][4], V[16];
+      {
+        float xa[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int U = kXRow * i + j + 2 * r;
+            xa[i][j] = buf[lane_x + (U >> 3) * GX + (U & 7) * 32];
+          }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          t[0][j] = xa[0][j] - xa[2][j];
+          t[1][j] = xa[1][j] + xa[2][j];
+          t[2][j] = xa[2][j] - xa[1][j];
+          t[3][j] = xa[1][j] - xa[3][j];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        V[4 * i + 0] = t[i][0] - t[i][2];
+        V[4 * i + 1] = t[i][1] + t[i][2];
+        V[4 * i + 2] = t[i][2] - t[i][1];
+        V[4 * i + 3] = t[i][1] - t[i][3];
+      }
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        float dy[2][2];
+#pragma unroll
+        for (int ap = 0; ap < 2; ++ap)
+#pragma unroll
+          for (int bp = 0; bp < 2; ++bp) {
+            const int P = kTW * ap + bp + 2 * r;
+            dy[ap][bp] = buf[lane_y + 16 * nh + (P >> 3) * GY + (P & 7) * 32];
+          }
+        // A dY A^T with A's last row taken as (0, +1): rows (d0, d0 + d1, d0 - d1, d1); the finish kernel applies the
+        // sign (-1)^[a == 3] (-1)^[b == 3]
+        float rw[4][2];
+#pragma unroll
+        for (int bp = 0; bp < 2; ++bp) {
+          rw[0][bp] = dy[0][bp];
+          rw[1][bp] = dy[0][bp] + dy[1][bp];
+          rw[2][bp] = dy[0][bp] - dy[1][bp];
+          rw[3][bp] = dy[1][bp];
+        }
+        float M[16];
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) {
+          M[4 * aa + 0] = rw[aa][0];
+          M[4 * aa + 1] = rw[aa][0] + rw[aa][1];
+          M[4 * aa + 2] = rw[aa][0] - rw[aa][1];
+          M[4 * aa + 3] = rw[aa][1];
+        }
+        dbsum[nh] += M[5];  // (1,1): the plain sum of the 2x2 tile
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi)
+          acc[xi][nh] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi], M[xi], acc[xi][nh], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // 128 accumulator registers: keep the next batch's operands from being hoisted
+      }
+    }
+  };
+
+  // tiles of this workgroup: blockIdx.x, +gridDim.x, ...   (buffer A holds even, buffer B odd local tiles)
+  const long stride = gridDim.x;
+  const long t0 = blockIdx.x;
+  const long n_my = (t0 < a.n_pix_tiles) ? (a.n_pix_tiles - t0 + stride - 1) / stride : 0;
+  if (n_my > 0) issue_tile(t0, buf_a);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // Waves w and w+4 share a SIMD: waves 0-3 issue the next patch's DMAs before their MFMAs, waves 4-7 half way through.
+  const bool late = wave >= 4;
+  for (long i = 0; i < n_my; i += 2) {
+    if (!late && i + 1 < n_my) issue_tile(t0 + (i + 1) * stride, buf_b);
+    compute(buf_a, 0);
+    if (late && i + 1 < n_my) issue_tile(t0 + (i + 1) * stride, buf_b);
+    compute(buf_a, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (i + 1 < n_my) {
+      if (!late && i + 2 < n_my) issue_tile(t0 + (i + 2) * stride, buf_a);
+      compute(buf_b, 0);
+      if (late && i + 2 < n_my) issue_tile(t0 + (i + 2) * stride, buf_a);
+      compute(buf_b, 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+
+  // ---- fixed-order tree over the 4 tile groups of each channel half: (tg0 + tg2) + (tg1 + tg3).  A region holds
+  // the 32 float4 accumulators of a wave lane-linearly (32 KB); two regions per buffer. ----
+  constexpr int R = 32 * 64 * 4;  // floats per region
+  auto region = [&](float* base) { return base + ch * R + lane * 4; };
+  auto put = [&](float* rg) {
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) *reinterpret_cast<f32x4*>(rg + (xi * 2 + nh) * 256) = acc[xi][nh];
+  };
+  auto add = [&](const float* rg) {
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(rg + (xi * 2 + nh) * 256);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[xi][nh][e] += v[e];
+        if (nh == 1 && (xi & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most 8 loads in flight
+      }
+  };
+  if (tg == 2) put(region(buf_a));
+  if (tg == 3) put(region(buf_b));
+  __syncthreads();
+  if (tg == 0) add(region(buf_a));
+  if (tg == 1) add(region(buf_b));
+  __syncthreads();
+  if (tg == 1) put(region(buf_a));
+  __syncthreads();
+  if (tg == 0) add(region(buf_a));
+
+  // ---- one slab per workgroup: planes xi = 0..15, then the db row ----
+  const long slab_stride = (16L * a.Ktot + 1) * a.Ncols;
+  float* slab = d.slabs + blockIdx.x * slab_stride;
+  if (tg == 0) {
+    // register e of acc[xi][nh] of lane (t16, g): channel 16*ch + 4*g + e, column 16*nh + t16
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      const int n = 16 * nh + t16;
+      if (n < n_cnt) {
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = 16 * ch + 4 * g + e;
+            if (c < k_cnt) slab[(static_cast<long>(xi) * a.Ktot + kbase + c0 + c) * a.Ncols + n0 + n] = acc[xi][nh][e];
+          }
+      }
+    }
+  }
+  if (want_db) {
+    __syncthreads();  // the regions are dead
+    float* dbs = buf_b;  // [tg 4][32 columns]
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+      dbsum[nh] += __shfl_xor(dbsum[nh], 16);
+      dbsum[nh] += __shfl_xor(dbsum[nh], 32);
+      if (ch == 0 && g == 0) dbs[tg * 32 + 16 * nh + t16] = dbsum[nh];
+    }
+    __syncthreads();
+    if (tid < n_cnt)
+      slab[16L * a.Ktot * a.Ncols + n0 + tid] = (dbs[tid] + dbs[64 + tid]) + (dbs[32 + tid] + dbs[96 + tid]);
+  }
+}
+
+// slab sum + G^T . G: 256 threads = 4 slab groups x (16 planes x 4 (k, n) pairs); the bias row is summed by extra blocks
+__global__ void wgrad_finish_wino_kernel(const float* __restrict__ slabs, int n_split, int K, int Ncols,
+                                         float* __restrict__ dw, long d_t, long d_k, long d_n, float* __restrict__ db) {
+  __shared__ float part[4][64];
+  const long pairs = static_cast<long>(K) * Ncols;
+  const long total = (16L * K + 1) * Ncols;
+  const long pair_blocks = (pairs + 3) / 4;
+  const int e = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  if (static_cast<long>(blockIdx.x) >= pair_blocks) {  // bias row: 64 columns per block
+    const long n = (blockIdx.x - pair_blocks) * 64L + e;
+    float s = 0.f;
+    if (n < Ncols)
+      for (int b = sg; b < n_split; b += 4) s += slabs[static_cast<long>(b) * total + 16L * pairs + n];
+    part[sg][e] = s;
+    __syncthreads();
+    if (sg == 0 && n < Ncols && db != nullptr) db[n] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+    return;
+  }
+  const int xi = e >> 2;
+  const long pair = blockIdx.x * 4L + (e & 3);
+  float s = 0.f;
+  if (pair < pairs) {
+    const long i = static_cast<long>(xi) * pairs + pair;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = sg;
+    for (; b + 12 < n_split; b += 16) {
+      s0 += slabs[static_cast<long>(b) * total + i];
+      s1 += slabs[static_cast<long>(b + 4) * total + i];
+      s2 += slabs[static_cast<long>(b + 8) * total + i];
+      s3 += slabs[static_cast<long>(b + 12) * total + i];
+    }
+    for (; b < n_split; b += 4) s0 += slabs[static_cast<long>(b) * total + i];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  part[sg][e] = s;
+  __syncthreads();
+  if (threadIdx.x < 64) part[0][e] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+  __syncthreads();
+  if (threadIdx.x >= 36 || dw == nullptr) return;
+  const int pl = threadIdx.x & 3, tap = threadIdx.x >> 2;  // 9 taps x 4 pairs
+  const long p = blockIdx.x * 4L + pl;
+  if (p >= pairs) return;
+  const int r = tap / 3, c = tap - 3 * r;
+  // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; column r of G, with the sign of the kernel's unsigned last row
+  const float gr[4] = {r == 0 ? 1.f : 0.f, 0.5f, (r == 1) ? -0.5f : 0.5f, r == 2 ? -1.f : 0.f};
+  const float gc[4] = {c == 0 ? 1.f : 0.f, 0.5f, (c == 1) ? -0.5f : 0.5f, c == 2 ? -1.f : 0.f};
+  float out = 0.f;
+#pragma unroll
+  for (int aa = 0; aa < 4; ++aa) {
+    float rowsum = 0.f;
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) rowsum = fmaf(gc[bb], part[0][(aa * 4 + bb) * 4 + pl], rowsum);
+    out = fmaf(gr[aa], rowsum, out);
+  }
+  const long k = p / Ncols, n = p - k * Ncols;
+  dw[tap * d_t + k * d_k + n * d_n] = out;
+}
+
+bool plain_aligned(const unetpp_view& v) {
+  return v.scale == nullptr && v.gate == nullptr && !v.relu && ((v.C | v.c_off | v.c_len) & 3) == 0 &&
+         (reinterpret_cast<uintptr_t>(v.ptr) & 15) == 0;
+}
+
+}  // namespace
+
+// 3x3, Winograd not forbidden, 32-wide patches, every view plain and 16-byte aligned, 32-bit byte offsets inside a patch
+bool wgrad_wino_applies(const unetpp_wgrad_desc* d) {
+  if (d == nullptr || d->taps != 9 || (d->flags & UNETPP_GEMM_DIRECT) != 0) return false;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || tile_geom(d->H, d->W).log2tw != 5) return false;
+  if (d->n_x < 1 || d->n_x > UNETPP_MAX_VIEWS || d->n_dy < 1 || d->n_dy > UNETPP_MAX_VIEWS) return false;
+  for (int i = 0; i < d->n_x; ++i) {
+    const unetpp_view& v = d->x[i];
+    if (!view_ok(v) || !plain_aligned(v) || v.c_len < 8) return false;
+    if (static_cast<long>(kHHp) * v.sy * v.Ws * v.C * 4 >= 0x7fffffffL) return false;
+  }
+  for (int i = 0; i < d->n_dy; ++i) {
+    const unetpp_view& v = d->dy[i];
+    if (!view_ok(v) || !plain_aligned(v)) return false;
+    if (static_cast<long>(kHHp) * v.sy * v.Ws * v.C * 4 >= 0x7fffffffL) return false;
+  }
+  return true;
+}
+
+// returns UNETPP_OK after launching, or 1 when the descriptor needs another kernel
+int launch_wgrad_wino(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_tiles_cols, int k_tiles, hipStream_t st) {
+  if (!wgrad_wino_applies(d)) return 1;
+  WWinoArgs a;
+  a.d = *d;
+  a.Ktot = Ktot;
+  a.Ncols = Ncols;
+  a.n_tiles_cols = n_tiles_cols;
+  const TileGeom g = tile_geom(d->H, d->W);
+  a.tiles_x = g.tiles_x;
+  a.tiles_y = g.tiles_y;
+  a.n_pix_tiles = static_cast<long>(d->N) * g.tiles_y * g.tiles_x;
+  const dim3 grid(static_cast<unsigned>(d->n_split), static_cast<unsigned>(static_cast<long>(k_tiles) * n_tiles_cols));
+  hipLaunchKernelGGL(wgrad_wino_kernel, grid, dim3(kWThreads), 0, st, a);
+  note_kernel("wgrad_wino_kernel");
+  return launch_status();
+}
+
+int launch_wgrad_finish_wino(const float* slabs, int n_split, int K, int Ncols, float* dw, long d_t, long d_k, long d_n,
+                             float* db, hipStream_t st) {
+  const long pairs = static_cast<long>(K) * Ncols;
+  const unsigned blocks = static_cast<unsigned>((pairs + 3) / 4 + (Ncols + 63) / 64);
+  hipLaunchKernelGGL(wgrad_finish_wino_kernel, dim3(blocks), dim3(256), 0, st, slabs, n_split, K, Ncols, dw, d_t, d_k,
+                     d_n, db);
+  return launch_status();
+}
+
+}  // namespace unetpp

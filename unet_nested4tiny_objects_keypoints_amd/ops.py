@@ -195,8 +195,10 @@ def pack_weight(dst: torch.Tensor, src: torch.Tensor, t: int, k: int, n: int, ds
 
 
 def wgrad(n: int, h: int, w: int, taps: int, xs: Sequence[V], dys: Sequence[V], dw: Optional[torch.Tensor],
-          dw_strides, db: Optional[torch.Tensor], n_inner: Optional[int] = None, target_blocks: int = 256) -> None:
-    """dw / db are written (not accumulated).  dw_strides = (d_t, d_k, d_n, d_o) into the torch-layout gradient."""
+          dw_strides, db: Optional[torch.Tensor], n_inner: Optional[int] = None, target_blocks: int = 256,
+          direct: bool = False) -> None:
+    """dw / db are written (not accumulated).  dw_strides = (d_t, d_k, d_n, d_o) into the torch-layout gradient.
+    direct=True forbids the Winograd form of the 3x3 kernel."""
     lib = _lib.lib()
     d = WgradDesc()
     d.N, d.H, d.W, d.taps = n, h, w, taps
@@ -207,14 +209,16 @@ def wgrad(n: int, h: int, w: int, taps: int, xs: Sequence[V], dys: Sequence[V], 
     if len(xs) == 1 and xs[0].t.shape[3] <= 4:
         target_blocks = 2048  # the 1..4-channel first layer runs an HBM-bound VALU kernel: many small workgroups
     split = max(1, min(int(lib.unetpp_wgrad_max_split(n, h, w)), target_blocks // max(1, pairs)))
-    slabs = torch.empty(split * (taps * k + 1) * nc, dtype=torch.float32, device=xs[0].t.device)
     d.n_split = split
+    d.flags = _lib.GEMM_DIRECT if (direct or not USE_WINOGRAD) else 0
+    planes = int(lib.unetpp_wgrad_slab_planes(C.byref(d)))  # taps, or 16 for the Winograd kernel
+    slabs = torch.empty(split * (planes * k + 1) * nc, dtype=torch.float32, device=xs[0].t.device)
     d.slabs = slabs.data_ptr()
     _timed_call(None, 2.0 * n * h * w * taps * k * nc,
                 lambda: check(lib.unetpp_wgrad(C.byref(d), _stream()), "unetpp_wgrad"))
     if n_inner is None:
         n_inner = nc
-    check(lib.unetpp_wgrad_finish(_ptr(slabs), split, taps, k, nc, n_inner, _ptr(dw), dw_strides[0], dw_strides[1],
+    check(lib.unetpp_wgrad_finish(_ptr(slabs), split, planes, k, nc, n_inner, _ptr(dw), dw_strides[0], dw_strides[1],
                                   dw_strides[2], dw_strides[3], _ptr(db), _stream()), "unetpp_wgrad_finish")
 
 
