@@ -254,6 +254,34 @@ def test_conv3x3_wgrad_plain_views(dev, shape, direct):
         assert rel_err(db.cpu(), bias.grad.float()) < TOL
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 32, 32, 32), (1, 24, 40, 12, 20), (2, 37, 21, 24, 8), (1, 64, 64, 64, 64)])
+@pytest.mark.parametrize("direct", [False, True])
+def test_conv3x3_wgrad_folded_batchnorm_view(dev, shape, direct):
+    """x view with the producer's BatchNorm apply + ReLU folded into the operand read (scale/shift + relu, zero padding
+    AFTER the transform; negative, zero and positive scales): Winograd kernel (NaN padding trick) and direct kernel."""
+    from unet_nested4tiny_objects_keypoints_amd import _lib, ops
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    b, h, w, ci, co = shape
+    g = torch.Generator().manual_seed(8)
+    y1 = torch.randn(b, ci, h, w, generator=g, dtype=torch.float64)
+    scale = torch.randn(ci, generator=g, dtype=torch.float64)
+    scale[0] = 0.0
+    shift = torch.randn(ci, generator=g, dtype=torch.float64)
+    xin = F.relu(y1 * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    wt = torch.randn(co, ci, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(co, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(b, co, h, w, generator=g, dtype=torch.float64)
+    F.conv2d(xin, wt, bias, padding=1).backward(dy)
+    dw = torch.full((co, ci, 3, 3), float("nan"), device=dev)
+    db = torch.full((co,), float("nan"), device=dev)
+    ops.wgrad(b, h, w, 9, [V(nhwc(y1.float()), scale=scale.float().cuda(), shift=shift.float().cuda(), relu=True)],
+              [V(nhwc(dy.float()))], dw, (1, 9, ci * 9, 0), db, direct=direct)
+    name = _lib.lib().unetpp_last_kernel_name().decode()
+    assert name == ("wgrad_fast_kernel<9>" if direct else "wgrad_wino_kernel")
+    assert rel_err(dw.cpu(), wt.grad.float()) < TOL
+    assert rel_err(db.cpu(), bias.grad.float()) < TOL
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 64, 1, 32), (1, 24, 40, 3, 8), (3, 16, 16, 4, 128), (2, 8, 8, 2, 4)])
 def test_first_layer_wgrad(dev, shape):
     """The 1..4-channel first convolution's dedicated weight-gradient kernel (plain dy, no gate)."""

@@ -157,10 +157,10 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(const WgradArgs a) {
 __global__ void wgrad_finish_kernel(const float* __restrict__ slabs, int n_split, int taps, int K, int Ncols,
                                     int n_inner, float* __restrict__ dw, long d_t, long d_k, long d_n, long d_o,
                                     float* __restrict__ db) {
-  // 256 threads = 64 consecutive slab elements x 4 slab groups: group g sums slabs g, g+4, ... (4 loads in
-  // flight), the groups are combined through LDS in fixed order -> reproducible, and 4x the parallelism of a
-  // one-thread-per-element loop over up to 1024 slabs.
-  __shared__ float part[4][64];
+  // 1024 threads = 64 consecutive slab elements x 16 slab groups; the groups are combined through LDS in fixed order
+  // -> reproducible, and 16x the parallelism of a one-thread-per-element loop over up to 1024 slabs.
+  constexpr int SG = 16;  // slab groups: group g sums slabs g, g+16, ... -- 1024 threads, all loads independent
+  __shared__ float part[SG][64];
   const long rows = static_cast<long>(taps) * K + 1;
   const long total = rows * Ncols;
   const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -169,19 +169,21 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ slabs, int n_split
   if (i < total) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int b = g;
-    for (; b + 12 < n_split; b += 16) {
+    for (; b + 3 * SG < n_split; b += 4 * SG) {
       s0 += slabs[static_cast<long>(b) * total + i];
-      s1 += slabs[static_cast<long>(b + 4) * total + i];
-      s2 += slabs[static_cast<long>(b + 8) * total + i];
-      s3 += slabs[static_cast<long>(b + 12) * total + i];
+      s1 += slabs[static_cast<long>(b + SG) * total + i];
+      s2 += slabs[static_cast<long>(b + 2 * SG) * total + i];
+      s3 += slabs[static_cast<long>(b + 3 * SG) * total + i];
     }
-    for (; b < n_split; b += 4) s0 += slabs[static_cast<long>(b) * total + i];
+    for (; b < n_split; b += SG) s0 += slabs[static_cast<long>(b) * total + i];
     s = (s0 + s1) + (s2 + s3);
   }
   part[g][e] = s;
   __syncthreads();
   if (g != 0 || i >= total) return;
-  s = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+  s = 0.f;
+#pragma unroll
+  for (int q = 0; q < SG; ++q) s += part[q][e];  // fixed order
   const long row = i / Ncols;
   const int nn = static_cast<int>(i - row * Ncols);
   if (row == rows - 1) {
@@ -297,7 +299,7 @@ extern "C" int unetpp_wgrad_finish(const float* slabs, int32_t n_split, int32_t 
   }
   const long total = (static_cast<long>(taps) * K + 1) * Ncols;
   const unsigned blocks = static_cast<unsigned>((total + 63) / 64);
-  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), slabs,
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(blocks), dim3(1024), 0, static_cast<hipStream_t>(stream), slabs,
                      n_split, taps, K, Ncols, n_inner, dw, d_t, d_k, d_n, d_o, db);
   return launch_status();
 }

@@ -17,6 +17,7 @@
 //     tile slots of an MFMA k-step are the 4 tile ROWS of the patch at one tile column, i.e. pixels a whole number of
 //     groups apart (x rows are 36 pixels in LDS), so every window address is a per-lane constant plus an immediate
 //     offset and the pads rotate the slots' banks apart (2-way conflicts at worst);
+//   * x views may carry the folded BatchNorm apply + ReLU of their producer (applied at the window read; NaN padding);
 //   * epilogue: the 4 tile groups are summed in a fixed-order tree through LDS, one slab per workgroup; db comes
 //     from the (1,1) element of A dY A^T, which is the plain sum of the 2x2 tile.
 #include "common.h"
@@ -48,6 +49,8 @@ struct WWinoArgs {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// XFORM: every x view carries the folded BatchNorm apply + ReLU (all or none: mixed launches take wgrad_fast.hip)
+template <bool XFORM>
 __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArgs a) {
   __shared__ __attribute__((aligned(16))) float buf_a[BUF];
   __shared__ __attribute__((aligned(16))) float buf_b[BUF];
@@ -110,6 +113,15 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
     const int p = (tid >> 3) + q * (kWThreads >> 3);
     ydelta[q] = static_cast<unsigned>((((p >> 5) * DY.sy) * DY.Ws + (p & 31) * DY.sx) * DY.C + cc) * 4u;
   }
+  // x views may carry the producer's BatchNorm apply + ReLU (scale/shift + relu): it is applied when the window is
+  // read.  Zero padding must stay zero AFTER that transform, so out-of-image pixels are filled with NaN instead:
+  // fma(NaN, s, t) = NaN and v_max_f32(NaN, 0) = 0.  Channels past the slice get scale = shift = 0.
+  const float x_pad = XFORM ? __builtin_nanf("") : 0.f;
+  float x_sc = 0.f, x_sh = 0.f;
+  if (XFORM && 16 * ch + t16 < k_cnt) {
+    x_sc = X.scale[c0 + 16 * ch + t16];
+    x_sh = X.shift[c0 + 16 * ch + t16];
+  }
   // Edge patches take two passes: zero fills of out-of-image pixels first (plain ds_writes), then the DMAs -- a
   // ds_write into an array with a DMA in flight makes hipcc drain vmcnt first (see wgrad_dma.hip).
   auto issue_tile = [&](long tile, float* buf) {
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
         const bool valid = hp < kNPix && hx < kHWp && kx_ok;
         const bool inimg = y >= 0 && y < d.H && x >= 0 && x < d.W;
         if (valid && inimg) xin |= 1u << q;
-        if (valid && !inimg) *reinterpret_cast<f32x4*>(buf + (q * 8 + wave) * GX + lq) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (valid && !inimg) *reinterpret_cast<f32x4*>(buf + (q * 8 + wave) * GX + lq) = f32x4{x_pad, x_pad, x_pad, x_pad};
       }
 #pragma unroll
       for (int q = 0; q < DY_ITEMS; ++q) {
@@ -198,6 +210,12 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
             const int U = kXRow * i + j + 2 * r;
             xa[i][j] = buf[lane_x + (U >> 3) * GX + (U & 7) * 32];
           }
+        if (XFORM) {  // BatchNorm apply + ReLU of the producer, folded into the operand read; max(NaN, 0) = 0 (padding)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xa[i][j] = fmaxf(fmaf(xa[i][j], x_sc, x_sh), 0.f);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           t[0][j] = xa[0][j] - xa[2][j];
@@ -307,7 +325,8 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
   __syncthreads();
   if (tg == 0) add(region(buf_a));
 
-  // ---- one slab per workgroup: planes xi = 0..15, then the db row ----
+  // ---- one slab per workgroup: [K][Ncols][16 planes] (the 16 planes of a (channel, column) pair are one 64-byte
+  // run: 16-byte stores here, coalesced reads in the finish kernel), then the db row ----
   const long slab_stride = (16L * a.Ktot + 1) * a.Ncols;
   float* slab = d.slabs + blockIdx.x * slab_stride;
   if (tg == 0) {
@@ -317,12 +336,16 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
       const int n = 16 * nh + t16;
       if (n < n_cnt) {
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi)
+        for (int e = 0; e < 4; ++e) {
+          const int c = 16 * ch + 4 * g + e;
+          if (c < k_cnt) {
+            float* dst = slab + (static_cast<long>(kbase + c0 + c) * a.Ncols + n0 + n) * 16;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int c = 16 * ch + 4 * g + e;
-            if (c < k_cnt) slab[(static_cast<long>(xi) * a.Ktot + kbase + c0 + c) * a.Ncols + n0 + n] = acc[xi][nh][e];
+            for (int q = 0; q < 4; ++q)
+              *reinterpret_cast<f32x4*>(dst + 4 * q) =
+                  f32x4{acc[4 * q][nh][e], acc[4 * q + 1][nh][e], acc[4 * q + 2][nh][e], acc[4 * q + 3][nh][e]};
           }
+        }
       }
     }
   }
@@ -341,10 +364,12 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
   }
 }
 
-// slab sum + G^T . G: 256 threads = 4 slab groups x (16 planes x 4 (k, n) pairs); the bias row is summed by extra blocks
+// slab sum + G^T . G: 1024 threads = 16 slab groups x (4 (k, n) pairs x 16 planes = 64 consecutive slab floats); the
+// bias row is summed by extra blocks
 __global__ void wgrad_finish_wino_kernel(const float* __restrict__ slabs, int n_split, int K, int Ncols,
                                          float* __restrict__ dw, long d_t, long d_k, long d_n, float* __restrict__ db) {
-  __shared__ float part[4][64];
+  constexpr int SG = 16;  // slab groups: group g sums slabs g, g+16, ... -- 1024 threads, all loads independent
+  __shared__ float part[SG][64];
   const long pairs = static_cast<long>(K) * Ncols;
   const long total = (16L * K + 1) * Ncols;
   const long pair_blocks = (pairs + 3) / 4;
@@ -353,31 +378,41 @@ __global__ void wgrad_finish_wino_kernel(const float* __restrict__ slabs, int n_
     const long n = (blockIdx.x - pair_blocks) * 64L + e;
     float s = 0.f;
     if (n < Ncols)
-      for (int b = sg; b < n_split; b += 4) s += slabs[static_cast<long>(b) * total + 16L * pairs + n];
+      for (int b = sg; b < n_split; b += SG) s += slabs[static_cast<long>(b) * total + 16L * pairs + n];
     part[sg][e] = s;
     __syncthreads();
-    if (sg == 0 && n < Ncols && db != nullptr) db[n] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+    if (sg == 0 && n < Ncols && db != nullptr) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < SG; ++q) t += part[q][e];
+      db[n] = t;
+    }
     return;
   }
-  const int xi = e >> 2;
-  const long pair = blockIdx.x * 4L + (e & 3);
+  const int xi = e & 15;
+  const long pair = blockIdx.x * 4L + (e >> 4);
   float s = 0.f;
   if (pair < pairs) {
-    const long i = static_cast<long>(xi) * pairs + pair;
+    const long i = pair * 16 + xi;  // 64 consecutive floats per block
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int b = sg;
-    for (; b + 12 < n_split; b += 16) {
+    for (; b + 3 * SG < n_split; b += 4 * SG) {
       s0 += slabs[static_cast<long>(b) * total + i];
-      s1 += slabs[static_cast<long>(b + 4) * total + i];
-      s2 += slabs[static_cast<long>(b + 8) * total + i];
-      s3 += slabs[static_cast<long>(b + 12) * total + i];
+      s1 += slabs[static_cast<long>(b + SG) * total + i];
+      s2 += slabs[static_cast<long>(b + 2 * SG) * total + i];
+      s3 += slabs[static_cast<long>(b + 3 * SG) * total + i];
     }
-    for (; b < n_split; b += 4) s0 += slabs[static_cast<long>(b) * total + i];
+    for (; b < n_split; b += SG) s0 += slabs[static_cast<long>(b) * total + i];
     s = (s0 + s1) + (s2 + s3);
   }
   part[sg][e] = s;
   __syncthreads();
-  if (threadIdx.x < 64) part[0][e] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+  if (threadIdx.x < 64) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < SG; ++q) t += part[q][e];  // fixed order
+    part[0][e] = t;
+  }
   __syncthreads();
   if (threadIdx.x >= 36 || dw == nullptr) return;
   const int pl = threadIdx.x & 3, tap = threadIdx.x >> 2;  // 9 taps x 4 pairs
@@ -392,7 +427,7 @@ __global__ void wgrad_finish_wino_kernel(const float* __restrict__ slabs, int n_
   for (int aa = 0; aa < 4; ++aa) {
     float rowsum = 0.f;
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb) rowsum = fmaf(gc[bb], part[0][(aa * 4 + bb) * 4 + pl], rowsum);
+    for (int bb = 0; bb < 4; ++bb) rowsum = fmaf(gc[bb], part[0][pl * 16 + aa * 4 + bb], rowsum);
     out = fmaf(gr[aa], rowsum, out);
   }
   const long k = p / Ncols, n = p - k * Ncols;
@@ -404,6 +439,12 @@ bool plain_aligned(const unetpp_view& v) {
          (reinterpret_cast<uintptr_t>(v.ptr) & 15) == 0;
 }
 
+// x views: plain, or with the folded BatchNorm load transform (scale + shift + relu together)
+bool x_view_ok(const unetpp_view& v) {
+  if (v.gate != nullptr || ((v.C | v.c_off | v.c_len) & 3) != 0 || (reinterpret_cast<uintptr_t>(v.ptr) & 15) != 0) return false;
+  return v.scale == nullptr ? !v.relu : (v.shift != nullptr && v.relu != 0);
+}
+
 }  // namespace
 
 // 3x3, Winograd not forbidden, 32-wide patches, every view plain and 16-byte aligned, 32-bit byte offsets inside a patch
@@ -413,7 +454,8 @@ bool wgrad_wino_applies(const unetpp_wgrad_desc* d) {
   if (d->n_x < 1 || d->n_x > UNETPP_MAX_VIEWS || d->n_dy < 1 || d->n_dy > UNETPP_MAX_VIEWS) return false;
   for (int i = 0; i < d->n_x; ++i) {
     const unetpp_view& v = d->x[i];
-    if (!view_ok(v) || !plain_aligned(v) || v.c_len < 8) return false;
+    if (!view_ok(v) || !x_view_ok(v) || v.c_len < 8) return false;
+    if ((v.scale != nullptr) != (d->x[0].scale != nullptr)) return false;  // all views transformed, or none
     if (static_cast<long>(kHHp) * v.sy * v.Ws * v.C * 4 >= 0x7fffffffL) return false;
   }
   for (int i = 0; i < d->n_dy; ++i) {
@@ -437,7 +479,10 @@ int launch_wgrad_wino(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_til
   a.tiles_y = g.tiles_y;
   a.n_pix_tiles = static_cast<long>(d->N) * g.tiles_y * g.tiles_x;
   const dim3 grid(static_cast<unsigned>(d->n_split), static_cast<unsigned>(static_cast<long>(k_tiles) * n_tiles_cols));
-  hipLaunchKernelGGL(wgrad_wino_kernel, grid, dim3(kWThreads), 0, st, a);
+  if (d->x[0].scale != nullptr)
+    hipLaunchKernelGGL(wgrad_wino_kernel<true>, grid, dim3(kWThreads), 0, st, a);
+  else
+    hipLaunchKernelGGL(wgrad_wino_kernel<false>, grid, dim3(kWThreads), 0, st, a);
   note_kernel("wgrad_wino_kernel");
   return launch_status();
 }
@@ -446,7 +491,7 @@ int launch_wgrad_finish_wino(const float* slabs, int n_split, int K, int Ncols, 
                              float* db, hipStream_t st) {
   const long pairs = static_cast<long>(K) * Ncols;
   const unsigned blocks = static_cast<unsigned>((pairs + 3) / 4 + (Ncols + 63) / 64);
-  hipLaunchKernelGGL(wgrad_finish_wino_kernel, dim3(blocks), dim3(256), 0, st, slabs, n_split, K, Ncols, dw, d_t, d_k,
+  hipLaunchKernelGGL(wgrad_finish_wino_kernel, dim3(blocks), dim3(1024), 0, st, slabs, n_split, K, Ncols, dw, d_t, d_k,
                      d_n, db);
   return launch_status();
 }
