@@ -399,6 +399,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 
     // ---- current chunk: per channel s the 4x4 window -> B^T d B in registers -> 32 MFMAs; every accumulator is
     // touched once per channel (no back-to-back dependence), the weight fragments are read AHEAD pairs early ----
+    // Raised wave priority for the MFMA phase: the co-resident workgroup's wave on this SIMD is usually in its staging
+    // or epilogue VALU code, and the matrix pipe should never wait behind that (+4 % measured).
+    __builtin_amdgcn_s_setprio(2);
     constexpr int AHEAD = 2;
     f32x2 u[AHEAD + 1];
 #pragma unroll
@@ -434,6 +437,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
         acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi], uc[1], acc[xi][1], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
     if (c_chunk + 1 == a.n_chunks) {
       epilogue(c_unit);  // stores drain while the next unit computes; the next chunk's loads are already in flight
