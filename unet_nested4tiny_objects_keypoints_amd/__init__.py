@@ -13,5 +13,6 @@ library, or with CPU tensors, raises.
 from .unet import UNet_Nested, count_param  # noqa: F401
 from .losses import FocalLoss_BCE_2d  # noqa: F401
 from .step import train_step  # noqa: F401
+from .targets import create_heatmap  # noqa: F401
 
-__all__ = ["UNet_Nested", "count_param", "FocalLoss_BCE_2d", "train_step"]
+__all__ = ["UNet_Nested", "count_param", "FocalLoss_BCE_2d", "train_step", "create_heatmap"]

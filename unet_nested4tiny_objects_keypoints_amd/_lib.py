@@ -15,7 +15,7 @@ _REPO = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.environ.get("UNETPP_LIB", os.path.join(_PKG_DIR, "libunetpp_hip.so"))  # override: kernel A/B runs
 CSRC = os.path.join(_PKG_DIR, "csrc")
 INCLUDE = os.path.join(_REPO, "include")
-SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_wino.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "wgrad_wino.hip", "first_layer.hip", "pointwise.hip")
+SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_wino.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "wgrad_wino.hip", "first_layer.hip", "pointwise.hip", "caller.hip")
 HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h")
 MAX_VIEWS = 8
 ABI_VERSION = 2
@@ -87,6 +87,10 @@ SIGNATURES = {
     "unetpp_head_bwd_blocks": (_I64, [_I64]),
     "unetpp_head_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _I32, _I32, _P, _P]),
     "unetpp_sum_partials": (C.c_int, [_P, _I64, _I64, _P, _P]),
+    "unetpp_focal_bce_blocks": (_I64, [_I64]),
+    "unetpp_focal_bce": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P]),
+    "unetpp_heatmap_workspace_bytes": (_I64, [_I32, _I32, _I32]),
+    "unetpp_create_heatmap": (C.c_int, [_P, _I32, _I32, _I32, _I32, _F, _P, _P, _P]),
     "unetpp_bilinear2x_fwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P]),
     "unetpp_bilinear2x_bwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "unetpp_nchw_to_nhwc": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P]),

@@ -323,3 +323,36 @@ def nhwc_to_nchw(src):
     dst = torch.empty((n, c, h, w), dtype=torch.float32, device=src.device)
     check(_lib.lib().unetpp_nhwc_to_nchw(_ptr(src), n, c, h, w, _ptr(dst), _stream()), "unetpp_nhwc_to_nchw")
     return dst
+
+
+def focal_bce(pred: torch.Tensor, target: torch.Tensor, rows: int, gamma: float, want_grad: bool = True):
+    """FocalLoss_BCE_2d value (0-dim tensor) and d loss / d pred in one pass over (pred, target)."""
+    lib = _lib.lib()
+    _need(pred, "pred")
+    _need(target, "target")
+    if pred.shape != target.shape:
+        raise ValueError("pred and target must have the same shape")
+    n = pred.numel()
+    blocks = int(lib.unetpp_focal_bce_blocks(n))
+    partial = torch.empty(blocks, dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred) if want_grad else None
+    st = _stream()
+    check(lib.unetpp_focal_bce(_ptr(pred), _ptr(target), n, rows, float(gamma), _ptr(grad), _ptr(partial), st),
+          "unetpp_focal_bce")
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    check(lib.unetpp_sum_partials(_ptr(partial), blocks, 1, _ptr(loss), st), "unetpp_sum_partials")
+    return loss.reshape(()), grad
+
+
+def create_heatmap(points: torch.Tensor, height: int, width: int, radius: float = 3.0) -> torch.Tensor:
+    """points [N, P, 2] (x, y) fp32 on the GPU -> target heat maps [N, 4, H, W] (tools/misc/helper.py:87-172)."""
+    lib = _lib.lib()
+    _need(points, "points")
+    if points.dim() != 3 or points.shape[2] != 2 or points.shape[1] < 6:
+        raise ValueError("points must be [N, P >= 6, 2]")
+    n, p = points.shape[0], points.shape[1]
+    out = torch.empty(n, 4, height, width, dtype=torch.float32, device=points.device)
+    ws = torch.empty(int(lib.unetpp_heatmap_workspace_bytes(n, height, width)), dtype=torch.uint8, device=points.device)
+    check(lib.unetpp_create_heatmap(_ptr(points), n, p, height, width, float(radius), _ptr(out), _ptr(ws), _stream()),
+          "unetpp_create_heatmap")
+    return out
