@@ -41,8 +41,8 @@ X00_MB_PER_IMG = 42.2
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=15)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (configs[1]: 32)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--feature-scale", type=float, default=1)

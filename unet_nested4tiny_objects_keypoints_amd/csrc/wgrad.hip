@@ -164,6 +164,30 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ slabs, int n_split
   const long rows = static_cast<long>(taps) * K + 1;
   const long total = rows * Ncols;
   const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long base_blocks = (total + 63) / 64;
+  if (static_cast<long>(blockIdx.x) >= base_blocks) {
+    // extra blocks, 2x2 deconvolution only (n_inner < Ncols): the bias gradient of an output channel is the sum of
+    // its (up to 4) pixel-phase columns -- 16 channels x 4 phases per block, fixed order
+    const int n_outer = Ncols / n_inner;
+    const int o = e >> 4;
+    const long nn = (blockIdx.x - base_blocks) * 16L + (e & 15);
+    float u = 0.f;
+    if (o < n_outer && nn < n_inner)
+      for (int b = g; b < n_split; b += SG) u += slabs[static_cast<long>(b) * total + (rows - 1) * Ncols + o * n_inner + nn];
+    part[g][e] = u;
+    __syncthreads();
+    if (g == 0 && e < 16 && nn < n_inner && db != nullptr) {
+      float t = 0.f;
+      for (int oo = 0; oo < n_outer; ++oo) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < SG; ++q) v += part[q][oo * 16 + e];
+        t += v;
+      }
+      db[nn] = t;
+    }
+    return;
+  }
   const long i = blockIdx.x * 64L + e;
   float s = 0.f;
   if (i < total) {
@@ -186,18 +210,8 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ slabs, int n_split
   for (int q = 0; q < SG; ++q) s += part[q][e];  // fixed order
   const long row = i / Ncols;
   const int nn = static_cast<int>(i - row * Ncols);
-  if (row == rows - 1) {
-    // bias gradient.  Plain convolution (n_inner == Ncols): the sum just formed.  2x2 deconvolution: the four
-    // pixel-phase columns of one output channel are added by the thread of the inner index (fixed order).
-    if (db != nullptr && nn < n_inner) {
-      float t = 0.f;
-      for (int o = nn; o < Ncols; o += n_inner) {
-        float u = 0.f;
-        for (int b = 0; b < n_split; ++b) u += slabs[static_cast<long>(b) * total + row * Ncols + o];
-        t += u;
-      }
-      db[nn] = (n_inner == Ncols) ? s : t;
-    }
+  if (row == rows - 1) {  // bias gradient of a plain convolution: the sum just formed (deconvolution: extra blocks)
+    if (db != nullptr && n_inner == Ncols) db[nn] = s;
     return;
   }
   if (dw == nullptr) return;
@@ -298,7 +312,8 @@ extern "C" int unetpp_wgrad_finish(const float* slabs, int32_t n_split, int32_t 
     return launch_wgrad_finish_wino(slabs, n_split, K, Ncols, dw, d_t, d_k, d_n, db, static_cast<hipStream_t>(stream));
   }
   const long total = (static_cast<long>(taps) * K + 1) * Ncols;
-  const unsigned blocks = static_cast<unsigned>((total + 63) / 64);
+  if (Ncols / n_inner > 4) return UNETPP_EINVAL;  // at most 4 pixel phases per output channel
+  const unsigned blocks = static_cast<unsigned>((total + 63) / 64 + (n_inner != Ncols ? (n_inner + 15) / 16 : 0));
   hipLaunchKernelGGL(wgrad_finish_kernel, dim3(blocks), dim3(1024), 0, static_cast<hipStream_t>(stream), slabs,
                      n_split, taps, K, Ncols, n_inner, dw, d_t, d_k, d_n, d_o, db);
   return launch_status();
