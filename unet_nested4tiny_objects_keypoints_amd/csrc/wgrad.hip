@@ -288,8 +288,8 @@ extern "C" int unetpp_wgrad(const unetpp_wgrad_desc* d, void* stream) {
     const int wino = launch_wgrad_wino(d, a.Ktot, a.Ncols, a.n_tiles_cols, k_tiles, st);  // 16-plane slabs
     if (wino != 1) return wino;
   }
-  if (getenv("UNETPP_NO_WGRAD_DMA") == nullptr) {  // (knob for A/B runs)
-    const int dma = launch_wgrad_dma(d, a.Ktot, a.Ncols, a.n_tiles_cols, k_tiles, st);
+  {
+    const int dma = launch_wgrad_dma(d, a.Ktot, a.Ncols, a.n_tiles_cols, k_tiles, st);  // plain views, direct sum
     if (dma != 1) return dma;
   }
   const int fast = launch_wgrad_fast(d, a.Ktot, a.Ncols, a.n_tiles_cols, k_tiles, st);
