@@ -1,5 +1,6 @@
-// Fast path of the multi-view pixel GEMM (same math and MFMA maps as gemm_pix.hip) for plain, 16-byte
-// aligned input views -- every 3x3 / deconv / 1x1 launch of the network except the 1- or 3-channel first layer.
+// Direct-summation fast path of the multi-view pixel GEMM (same math and MFMA maps as gemm_pix.hip, bit-identical
+// results) for 16-byte aligned input views: the pointwise GEMMs of the 2x2 deconvolution / 1x1 convolution, and the
+// 3x3 convolutions when UNETPP_GEMM_DIRECT forbids the Winograd kernel (gemm_wino.hip).
 //
 // What changes against the generic kernel:
 //   * software pipeline: the global loads of K-chunk c+1 (input patch + weight image) are issued into
@@ -64,9 +65,9 @@ __global__ void pack_image_kernel(const FastArgs a, float* __restrict__ img) {
 }
 
 // NT = column tiles per unit.  3x3 convolutions use NT = 1 (3 workgroups per CU); the pointwise GEMMs of the 2x2
-// deconvolution (K = Cin only, N = 4*Cout) use NT = 2/4 so that one staged input patch feeds 64/128 columns.
+// deconvolution (K = Cin only, N = 4*Cout) use NT = 2 so that one staged input patch feeds 64 columns.
 template <int TAPS, int LOG2TW, int NT>
-__global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : (NT == 2 ? 3 : 2)) : 3)) void gemm_fast_kernel(const FastArgs a) {
+__global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : 3) : 3)) void gemm_fast_kernel(const FastArgs a) {
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
   constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;   // compile-time patch shape: every
   constexpr int HWp = TW + 2 * HALO, HHp = TH + 2 * HALO;        // division below is by a constant
@@ -427,7 +428,7 @@ int launch_gemm_fast(const unetpp_gemm_desc* d, hipStream_t st) {
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     return UNETPP_ELAUNCH;
-  const long per_cu = (d->taps == 1) ? (a.nt_unit == 1 ? 4 : (a.nt_unit == 2 ? 3 : 2)) : 3;  // = the kernel's launch bounds
+  const long per_cu = (d->taps == 1 && a.nt_unit == 1) ? 4 : 3;  // = the kernel's launch bounds
   long workers = (per_cu * cus) & ~7L;
   if (workers < 8) workers = 8;
   const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(kThreads);
@@ -438,7 +439,6 @@ int launch_gemm_fast(const unetpp_gemm_desc* d, hipStream_t st) {
     else hipLaunchKernelGGL((gemm_fast_kernel<T, 3, NTU>), grid, block, 0, st, a);                      \
   } while (0)
   if (d->taps == 9) UNETPP_LAUNCH_FAST(9, 1);
-  else if (a.nt_unit == 4) UNETPP_LAUNCH_FAST(1, 4);
   else if (a.nt_unit == 2) UNETPP_LAUNCH_FAST(1, 2);
   else UNETPP_LAUNCH_FAST(1, 1);
 #undef UNETPP_LAUNCH_FAST

@@ -103,10 +103,9 @@ inline bool fast_args(const unetpp_gemm_desc* d, FastArgs& a, int kc, int ncol =
   a.log2tw = g.log2tw;
   a.tiles_x = g.tiles_x;
   a.tiles_y = g.tiles_y;
-  // column tiles per unit: pointwise GEMMs (deconvolution phases) without a statistics epilogue take 4 or 2
-  a.nt_unit = 1;
-  if (d->taps == 1 && d->stats_partial == nullptr) a.nt_unit = (a.n_tiles % 4 == 0) ? 4 : ((a.n_tiles % 2 == 0) ? 2 : 1);
-  if (a.nt_unit > 2) a.nt_unit = 2;  // measured: 2 tiles x 3 workgroups per CU beats 4 tiles x 2 on the deconvolutions
+  // column tiles per unit: pointwise GEMMs (deconvolution phases) without a statistics epilogue take 2 (measured:
+  // 2 tiles x 3 workgroups per CU beats 4 tiles x 2 and 1 tile x 4 on the deconvolutions)
+  a.nt_unit = (d->taps == 1 && d->stats_partial == nullptr && a.n_tiles % 2 == 0) ? 2 : 1;
   a.n_groups = a.n_tiles / a.nt_unit;
   a.total_blocks = static_cast<long>(d->N) * g.tiles_y * g.tiles_x * a.n_groups;
   return a.total_blocks <= 0x7fffffffL;
