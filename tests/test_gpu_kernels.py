@@ -134,7 +134,8 @@ def test_fast_and_generic_gemm_agree(dev, shape):
 
 @pytest.mark.parametrize("shape", [(2, 32, 32, [32], 32), (1, 64, 64, [32, 32, 32, 32], 32), (2, 8, 8, [16, 8, 8], 40),
                                    (1, 24, 40, [8], 4), (3, 16, 16, [64, 32], 96), (2, 3, 5, [12], 16),
-                                   (1, 37, 21, [20, 4], 36), (1, 128, 128, [64], 64)])
+                                   (1, 37, 21, [20, 4], 36), (1, 128, 128, [64], 64),
+                                   (2, 32, 32, [16], 16), (1, 64, 32, [32, 8], 16)])  # <= 16 columns: half-tile kernel
 def test_winograd_matches_direct(dev, shape):
     """Winograd F(2x2,3x3) and direct summation are the same convolution up to fp32 rounding: outputs within 2e-6 of
     the largest magnitude (odd image sizes, ragged patches, partial column tiles and K chunks included), BatchNorm

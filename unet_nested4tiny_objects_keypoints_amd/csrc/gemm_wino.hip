@@ -79,7 +79,9 @@ __global__ void pack_wino_kernel(const FastArgs a, float* __restrict__ img) {
   img[i] = u;
 }
 
-template <int LOG2TW>
+// NH = 16-column halves of the tile that are computed: 2, or 1 when no output view is wider than 16 channels (narrow
+// networks, e.g. the reference's default base width 16) -- the second half would multiply zero weights.
+template <int LOG2TW, int NH>
 __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a) {
   constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;
   constexpr int HWp = TW + 2, HHp = TH + 2;
@@ -123,11 +125,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   const int a_base = ((2 * (my_tile / TXN)) * HWp + 2 * (my_tile % TXN)) * WP + 2 * g;  // channel 2g (+s)
   const int b_base = (g * 16 + t16) * 2;
 
-  f32x4 acc[16][2];
+  f32x4 acc[16][NH];
 #pragma unroll
   for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
-    for (int nh = 0; nh < 2; ++nh) acc[xi][nh] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nh = 0; nh < NH; ++nh) acc[xi][nh] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- prefetch side (same scheme as gemm_fast.hip): the chunk that is loaded next ----
   f32x4 reg_in[IN_ITEMS], reg_w[W_ITEMS];
@@ -231,12 +233,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
     // bias folded into M[1][1]: its weight is +1 in all four outputs
 #pragma unroll
-    for (int nh = 0; nh < 2; ++nh) {
+    for (int nh = 0; nh < NH; ++nh) {
       const float bj = (d.bias != nullptr && t16 + 16 * nh < tc.n_cnt) ? d.bias[tc.n0 + t16 + 16 * nh] : 0.f;
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) acc[5][nh][rr] += bj;
     }
-    if (interior && vec_out && tc.n_cnt == WNC) {
+    if (interior && vec_out && tc.n_cnt == 16 * NH) {
       // ---- lean path (whole patch inside the image, all 32 columns, 16-byte stores): no per-element predicates.
       // Transpose scratch per wave: [pixel slot (rr, bp, g)][32 columns], column half XOR (g>>1): the 64 lanes of a
       // store hit 64 distinct banks. ----
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
-          for (int nh = 0; nh < 2; ++nh) {
+          for (int nh = 0; nh < NH; ++nh) {
             float tb[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b)
@@ -271,6 +273,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
           const unsigned py = 2 * (tile / TXN) + ap, px = 2 * (tile % TXN) + ((ps >> 2) & 1);
           const unsigned off = py * rs + px * cs + q4;
           f32x4 v = *reinterpret_cast<const f32x4*>(&scratch[ps * 32 + (q4 ^ ((gg >> 1) << 4))]);
+          if (q4 >= 16 * NH) continue;  // NH = 1: only 16 columns exist
           if (gbase != nullptr) {
             const f32x4 gt = *reinterpret_cast<const f32x4*>(gbase + off);
             if (!O.gate_sum) {
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
           const int tile = 16 * wave + 4 * g + rr;
           const int py = 2 * (tile / TXN) + ap, px0 = 2 * (tile % TXN);
 #pragma unroll
-          for (int nh = 0; nh < 2; ++nh) {
+          for (int nh = 0; nh < NH; ++nh) {
             float tb[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b)
@@ -331,10 +334,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
-      for (int nh = 0; nh < 2; ++nh) acc[xi][nh] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int nh = 0; nh < NH; ++nh) acc[xi][nh] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (want_stats) {  // the LDS tiles are free here (barrier after the MFMA loop)
 #pragma unroll
-      for (int nh = 0; nh < 2; ++nh) {
+      for (int nh = 0; nh < NH; ++nh) {
         s1[nh] += __shfl_xor(s1[nh], 16);
         s2[nh] += __shfl_xor(s2[nh], 16);
         s1[nh] += __shfl_xor(s1[nh], 32);
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
           u[(step + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const f32x2*>(&w_tile[(step + AHEAD) * 128 + b_base]);
         const f32x2 uc = u[step % (AHEAD + 1)];
         acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi], uc[0], acc[xi][0], 0, 0, 0);
-        acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi], uc[1], acc[xi][1], 0, 0, 0);
+        if (NH == 2) acc[xi][NH - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi], uc[1], acc[xi][NH - 1], 0, 0, 0);
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -484,9 +487,17 @@ int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
   long workers = (2L * cus) & ~7L;  // persistent grid: two workgroups per CU (= the kernel's launch bounds)
   if (workers < 8) workers = 8;
   const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(kThreads);
-  if (a.log2tw == 5) hipLaunchKernelGGL((gemm_wino_kernel<5>), grid, block, 0, st, a);
-  else if (a.log2tw == 4) hipLaunchKernelGGL((gemm_wino_kernel<4>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((gemm_wino_kernel<3>), grid, block, 0, st, a);
+  bool narrow = true;  // no output view wider than 16 channels: the second column half is never used
+  for (int i = 0; i < d->n_out; ++i) narrow = narrow && d->out[i].c_len <= 16;
+#define UNETPP_LAUNCH_WINO(L)                                                                          \
+  do {                                                                                                 \
+    if (narrow) hipLaunchKernelGGL((gemm_wino_kernel<L, 1>), grid, block, 0, st, a);                   \
+    else hipLaunchKernelGGL((gemm_wino_kernel<L, 2>), grid, block, 0, st, a);                          \
+  } while (0)
+  if (a.log2tw == 5) UNETPP_LAUNCH_WINO(5);
+  else if (a.log2tw == 4) UNETPP_LAUNCH_WINO(4);
+  else UNETPP_LAUNCH_WINO(3);
+#undef UNETPP_LAUNCH_WINO
   note_kernel("gemm_wino_kernel");
   return launch_status();
 }
