@@ -91,8 +91,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   constexpr int IN_ITEMS = (NPIX * 2 + kThreads - 1) / kThreads;  // 16-byte items, 2 per pixel (<= 3)
   constexpr int W_ITEMS = WIMG / 4 / kThreads;                    // 4
   static_assert(kMaxHaloPixels * WP <= IN_FLOATS, "input patch does not fit");
-  __shared__ __attribute__((aligned(16))) float smem[IN_FLOATS + WIMG];
-  float* in_tile = smem;
+  // Two (input patch, weight image) buffers: the next chunk is written into the other buffer in the MIDDLE of the
+  // current chunk's MFMA phase (its loads were issued at the top of the chunk), so a chunk costs one barrier.
+  constexpr int BUF = IN_FLOATS + WIMG;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+  float* in_tile = smem;             // buffers of the chunk being computed
   float* w_tile = smem + IN_FLOATS;
 
   const unetpp_gemm_desc& d = a.d;
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 #pragma unroll
     for (int q = 0; q < W_ITEMS; ++q) reg_w[q] = *reinterpret_cast<const f32x4*>(wp + (tid + q * kThreads) * 4);
   };
-  auto store_chunk = [&]() {
+  auto store_chunk = [&](float* in_dst, float* w_dst) {
     const unetpp_view& V = d.in[p_s];
     const bool affine = V.scale != nullptr;  // BatchNorm apply + ReLU folded into the operand load
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -207,12 +210,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = keep ? fmaxf(v[e], floor_v) : 0.f;  // zero padding AFTER the transform
       if (it < NPIX * 2) {  // 40-byte pixel rows: two 8-byte stores
-        *reinterpret_cast<f32x2*>(&in_tile[(it >> 1) * WP + cc]) = f32x2{v[0], v[1]};
-        *reinterpret_cast<f32x2*>(&in_tile[(it >> 1) * WP + cc + 2]) = f32x2{v[2], v[3]};
+        *reinterpret_cast<f32x2*>(&in_dst[(it >> 1) * WP + cc]) = f32x2{v[0], v[1]};
+        *reinterpret_cast<f32x2*>(&in_dst[(it >> 1) * WP + cc + 2]) = f32x2{v[2], v[3]};
       }
     }
 #pragma unroll
-    for (int q = 0; q < W_ITEMS; ++q) *reinterpret_cast<f32x4*>(&w_tile[(tid + q * kThreads) * 4]) = reg_w[q];
+    for (int q = 0; q < W_ITEMS; ++q) *reinterpret_cast<f32x4*>(&w_dst[(tid + q * kThreads) * 4]) = reg_w[q];
   };
 
   // ---- epilogue of a finished unit: output transform, bias / ReLU / gate / accumulate, BatchNorm partial sums ----
@@ -366,11 +369,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   prefetch_unit(0);
   view_offsets(d.in[0]);
   load_chunk();
-  store_chunk();
+  store_chunk(in_tile, w_tile);
   __syncthreads();
 
   long c_unit = 0;  // compute side: unit and chunk currently in LDS
   int c_chunk = 0;
+  int cur = 0;      // buffer being computed from
   while (true) {
     // ---- advance the prefetch cursor: next chunk of this unit, or chunk 0 of the next unit ----
     bool more = true;
@@ -439,20 +443,25 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
         acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi], uc[0], acc[xi][0], 0, 0, 0);
         if (NH == 2) acc[xi][NH - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi], uc[1], acc[xi][NH - 1], 0, 0, 0);
       }
+      if (s == 0) {  // the next chunk's registers -> the other buffer, half way through this chunk's MFMAs
+        float* nxt = smem + (cur ^ 1) * BUF;
+        store_chunk(nxt, nxt + IN_FLOATS);
+      }
     }
     __builtin_amdgcn_s_setprio(0);
-    __syncthreads();
+    __syncthreads();  // all waves: done reading the current buffers, next buffers written
     if (c_chunk + 1 == a.n_chunks) {
-      epilogue(c_unit);  // stores drain while the next unit computes; the next chunk's loads are already in flight
-      __syncthreads();   // the epilogue used the input tile as transpose scratch
+      epilogue(c_unit);  // the current buffers are its scratch; stores drain while the next unit computes
+      __syncthreads();   // before the next chunk's staging overwrites that scratch
       ++c_unit;
       c_chunk = 0;
     } else {
       ++c_chunk;
     }
     if (!more) break;
-    store_chunk();
-    __syncthreads();
+    cur ^= 1;
+    in_tile = smem + cur * BUF;
+    w_tile = in_tile + IN_FLOATS;
   }
 }
 
