@@ -86,24 +86,8 @@ __global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : 3) : 3)) void
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
 
-  // ---- this workgroup's units: XCD x = blockIdx & 7 owns a contiguous range of units (neighbouring patches
-  // share an L2), its workgroups take them round-robin ----
-  const long W8 = gridDim.x >> 3;  // workgroups per XCD label (the launcher makes gridDim.x a multiple of 8
-                                   // whenever a workgroup has more than one unit)
-  long first_unit, unit_step, my_units;
-  if (gridDim.x >= a.total_blocks) {
-    first_unit = xcd_remap(blockIdx.x, a.total_blocks);
-    unit_step = 0;
-    my_units = 1;
-  } else {
-    const long q = a.total_blocks >> 3, r = a.total_blocks & 7;
-    const long xcd = blockIdx.x & 7, widx = blockIdx.x >> 3;
-    const long start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    const long cnt = q + (xcd < r ? 1 : 0);
-    first_unit = start + widx;
-    unit_step = W8;
-    my_units = widx < cnt ? (cnt - widx + W8 - 1) / W8 : 0;
-  }
+  const UnitRange ur = my_unit_range(a.total_blocks);  // XCD-contiguous ranges, round-robin inside an XCD
+  const long first_unit = ur.first, unit_step = ur.step, my_units = ur.count;
   if (my_units == 0) return;
 
   int apix[2];

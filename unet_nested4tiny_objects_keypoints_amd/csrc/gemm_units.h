@@ -137,4 +137,25 @@ __device__ __forceinline__ UnitRange my_unit_range(long total_blocks) {
   return u;
 }
 
+// The same XCD ranges, but every workgroup takes a CONTIGUOUS piece (unit order: column tile fastest), so successive
+// units of a workgroup mostly share the pixel patch and its geometry can be reused (gemm_wino.hip).
+__device__ __forceinline__ UnitRange my_contiguous_unit_range(long total_blocks) {
+  UnitRange u;
+  const long W8 = gridDim.x >> 3;
+  u.step = 1;
+  if (gridDim.x >= total_blocks) {
+    u.first = xcd_remap(blockIdx.x, total_blocks);
+    u.count = 1;
+  } else {
+    const long q = total_blocks >> 3, r = total_blocks & 7;
+    const long xcd = blockIdx.x & 7, widx = blockIdx.x >> 3;
+    const long start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const long cnt = q + (xcd < r ? 1 : 0);
+    const long per = cnt / W8, rem = cnt % W8;
+    u.first = start + widx * per + (widx < rem ? widx : rem);
+    u.count = per + (widx < rem ? 1 : 0);
+  }
+  return u;
+}
+
 }  // namespace unetpp

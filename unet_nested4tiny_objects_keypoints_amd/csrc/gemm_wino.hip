@@ -102,25 +102,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, t16 = lane & 15, g = lane >> 4;
 
-  // this workgroup's units: XCD x = blockIdx & 7 owns a contiguous range of units and each of its workgroups a
-  // CONTIGUOUS piece of it (unit order: column tile fastest), so successive units mostly share the pixel patch
-  UnitRange ur;
-  {
-    const long W8 = gridDim.x >> 3;
-    if (gridDim.x >= a.total_blocks) {
-      ur.first = xcd_remap(blockIdx.x, a.total_blocks);
-      ur.count = 1;
-    } else {
-      const long q = a.total_blocks >> 3, r = a.total_blocks & 7;
-      const long xcd = blockIdx.x & 7, widx = blockIdx.x >> 3;
-      const long start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-      const long cnt = q + (xcd < r ? 1 : 0);
-      const long per = cnt / W8, rem = cnt % W8;
-      ur.first = start + widx * per + (widx < rem ? widx : rem);
-      ur.count = per + (widx < rem ? 1 : 0);
-    }
-    ur.step = 1;
-  }
+  const UnitRange ur = my_contiguous_unit_range(a.total_blocks);
   if (ur.count == 0) return;
 
   // compute side: this lane's tile (A operand / input transform) and weight-image slot (B operand)
