@@ -190,11 +190,11 @@ int unetpp_bilinear2x_bwd(const float* dy, int32_t N, int32_t H, int32_t W, int3
 /* ---- caller side of the training step (trainer/trainer.py:114-136) -------------------------- */
 /* FocalLoss_BCE_2d (tools/losses/focal_loss.py:255-301, size_average = False), value and gradient in one pass:
  * e = 1 - |pred - target| + 1e-20;  loss = sum(-(1 - e)^gamma log e) / rows;  rows = N*C of the [N,C,H,W] heads.
- * partial[unetpp_focal_bce_blocks(n)] receives per-block sums already divided by rows (finish with
- * unetpp_sum_partials); grad (may be NULL) receives dloss/dpred.  pred/target/grad 16-byte aligned, n elements. */
+ * partial[unetpp_focal_bce_blocks(n)] is workspace (per-block sums, added in fixed order); loss[0] receives the
+ * value, grad (may be NULL) dloss/dpred.  pred/target/grad 16-byte aligned, n elements. */
 int64_t unetpp_focal_bce_blocks(int64_t n);
 int unetpp_focal_bce(const float* pred, const float* target, int64_t n, int64_t rows, float gamma, float* grad,
-                     float* partial, void* stream);
+                     float* partial, float* loss, void* stream);
 /* create_heatmap (tools/misc/helper.py:87-172): key points [N][P][2] as (x, y), P >= 6 -> float32 [N,4,H,W]:
  * ch0 = point 0, ch1 = points 1..3 summed / max, ch2 = point 4, ch3 = points 5..P-1 summed / max, each map
  * exp(-0.5 sqrt(dx^2 + dy^2) / radius) (the reference uses radius 3).  workspace: unetpp_heatmap_workspace_bytes(). */

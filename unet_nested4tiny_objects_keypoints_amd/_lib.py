@@ -88,7 +88,7 @@ SIGNATURES = {
     "unetpp_head_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _I32, _I32, _P, _P]),
     "unetpp_sum_partials": (C.c_int, [_P, _I64, _I64, _P, _P]),
     "unetpp_focal_bce_blocks": (_I64, [_I64]),
-    "unetpp_focal_bce": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P]),
+    "unetpp_focal_bce": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _P]),
     "unetpp_heatmap_workspace_bytes": (_I64, [_I32, _I32, _I32]),
     "unetpp_create_heatmap": (C.c_int, [_P, _I32, _I32, _I32, _I32, _F, _P, _P, _P]),
     "unetpp_bilinear2x_fwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P]),

@@ -73,6 +73,21 @@ __global__ __launch_bounds__(kLossThreads) void focal_bce_kernel(const float* __
   if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_rows;
 }
 
+// one block: loss = sum of the per-block partials, fixed order (1024 strided sums, then an LDS tree)
+__global__ __launch_bounds__(1024) void focal_bce_finish_kernel(const float* __restrict__ partial, long n_blocks,
+                                                                float* __restrict__ loss) {
+  __shared__ float red[1024];
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n_blocks; i += 1024) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 512; w >= 1; w >>= 1) {
+    if (static_cast<int>(threadIdx.x) < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = red[0];
+}
+
 // grid (blocks per image, N): unnormalised maps of the 4 channels + per-block maxima of channels 1 and 3
 __global__ __launch_bounds__(256) void heatmap_kernel(const float* __restrict__ points, int P, int H, int W, double radius,
                                                       float* __restrict__ out, float* __restrict__ scratch,
@@ -159,8 +174,8 @@ extern "C" int64_t unetpp_focal_bce_blocks(int64_t n) {
 }
 
 extern "C" int unetpp_focal_bce(const float* pred, const float* target, int64_t n, int64_t rows, float gamma, float* grad,
-                                float* partial, void* stream) {
-  if (pred == nullptr || target == nullptr || partial == nullptr || n < 1 || rows < 1) return UNETPP_EINVAL;
+                                float* partial, float* loss, void* stream) {
+  if (pred == nullptr || target == nullptr || partial == nullptr || loss == nullptr || n < 1 || rows < 1) return UNETPP_EINVAL;
   if (((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target) | reinterpret_cast<uintptr_t>(grad)) & 15) != 0)
     return UNETPP_EINVAL;
   const int64_t blocks = unetpp_focal_bce_blocks(n);
@@ -168,6 +183,8 @@ extern "C" int unetpp_focal_bce(const float* pred, const float* target, int64_t 
   hipLaunchKernelGGL(focal_bce_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kLossThreads), 0,
                      static_cast<hipStream_t>(stream), pred, target, static_cast<long>(n), gamma,
                      1.f / static_cast<float>(rows), grad, partial);
+  hipLaunchKernelGGL(focal_bce_finish_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), partial,
+                     static_cast<long>(blocks), loss);
   return launch_status();
 }
 

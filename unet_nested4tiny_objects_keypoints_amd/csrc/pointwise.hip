@@ -611,22 +611,22 @@ __global__ __launch_bounds__(kThreads, 4) void head_bwd_vec_kernel(const float* 
 }
 
 __global__ void sum_partials_kernel(const float* __restrict__ partial, long n_blocks, long len, float* __restrict__ out) {
-  // 64 outputs x 16 row groups per workgroup (1024 threads), 4 loads in flight per thread; the groups are
-  // combined through LDS in fixed order
-  __shared__ double part[16][64];
-  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const long i = blockIdx.x * 64L + e;
+  // 16 outputs x 64 row groups per workgroup (1024 threads): a thread adds n_blocks / 64 rows (4 loads in flight);
+  // the groups are combined through LDS in fixed order.  fp64 sums: thousands of same-sign partials.
+  __shared__ double part[64][16];
+  const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const long i = blockIdx.x * 16L + e;
   double s = 0.0;
   if (i < len) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     long b = g;
-    for (; b + 48 < n_blocks; b += 64) {
+    for (; b + 192 < n_blocks; b += 256) {
       s0 += static_cast<double>(partial[b * len + i]);
-      s1 += static_cast<double>(partial[(b + 16) * len + i]);
-      s2 += static_cast<double>(partial[(b + 32) * len + i]);
-      s3 += static_cast<double>(partial[(b + 48) * len + i]);
+      s1 += static_cast<double>(partial[(b + 64) * len + i]);
+      s2 += static_cast<double>(partial[(b + 128) * len + i]);
+      s3 += static_cast<double>(partial[(b + 192) * len + i]);
     }
-    for (; b < n_blocks; b += 16) s0 += static_cast<double>(partial[b * len + i]);
+    for (; b < n_blocks; b += 64) s0 += static_cast<double>(partial[b * len + i]);
     s = (s0 + s1) + (s2 + s3);
   }
   part[g][e] = s;
@@ -634,7 +634,7 @@ __global__ void sum_partials_kernel(const float* __restrict__ partial, long n_bl
   if (g == 0 && i < len) {
     double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += part[k][e];
+    for (int k = 0; k < 64; ++k) t += part[k][e];
     out[i] = static_cast<float>(t);
   }
 }
@@ -942,7 +942,7 @@ extern "C" int unetpp_head_bwd(const float* d_out_nchw, const float* out_nchw, c
 
 extern "C" int unetpp_sum_partials(const float* partial, int64_t n_blocks, int64_t len, float* out, void* stream) {
   if (!partial || !out || n_blocks < 1 || len < 1) return UNETPP_EINVAL;
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(static_cast<unsigned>((len + 63) / 64)), dim3(1024), 0, ST(stream),
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(static_cast<unsigned>((len + 15) / 16)), dim3(1024), 0, ST(stream),
                      partial, n_blocks, len, out);
   return launch_status();
 }

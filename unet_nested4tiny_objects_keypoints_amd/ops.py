@@ -336,11 +336,9 @@ def focal_bce(pred: torch.Tensor, target: torch.Tensor, rows: int, gamma: float,
     blocks = int(lib.unetpp_focal_bce_blocks(n))
     partial = torch.empty(blocks, dtype=torch.float32, device=pred.device)
     grad = torch.empty_like(pred) if want_grad else None
-    st = _stream()
-    check(lib.unetpp_focal_bce(_ptr(pred), _ptr(target), n, rows, float(gamma), _ptr(grad), _ptr(partial), st),
-          "unetpp_focal_bce")
     loss = torch.empty(1, dtype=torch.float32, device=pred.device)
-    check(lib.unetpp_sum_partials(_ptr(partial), blocks, 1, _ptr(loss), st), "unetpp_sum_partials")
+    check(lib.unetpp_focal_bce(_ptr(pred), _ptr(target), n, rows, float(gamma), _ptr(grad), _ptr(partial), _ptr(loss),
+                               _stream()), "unetpp_focal_bce")
     return loss.reshape(()), grad
 
 
