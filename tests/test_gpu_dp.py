@@ -103,3 +103,55 @@ def test_two_rank_step_matches_averaged_oracle(tmp_path):
     k = "final_3.weight"
     assert float((ref.final_3.weight.grad - grads[0][k]).abs().max()) < 1e-4 * float(grads[0][k].abs().max())
     assert not is_pre_bn_bias(k, CTOR)
+
+
+def _rccl_worker(rank, port, state, out_dir):
+    import torch.distributed as dist
+
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, UNet_Nested, dp, train_step
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)  # nccl = RCCL on ROCm
+    try:
+        res = {}
+        for tag, hook in (("plain", False), ("rccl", True)):
+            m = UNet_Nested(**CTOR)
+            m.load_state_dict(state)
+            m = m.to(dev).train()
+            m.drop_out.eval()
+            buckets = 0
+            if hook:
+                avg = dp.make_data_parallel(m, bucket_bytes=16 << 10, always_reduce=True)
+            g = torch.Generator().manual_seed(300)
+            x = torch.randn(2, 1, 32, 32, generator=g).to(dev)
+            t = torch.rand(2, 4, 32, 32, generator=g).to(dev)
+            opt = torch.optim.SGD(m.parameters(), lr=0.05)
+            train_step(m, opt, FocalLoss_BCE_2d(gamma=3, size_average=False), x, t)
+            torch.cuda.synchronize()
+            if hook:
+                buckets = len(avg.buckets_last_step)
+            res[tag] = {k: p.detach().cpu() for k, p in m.named_parameters()}
+            res[tag + "_buckets"] = buckets
+        torch.save(res, os.path.join(out_dir, "rccl.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_collective_path_world_of_one(tmp_path):
+    """The bucketed all-reduces on the side stream through the real RCCL backend (a world of one on the 1-GPU box:
+    the reduction is the identity, so the step must equal the unhooked step bit for bit)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+
+    from oracle.unet_nested_oracle import UNetNestedOracle
+    torch.manual_seed(9)
+    state = {k: v.clone() for k, v in UNetNestedOracle(**CTOR).state_dict().items()}
+    mp.spawn(_rccl_worker, args=(_free_port(), state, str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(tmp_path / "rccl.pt")
+    assert r["rccl_buckets"] >= 2
+    for k in r["plain"]:
+        assert torch.equal(r["plain"][k], r["rccl"][k]), k

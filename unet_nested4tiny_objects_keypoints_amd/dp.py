@@ -58,8 +58,10 @@ class GradientAverager:
     """Flat gradient buffer + bucketed, overlapped all-reduce.  Works on any backend (nccl = RCCL on ROCm;
     gloo on CPU for tests, where the 'side stream' degenerates to in-order execution)."""
 
-    def __init__(self, params: Sequence[torch.nn.Parameter], process_group=None, bucket_bytes: int = 2 << 20):
+    def __init__(self, params: Sequence[torch.nn.Parameter], process_group=None, bucket_bytes: int = 2 << 20,
+                 always_reduce: bool = False):
         self.params = list(params)
+        self.always_reduce = always_reduce  # issue the collectives even in a world of one (backend smoke tests)
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         dev = self.params[0].device
@@ -123,7 +125,7 @@ class GradientAverager:
         chunk = self.flat[self._sent_upto:upto]
         self.buckets_last_step.append((self._sent_upto, upto))
         self._sent_upto = upto
-        if self.world == 1:
+        if self.world == 1 and not self.always_reduce:
             return
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream())  # the slice's wgrad kernels are enqueued before this
@@ -155,7 +157,8 @@ def broadcast_parameters(model, src: int = 0, process_group=None) -> None:
         dist.broadcast(t.data, src=src, group=process_group)
 
 
-def make_data_parallel(model, process_group=None, bucket_bytes: int = 2 << 20) -> GradientAverager:
+def make_data_parallel(model, process_group=None, bucket_bytes: int = 2 << 20,
+                       always_reduce: bool = False) -> GradientAverager:
     """Broadcast rank 0's parameters/buffers, then hook the gradient averager into the model's backward."""
     broadcast_parameters(model, 0, process_group)
-    return GradientAverager(ready_order(model), process_group, bucket_bytes).attach(model)
+    return GradientAverager(ready_order(model), process_group, bucket_bytes, always_reduce).attach(model)
