@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNETPP_ABI_VERSION 2
+#define UNETPP_ABI_VERSION 3
 #define UNETPP_MAX_VIEWS 8
 
 #define UNETPP_OK 0
@@ -71,7 +71,7 @@ typedef struct unetpp_gemm_desc {
   int32_t reserved; /* 0 */
   unetpp_view in[UNETPP_MAX_VIEWS];
   unetpp_view out[UNETPP_MAX_VIEWS];
-  const float* weight; /* packed [taps][K][Ncols] (see unetpp_pack_weight) */
+  const float* weight; /* packed [taps][K][Ncols] (see unetpp_pack_weight); may be NULL when weight_image is set */
   const float* bias;   /* [Ncols] or NULL */
   /* optional BatchNorm statistics epilogue: per pixel-block partial (sum, sum of squares) of the
    * stored values, [unetpp_gemm_pixel_blocks()][Ncols][2]; requires n_out == 1. */
@@ -113,7 +113,32 @@ int unetpp_gemm_fwd(const unetpp_gemm_desc* d, void* stream);
  * multiples of 4; an affine + ReLU load transform is allowed).  Returns the image size in floats, or 0 when the
  * descriptor must use the generic kernel. */
 int64_t unetpp_gemm_weight_image_floats(const unetpp_gemm_desc* d);
-int unetpp_gemm_pack_weight_image(const unetpp_gemm_desc* d, float* image, void* stream);
+int unetpp_gemm_pack_weight_image(const unetpp_gemm_desc* d, float* image, void* stream); /* from d->weight (packed) */
+/* The same image built straight from a parameter in its torch layout (no unetpp_pack_weight pass; d->weight may be
+ * NULL for a launch that carries a weight image).  Element W[tap][k][n] of the GEMM weight is read at
+ *   src[tap' * s_t + (k % k_inner) * s_k + (k / k_inner) * s_ko + (n % n_inner) * s_n + (n / n_inner) * s_no],
+ * tap' = flip ? taps-1-tap : tap; k_inner / n_inner = 0 mean "no split".  nn.Conv2d [co,ci,3,3] forward:
+ * (s_t,s_k,s_n) = (1, 9, 9ci); its input gradient: flip, (1, 9ci, 9); nn.ConvTranspose2d [ci,co,2,2] forward
+ * (N = phase*co + c): s_k = 4co, n_inner = co, s_n = 4, s_no = 1; its input gradient (K = phase*co + c): k_inner = co,
+ * s_k = 4, s_ko = 1, s_n = 4co. */
+typedef struct unetpp_weight_src {
+  const float* src;
+  int64_t s_t, s_k, s_ko, s_n, s_no;
+  int32_t k_inner, n_inner, flip, reserved;
+} unetpp_weight_src;
+int unetpp_gemm_pack_weight_image_from(const unetpp_gemm_desc* d, const unetpp_weight_src* src, float* image, void* stream);
+/* Many images in ONE launch (all launches of a forward or backward pass): a table of jobs in DEVICE memory.  A job
+ * carries what the image layout depends on -- taps, flags and the channel counts of the launch's input / output views
+ * (must describe a launch for which unetpp_gemm_weight_image_floats() > 0) -- plus source and destination.
+ * max_image_floats = the largest image of the table (sizes the grid). */
+typedef struct unetpp_pack_job {
+  unetpp_weight_src src;
+  float* image;
+  int32_t taps, flags, n_in, n_out;
+  int32_t in_len[UNETPP_MAX_VIEWS], out_len[UNETPP_MAX_VIEWS];
+} unetpp_pack_job;
+int unetpp_gemm_pack_weight_images(const unetpp_pack_job* jobs_device, int32_t n_jobs, int64_t max_image_floats,
+                                   void* stream);
 
 int32_t unetpp_wgrad_max_split(int32_t N, int32_t H, int32_t W);
 /* Planes per slab the kernel chosen for this descriptor writes: `taps` for direct summation, 16 for the Winograd

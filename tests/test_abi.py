@@ -41,7 +41,7 @@ def test_exported_symbols_are_plain_c(built_lib):
     out = subprocess.run(["nm", "-D", "--defined-only", built_lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
     assert set(_declared_functions()) <= exported
-    assert built_lib.lib().unetpp_abi_version() == built_lib.ABI_VERSION == 2
+    assert built_lib.lib().unetpp_abi_version() == built_lib.ABI_VERSION == 3
     assert built_lib.lib().unetpp_build_arch() == b"gfx950"
 
 
@@ -49,17 +49,19 @@ def test_struct_layout_matches_header(built_lib, tmp_path):
     """sizeof/offsetof from a C compile of the header vs the ctypes mirrors."""
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "unetpp_hip.h"\nint main(void){'
-                   'printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(unetpp_view), offsetof(unetpp_view, gate),'
+                   'printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(unetpp_view), offsetof(unetpp_view, gate),'
                    'offsetof(unetpp_view, gate_sum), sizeof(unetpp_gemm_desc), offsetof(unetpp_gemm_desc, out),'
                    'offsetof(unetpp_gemm_desc, weight_image), sizeof(unetpp_wgrad_desc), offsetof(unetpp_wgrad_desc, dy),'
-                   'offsetof(unetpp_wgrad_desc, slabs));return 0;}')
+                   'offsetof(unetpp_wgrad_desc, slabs), sizeof(unetpp_weight_src), offsetof(unetpp_weight_src, k_inner),'
+                   'sizeof(unetpp_pack_job), offsetof(unetpp_pack_job, image), offsetof(unetpp_pack_job, out_len));return 0;}')
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
     L = built_lib
     want = [ctypes.sizeof(L.View), L.View.gate.offset, L.View.gate_sum.offset, ctypes.sizeof(L.GemmDesc),
             L.GemmDesc.out.offset, L.GemmDesc.weight_image.offset, ctypes.sizeof(L.WgradDesc), L.WgradDesc.dy.offset,
-            L.WgradDesc.slabs.offset]
+            L.WgradDesc.slabs.offset, ctypes.sizeof(L.WeightSrc), L.WeightSrc.k_inner.offset, ctypes.sizeof(L.PackJob),
+            L.PackJob.image.offset, L.PackJob.out_len.offset]
     assert got == want
 
 

@@ -15,10 +15,10 @@ _REPO = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.environ.get("UNETPP_LIB", os.path.join(_PKG_DIR, "libunetpp_hip.so"))  # override: kernel A/B runs
 CSRC = os.path.join(_PKG_DIR, "csrc")
 INCLUDE = os.path.join(_REPO, "include")
-SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_wino.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "wgrad_wino.hip", "first_layer.hip", "pointwise.hip", "caller.hip")
+SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_wino.hip", "weight_image.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "wgrad_wino.hip", "first_layer.hip", "pointwise.hip", "caller.hip")
 HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h")
 MAX_VIEWS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 # packed-f32 VALU (SLP-vectorised add pairs) costs issue slots beside MFMAs: keep the Winograd transforms scalar
 EXTRA_FLAGS = {"gemm_wino.hip": ("-fno-slp-vectorize",), "wgrad_wino.hip": ("-fno-slp-vectorize",)}
 GEMM_DIRECT = 1  # unetpp_gemm_desc.flags: direct summation only (no Winograd)
@@ -48,6 +48,25 @@ class GemmDesc(C.Structure):
     ]
 
 
+class WeightSrc(C.Structure):
+    """mirror of struct unetpp_weight_src"""
+    _fields_ = [
+        ("src", C.c_void_p),
+        ("s_t", C.c_int64), ("s_k", C.c_int64), ("s_ko", C.c_int64), ("s_n", C.c_int64), ("s_no", C.c_int64),
+        ("k_inner", C.c_int32), ("n_inner", C.c_int32), ("flip", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class PackJob(C.Structure):
+    """mirror of struct unetpp_pack_job"""
+    _fields_ = [
+        ("src", WeightSrc),
+        ("image", C.c_void_p),
+        ("taps", C.c_int32), ("flags", C.c_int32), ("n_in", C.c_int32), ("n_out", C.c_int32),
+        ("in_len", C.c_int32 * MAX_VIEWS), ("out_len", C.c_int32 * MAX_VIEWS),
+    ]
+
+
 class WgradDesc(C.Structure):
     """mirror of struct unetpp_wgrad_desc"""
     _fields_ = [
@@ -70,6 +89,8 @@ SIGNATURES = {
     "unetpp_gemm_fwd": (C.c_int, [C.POINTER(GemmDesc), _P]),
     "unetpp_gemm_weight_image_floats": (_I64, [C.POINTER(GemmDesc)]),
     "unetpp_gemm_pack_weight_image": (C.c_int, [C.POINTER(GemmDesc), _P, _P]),
+    "unetpp_gemm_pack_weight_image_from": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(WeightSrc), _P, _P]),
+    "unetpp_gemm_pack_weight_images": (C.c_int, [_P, _I32, _I64, _P]),
     "unetpp_wgrad_max_split": (_I32, [_I32, _I32, _I32]),
     "unetpp_wgrad_slab_planes": (_I32, [C.POINTER(WgradDesc)]),
     "unetpp_wgrad": (C.c_int, [C.POINTER(WgradDesc), _P]),

@@ -92,8 +92,6 @@ void note_kernel(const char* name);
 int launch_gemm_fast(const unetpp_gemm_desc* d, hipStream_t st);
 // gemm_wino.hip: Winograd F(2x2,3x3) kernel for taps == 9 without UNETPP_GEMM_DIRECT (needs its own weight image)
 bool wino_applies(const unetpp_gemm_desc* d);
-long wino_image_floats(const unetpp_gemm_desc* d);
-int wino_pack_image(const unetpp_gemm_desc* d, float* image, hipStream_t st);
 int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st);
 // wgrad_fast.hip: 8-wave double-buffered kernel for plain aligned views; returns 1 when it does not apply
 int launch_wgrad_fast(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_tiles_cols, int k_tiles, hipStream_t st);

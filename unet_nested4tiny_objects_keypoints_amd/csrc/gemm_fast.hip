@@ -24,46 +24,6 @@ namespace {
 
 constexpr int KC = 16;
 
-// image of one (column tile, K chunk): [tap][g 2][col 32][half' 2][4] floats, half' = half ^ ((col>>3)&1)
-template <int TAPS>
-__global__ void pack_image_kernel(const FastArgs a, float* __restrict__ img) {
-  constexpr int IMG = TAPS * 512;
-  const long total = static_cast<long>(a.n_tiles) * a.n_chunks * IMG;
-  const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
-  if (i >= total) return;
-  const int e = i & 3, hs = (i >> 2) & 1, j = (i >> 3) & 31, g = (i >> 8) & 1;
-  long r = i >> 9;
-  const int tap = static_cast<int>(r % TAPS);
-  r /= TAPS;
-  int chunk = static_cast<int>(r % a.n_chunks);
-  int nt = static_cast<int>(r / a.n_chunks);
-  const int h = hs ^ ((j >> 3) & 1);
-  const int kk = 8 * g + 4 * h + e;
-  // chunk -> (view, first channel)
-  int kbase = 0, s = 0;
-  for (; s < a.d.n_in; ++s) {
-    const int ch = (a.d.in[s].c_len + KC - 1) / KC;
-    if (chunk < ch) break;
-    chunk -= ch;
-    kbase += a.d.in[s].c_len;
-  }
-  const int kin = chunk * KC + kk;
-  const bool k_ok = kin < a.d.in[s].c_len;
-  // column tile -> (out view, first column)
-  int col_base = 0, ov = 0;
-  for (; ov < a.d.n_out; ++ov) {
-    const int tv = (a.d.out[ov].c_len + 31) >> 5;
-    if (nt < tv) break;
-    nt -= tv;
-    col_base += a.d.out[ov].c_len;
-  }
-  const int cin = nt * 32 + j;
-  const bool n_ok = cin < a.d.out[ov].c_len;
-  float v = 0.f;
-  if (k_ok && n_ok) v = a.d.weight[(static_cast<long>(tap) * a.Ktot + kbase + kin) * a.Ncols + col_base + cin];
-  img[i] = v;
-}
-
 // NT = column tiles per unit.  3x3 convolutions use NT = 1 (3 workgroups per CU); the pointwise GEMMs of the 2x2
 // deconvolution (K = Cin only, N = 4*Cout) use NT = 2 so that one staged input patch feeds 64 columns.
 template <int TAPS, int LOG2TW, int NT>
@@ -431,26 +391,3 @@ int launch_gemm_fast(const unetpp_gemm_desc* d, hipStream_t st) {
 }
 
 }  // namespace unetpp
-
-using namespace unetpp;
-
-extern "C" int64_t unetpp_gemm_weight_image_floats(const unetpp_gemm_desc* d) {
-  if (wino_applies(d)) return wino_image_floats(d);
-  FastArgs a;
-  if (!fast_args(d, a, KC)) return 0;
-  return static_cast<int64_t>(a.n_tiles) * a.n_chunks * d->taps * 512;
-}
-
-extern "C" int unetpp_gemm_pack_weight_image(const unetpp_gemm_desc* d, float* image, void* stream) {
-  if (wino_applies(d)) return wino_pack_image(d, image, static_cast<hipStream_t>(stream));
-  FastArgs a;
-  if (!fast_args(d, a, KC) || image == nullptr || d->weight == nullptr) return UNETPP_EINVAL;
-  const long total = static_cast<long>(a.n_tiles) * a.n_chunks * d->taps * 512;
-  const unsigned blocks = static_cast<unsigned>((total + 255) / 256);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (d->taps == 9)
-    hipLaunchKernelGGL(pack_image_kernel<9>, dim3(blocks), dim3(256), 0, st, a, image);
-  else
-    hipLaunchKernelGGL(pack_image_kernel<1>, dim3(blocks), dim3(256), 0, st, a, image);
-  return launch_status();
-}

@@ -204,7 +204,7 @@ extern "C" int unetpp_gemm_fwd(const unetpp_gemm_desc* d, void* stream) {
   if (d == nullptr || d->N <= 0 || d->H <= 0 || d->W <= 0) return UNETPP_EINVAL;
   if (d->taps != 9 && d->taps != 1) return UNETPP_EINVAL;
   if (d->n_in < 1 || d->n_in > UNETPP_MAX_VIEWS || d->n_out < 1 || d->n_out > UNETPP_MAX_VIEWS) return UNETPP_EINVAL;
-  if (d->weight == nullptr) return UNETPP_EINVAL;
+  if (d->weight == nullptr && d->weight_image == nullptr) return UNETPP_EINVAL;
   if (d->stats_partial != nullptr && d->n_out != 1) return UNETPP_EINVAL;
   if (d->weight_image != nullptr)  // the image was packed for the algorithm the same descriptor selects
     return wino_applies(d) ? launch_gemm_wino(d, static_cast<hipStream_t>(stream))

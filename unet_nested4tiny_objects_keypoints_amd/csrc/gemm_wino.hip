@@ -13,7 +13,7 @@
 //   * A operand: lane (tile t, k-slot g) reads its 4x4 window one channel at a time (16 ds_read_b32), runs the input
 //     transform B^T d B IN REGISTERS (32 add/sub per channel) and feeds the 16 results straight to 32 MFMAs -- the
 //     transformed input never exists in memory;
-//   * B operand: the transformed weights U = G g G^T are precomputed per launch (pack_wino_kernel) as an LDS image
+//   * B operand: the transformed weights U = G g G^T are precomputed per launch (weight_image.hip) as an LDS image
 //     whose lane-linear 8-byte reads each feed two MFMAs;
 //   * all 16 xi of a (tile, column) land in the same lane and register index, so the output transform A^T M A is
 //     lane-local (24 add/sub per 2x2 tile); bias/ReLU/gate/accumulate/BatchNorm partial sums and 16-byte transposed
@@ -33,51 +33,6 @@ constexpr int WKC = 8;      // channels per K chunk
 constexpr int WNC = 32;     // columns per unit
 constexpr int WP = 10;      // LDS pixel stride of the input patch (floats): 8 channels + 2 pad
 constexpr int WIMG = 4096;  // floats of one (column tile, chunk) weight image
-
-// image of one (column tile, chunk): [s 2][xi 16][g 4][col 16][nh 2],
-// value = U[xi][channel chunk*8 + 2g + s][column tile*32 + 16*nh + col],  U = G g G^T
-__global__ void pack_wino_kernel(const FastArgs a, float* __restrict__ img) {
-  const long total = static_cast<long>(a.n_tiles) * a.n_chunks * WIMG;
-  const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
-  if (i >= total) return;
-  const int nh = i & 1, col = (i >> 1) & 15, g = (i >> 5) & 3, xi = (i >> 7) & 15, s = (i >> 11) & 1;
-  const long r = i >> 12;
-  int chunk = static_cast<int>(r % a.n_chunks);
-  int nt = static_cast<int>(r / a.n_chunks);
-  int kbase = 0, v = 0;
-  for (; v < a.d.n_in; ++v) {
-    const int ch = (a.d.in[v].c_len + WKC - 1) / WKC;
-    if (chunk < ch) break;
-    chunk -= ch;
-    kbase += a.d.in[v].c_len;
-  }
-  const int kin = chunk * WKC + 2 * g + s;
-  const bool k_ok = kin < a.d.in[v].c_len;
-  int col_base = 0, ov = 0;
-  for (; ov < a.d.n_out; ++ov) {
-    const int tv = (a.d.out[ov].c_len + WNC - 1) / WNC;
-    if (nt < tv) break;
-    nt -= tv;
-    col_base += a.d.out[ov].c_len;
-  }
-  const int cin = nt * WNC + 16 * nh + col;
-  const bool n_ok = cin < a.d.out[ov].c_len;
-  float u = 0.f;
-  if (k_ok && n_ok) {
-    const float* w = a.d.weight + static_cast<long>(kbase + kin) * a.Ncols + col_base + cin;
-    const long tap_stride = static_cast<long>(a.Ktot) * a.Ncols;
-    const int ra = xi >> 2, rb = xi & 3;
-    // row ra of G applied down the filter rows, then row rb of G along the filter columns
-    float t[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float w0 = w[(0 * 3 + c) * tap_stride], w1 = w[(1 * 3 + c) * tap_stride], w2 = w[(2 * 3 + c) * tap_stride];
-      t[c] = ra == 0 ? w0 : (ra == 1 ? 0.5f * (w0 + w1 + w2) : (ra == 2 ? 0.5f * (w0 - w1 + w2) : w2));
-    }
-    u = rb == 0 ? t[0] : (rb == 1 ? 0.5f * (t[0] + t[1] + t[2]) : (rb == 2 ? 0.5f * (t[0] - t[1] + t[2]) : t[2]));
-  }
-  img[i] = u;
-}
 
 // NH = 16-column halves of the tile that are computed: 2, or 1 when no output view is wider than 16 channels (narrow
 // networks, e.g. the reference's default base width 16) -- the second half would multiply zero weights.
@@ -451,20 +406,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 
 bool wino_applies(const unetpp_gemm_desc* d) {
   return d != nullptr && d->taps == 9 && (d->flags & UNETPP_GEMM_DIRECT) == 0;
-}
-
-long wino_image_floats(const unetpp_gemm_desc* d) {
-  FastArgs a;
-  if (!wino_applies(d) || !fast_args(d, a, WKC, WNC)) return 0;
-  return static_cast<long>(a.n_tiles) * a.n_chunks * WIMG;
-}
-
-int wino_pack_image(const unetpp_gemm_desc* d, float* image, hipStream_t st) {
-  FastArgs a;
-  if (!wino_applies(d) || !fast_args(d, a, WKC, WNC) || image == nullptr || d->weight == nullptr) return UNETPP_EINVAL;
-  const long total = static_cast<long>(a.n_tiles) * a.n_chunks * WIMG;
-  hipLaunchKernelGGL(pack_wino_kernel, dim3(static_cast<unsigned>((total + 255) / 256)), dim3(256), 0, st, a, image);
-  return launch_status();
 }
 
 int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {

@@ -1,0 +1,183 @@
+// Weight images of the fast GEMM kernels, built straight from the torch-layout parameters.
+//
+// A fast kernel reads its B operand as an LDS image per (column tile, K chunk): the direct kernels
+// (gemm_fast.hip) [tap][g 2][col 32][half' 2][4] over 16-channel chunks, the Winograd kernel (gemm_wino.hip)
+// [s 2][xi 16][g 4][col 16][nh 2] of U = G g G^T over 8-channel chunks.  The element of the GEMM weight that lands in
+// an image slot is W[tap][k][n]; `unetpp_weight_src` says where that element sits in memory:
+//     src[tap' * s_t + (k % k_inner) * s_k + (k / k_inner) * s_ko + (n % n_inner) * s_n + (n / n_inner) * s_no],
+// tap' = flip ? taps - 1 - tap : tap, which covers the packed [taps][K][N] operand as well as nn.Conv2d
+// ([co,ci,3,3]: forward and 180-degree-rotated input-gradient form) and nn.ConvTranspose2d ([ci,co,2,2]: forward
+// with N = 4 phases x co, input gradient with K = 4 phases x co) parameters -- no intermediate re-layout launch.
+// unetpp_gemm_pack_weight_images builds the images of many launches (a whole forward or backward pass) in ONE launch
+// from a table of jobs in device memory.
+#include "common.h"
+#include "gemm_units.h"
+
+namespace unetpp {
+namespace {
+
+constexpr int kKindFast = 0, kKindWino = 1;
+
+struct PackGeom {  // what the image layout depends on: the channel structure of the launch
+  int kind, taps, kc, ncol;  // kc = channels per K chunk, ncol = columns per tile
+  int n_in, n_out;
+  int in_len[UNETPP_MAX_VIEWS], out_len[UNETPP_MAX_VIEWS];
+  int n_chunks, n_tiles;
+  long floats;
+};
+
+__host__ __device__ inline long image_floats_per_tile_chunk(int kind, int taps) { return kind == kKindWino ? 4096 : taps * 512L; }
+
+__host__ __device__ inline void finish_geom(PackGeom& g) {
+  g.n_chunks = 0;
+  g.n_tiles = 0;
+  for (int i = 0; i < g.n_in; ++i) g.n_chunks += (g.in_len[i] + g.kc - 1) / g.kc;
+  for (int i = 0; i < g.n_out; ++i) g.n_tiles += (g.out_len[i] + g.ncol - 1) / g.ncol;
+  g.floats = static_cast<long>(g.n_tiles) * g.n_chunks * image_floats_per_tile_chunk(g.kind, g.taps);
+}
+
+__device__ __forceinline__ float wsrc_at(const unetpp_weight_src& w, int taps, int tap, int k, int n) {
+  const int tt = w.flip ? taps - 1 - tap : tap;
+  const int ki = w.k_inner > 0 ? k % w.k_inner : k, ko = w.k_inner > 0 ? k / w.k_inner : 0;
+  const int ni = w.n_inner > 0 ? n % w.n_inner : n, no = w.n_inner > 0 ? n / w.n_inner : 0;
+  return w.src[tt * w.s_t + ki * w.s_k + ko * w.s_ko + ni * w.s_n + no * w.s_no];
+}
+
+// value of image element i
+__device__ __forceinline__ float image_element(const PackGeom& g, const unetpp_weight_src& w, long i) {
+  int kk, cin_local, tap = 0, xi = 0;
+  long r;
+  if (g.kind == kKindWino) {  // [s 2][xi 16][g 4][col 16][nh 2]
+    const int nh = i & 1, col = (i >> 1) & 15, gq = (i >> 5) & 3, s = (i >> 11) & 1;
+    xi = (i >> 7) & 15;
+    kk = 2 * gq + s;
+    cin_local = 16 * nh + col;
+    r = i >> 12;
+  } else {  // [tap][g 2][col 32][half' 2][4], half' = half ^ ((col>>3)&1)
+    const int e = i & 3, hs = (i >> 2) & 1, j = (i >> 3) & 31, gq = (i >> 8) & 1;
+    r = i >> 9;
+    tap = static_cast<int>(r % g.taps);
+    r /= g.taps;
+    kk = 8 * gq + 4 * (hs ^ ((j >> 3) & 1)) + e;
+    cin_local = j;
+  }
+  int chunk = static_cast<int>(r % g.n_chunks);
+  int nt = static_cast<int>(r / g.n_chunks);
+  int kbase = 0, v = 0;
+  for (; v < g.n_in - 1; ++v) {
+    const int ch = (g.in_len[v] + g.kc - 1) / g.kc;
+    if (chunk < ch) break;
+    chunk -= ch;
+    kbase += g.in_len[v];
+  }
+  const int kin = chunk * g.kc + kk;
+  int col_base = 0, ov = 0;
+  for (; ov < g.n_out - 1; ++ov) {
+    const int tv = (g.out_len[ov] + g.ncol - 1) / g.ncol;
+    if (nt < tv) break;
+    nt -= tv;
+    col_base += g.out_len[ov];
+  }
+  const int cin = nt * g.ncol + cin_local;
+  if (kin >= g.in_len[v] || cin >= g.out_len[ov]) return 0.f;
+  const int k = kbase + kin, n = col_base + cin;
+  if (g.kind != kKindWino) return wsrc_at(w, g.taps, tap, k, n);
+  // U = G g G^T: row ra of G down the filter rows, then row rb of G along the filter columns
+  const int ra = xi >> 2, rb = xi & 3;
+  float t[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float w0 = wsrc_at(w, 9, 0 * 3 + c, k, n), w1 = wsrc_at(w, 9, 1 * 3 + c, k, n), w2 = wsrc_at(w, 9, 2 * 3 + c, k, n);
+    t[c] = ra == 0 ? w0 : (ra == 1 ? 0.5f * (w0 + w1 + w2) : (ra == 2 ? 0.5f * (w0 - w1 + w2) : w2));
+  }
+  return rb == 0 ? t[0] : (rb == 1 ? 0.5f * (t[0] + t[1] + t[2]) : (rb == 2 ? 0.5f * (t[0] - t[1] + t[2]) : t[2]));
+}
+
+__global__ void pack_image_one_kernel(const PackGeom g, const unetpp_weight_src w, float* __restrict__ img) {
+  const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
+  if (i < g.floats) img[i] = image_element(g, w, i);
+}
+
+// blockIdx.y = job; every job derives its geometry from its own channel lists
+__global__ void pack_image_jobs_kernel(const unetpp_pack_job* __restrict__ jobs) {
+  const unetpp_pack_job& j = jobs[blockIdx.y];
+  __shared__ PackGeom g;
+  if (threadIdx.x == 0) {
+    const bool wino = j.taps == 9 && (j.flags & UNETPP_GEMM_DIRECT) == 0;
+    g.kind = wino ? kKindWino : kKindFast;
+    g.taps = j.taps;
+    g.kc = wino ? 8 : 16;
+    g.ncol = 32;
+    g.n_in = j.n_in;
+    g.n_out = j.n_out;
+    for (int i = 0; i < UNETPP_MAX_VIEWS; ++i) {
+      g.in_len[i] = j.in_len[i];
+      g.out_len[i] = j.out_len[i];
+    }
+    finish_geom(g);
+  }
+  __syncthreads();
+  for (long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x; i < g.floats;
+       i += static_cast<long>(gridDim.x) * blockDim.x)
+    j.image[i] = image_element(g, j.src, i);
+}
+
+bool geom_of(const unetpp_gemm_desc* d, PackGeom& g) {
+  FastArgs a;
+  const bool wino = wino_applies(d);
+  if (!fast_args(d, a, wino ? 8 : 16, 32)) return false;
+  g.kind = wino ? kKindWino : kKindFast;
+  g.taps = d->taps;
+  g.kc = wino ? 8 : 16;
+  g.ncol = 32;
+  g.n_in = d->n_in;
+  g.n_out = d->n_out;
+  for (int i = 0; i < UNETPP_MAX_VIEWS; ++i) {
+    g.in_len[i] = i < d->n_in ? d->in[i].c_len : 0;
+    g.out_len[i] = i < d->n_out ? d->out[i].c_len : 0;
+  }
+  finish_geom(g);
+  return g.n_chunks == a.n_chunks && g.n_tiles == a.n_tiles;
+}
+
+}  // namespace
+}  // namespace unetpp
+
+using namespace unetpp;
+
+extern "C" int64_t unetpp_gemm_weight_image_floats(const unetpp_gemm_desc* d) {
+  PackGeom g;
+  return geom_of(d, g) ? g.floats : 0;
+}
+
+extern "C" int unetpp_gemm_pack_weight_image_from(const unetpp_gemm_desc* d, const unetpp_weight_src* src, float* image,
+                                                  void* stream) {
+  PackGeom g;
+  if (src == nullptr || src->src == nullptr || image == nullptr || !geom_of(d, g)) return UNETPP_EINVAL;
+  hipLaunchKernelGGL(pack_image_one_kernel, dim3(static_cast<unsigned>((g.floats + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), g, *src, image);
+  return launch_status();
+}
+
+extern "C" int unetpp_gemm_pack_weight_image(const unetpp_gemm_desc* d, float* image, void* stream) {
+  if (d == nullptr || d->weight == nullptr) return UNETPP_EINVAL;
+  long K = 0, N = 0;
+  for (int i = 0; i < d->n_in && i < UNETPP_MAX_VIEWS; ++i) K += d->in[i].c_len;
+  for (int i = 0; i < d->n_out && i < UNETPP_MAX_VIEWS; ++i) N += d->out[i].c_len;
+  unetpp_weight_src w = {};  // the packed [taps][K][Ncols] operand
+  w.src = d->weight;
+  w.s_t = K * N;
+  w.s_k = N;
+  w.s_n = 1;
+  return unetpp_gemm_pack_weight_image_from(d, &w, image, stream);
+}
+
+extern "C" int unetpp_gemm_pack_weight_images(const unetpp_pack_job* jobs_device, int32_t n_jobs, int64_t max_image_floats,
+                                              void* stream) {
+  if (jobs_device == nullptr || n_jobs < 1 || n_jobs > 65535 || max_image_floats < 1) return UNETPP_EINVAL;
+  long bx = (max_image_floats + 256L * 8 - 1) / (256L * 8);  // ~8 elements per thread for the largest image
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(pack_image_jobs_kernel, dim3(static_cast<unsigned>(bx), static_cast<unsigned>(n_jobs)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), jobs_device);
+  return launch_status();
+}
