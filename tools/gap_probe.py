@@ -14,7 +14,7 @@ from unet_nested4tiny_objects_keypoints_amd.ops import V  # noqa: E402
 b, hw, ci, co = 32, 256, 32, 32
 x = torch.randn(b, hw, hw, ci, device="cuda")
 y = torch.empty(b, hw, hw, co, device="cuda")
-w = engine.pack_conv_fwd(torch.randn(co, ci, 3, 3, device="cuda") * 0.05)
+w = engine.pack_conv_fwd(torch.randn(co, ci, 3, 3, device="cuda") * 0.05).packed()
 lib = _lib.lib()
 d = GemmDesc()
 d.N, d.H, d.W, d.taps, d.n_in, d.n_out = b, hw, hw, 9, 1, 1

@@ -25,38 +25,40 @@ def _empty(n, like):
     return torch.empty(n, dtype=torch.float32, device=like.device)
 
 
+def _packed(w, t, k, n, dstr, sstr, flip=False):
+    dst = _empty(t * k * n, w)
+    ops.pack_weight(dst, w, t, k, n, dstr, sstr, flip=flip)
+    return dst
+
+
 def pack_conv_fwd(w):
-    """[co, ci, k, k] -> [taps][ci][co]"""
+    """[co, ci, k, k] as the GEMM weight [taps][ci][co] (lazily: the fast kernels read the parameter directly)"""
     co, ci, kh, kw = w.shape
     t = kh * kw
-    dst = _empty(t * ci * co, w)
-    ops.pack_weight(dst, w, t, ci, co, (ci * co, co, 1), (1, t, ci * t))
-    return dst
+    return ops.WSrc(w, t, ci, co, s_t=1, s_k=t, s_n=ci * t,
+                    pack=lambda: _packed(w, t, ci, co, (ci * co, co, 1), (1, t, ci * t)))
 
 
 def pack_conv_dgrad(w):
-    """[co, ci, k, k] -> [taps (rotated 180)][co][ci]: dx = conv(dy, this)"""
+    """[co, ci, k, k] as [taps (rotated 180)][co][ci]: dx = conv(dy, this)"""
     co, ci, kh, kw = w.shape
     t = kh * kw
-    dst = _empty(t * co * ci, w)
-    ops.pack_weight(dst, w, t, co, ci, (co * ci, ci, 1), (1, ci * t, t), flip=True)
-    return dst
+    return ops.WSrc(w, t, co, ci, s_t=1, s_k=ci * t, s_n=t, flip=True,
+                    pack=lambda: _packed(w, t, co, ci, (co * ci, ci, 1), (1, ci * t, t), flip=True))
 
 
 def pack_deconv_fwd(w):
-    """[ci, co, 2, 2] -> [1][ci][4*co], column = (a*2+b)*co + c"""
+    """[ci, co, 2, 2] as [1][ci][4*co], column = (a*2+b)*co + c"""
     ci, co = w.shape[0], w.shape[1]
-    dst = _empty(ci * 4 * co, w)
-    ops.pack_weight(dst, w, 4, ci, co, (co, 4 * co, 1), (1, 4 * co, 4))
-    return dst
+    return ops.WSrc(w, 1, ci, 4 * co, s_t=0, s_k=4 * co, s_n=4, s_no=1, n_inner=co,
+                    pack=lambda: _packed(w, 4, ci, co, (co, 4 * co, 1), (1, 4 * co, 4)))
 
 
 def pack_deconv_dgrad(w):
-    """[ci, co, 2, 2] -> [1][4*co][ci], row = (a*2+b)*co + c"""
+    """[ci, co, 2, 2] as [1][4*co][ci], row = (a*2+b)*co + c"""
     ci, co = w.shape[0], w.shape[1]
-    dst = _empty(4 * co * ci, w)
-    ops.pack_weight(dst, w, 4, co, ci, (co * ci, ci, 1), (1, 4, 4 * co))
-    return dst
+    return ops.WSrc(w, 1, 4 * co, ci, s_t=0, s_k=4, s_ko=1, k_inner=co, s_n=4 * co,
+                    pack=lambda: _packed(w, 4, co, ci, (co * ci, ci, 1), (1, 4, 4 * co)))
 
 
 def tile_bias4(b):

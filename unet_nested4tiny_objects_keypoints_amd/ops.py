@@ -14,7 +14,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import MAX_VIEWS, GemmDesc, View, WgradDesc, check
+from ._lib import MAX_VIEWS, GemmDesc, View, WeightSrc, WgradDesc, check
 
 
 def _stream():
@@ -149,6 +149,44 @@ USE_FAST_GEMM = True  # tests flip this to exercise the generic kernel on the sa
 USE_WINOGRAD = os.environ.get("UNETPP_NO_WINOGRAD") is None  # 3x3 fast path: Winograd F(2x2,3x3) unless disabled
 
 
+@dataclass
+class WSrc:
+    """A GEMM weight [taps][K][N] given by a parameter in its torch layout (struct unetpp_weight_src): element
+    (tap, k, n) sits at tap' * s_t + (k % k_inner) * s_k + (k // k_inner) * s_ko + (n % n_inner) * s_n +
+    (n // n_inner) * s_no, tap' = taps-1-tap when flip.  The fast kernels build their LDS image straight from it;
+    `packed()` materialises the [taps][K][N] operand for the generic kernel."""
+    t: torch.Tensor
+    taps: int
+    k: int
+    n: int
+    s_t: int
+    s_k: int
+    s_n: int
+    s_ko: int = 0
+    s_no: int = 0
+    k_inner: int = 0
+    n_inner: int = 0
+    flip: bool = False
+    pack: Optional[callable] = None  # () -> packed tensor
+
+    def numel(self) -> int:
+        return self.taps * self.k * self.n
+
+    @property
+    def device(self):
+        return self.t.device
+
+    def fill(self, dst: WeightSrc) -> None:
+        dst.src = _need(self.t, "weight").data_ptr()
+        dst.s_t, dst.s_k, dst.s_ko, dst.s_n, dst.s_no = self.s_t, self.s_k, self.s_ko, self.s_n, self.s_no
+        dst.k_inner, dst.n_inner, dst.flip = self.k_inner, self.n_inner, int(self.flip)
+
+    def packed(self) -> torch.Tensor:
+        if self.pack is None:
+            raise ValueError("this weight source has no packed form")
+        return self.pack()
+
+
 def gemm_pixel_blocks(n: int, h: int, w: int) -> int:
     return int(_lib.lib().unetpp_gemm_pixel_blocks(n, h, w))
 
@@ -165,24 +203,36 @@ def gemm_fwd(n: int, h: int, w: int, taps: int, ins: Sequence[V], outs: Sequence
     d.n_in, d.n_out = len(ins), len(outs)
     k = sum(v.fill(d.inp[i]) for i, v in enumerate(ins))
     nc = sum(v.fill(d.out[i]) for i, v in enumerate(outs))
-    _need(weight, "packed weight")
-    if weight.numel() != taps * k * nc:
-        raise ValueError("packed weight has %d elements, expected %d*%d*%d" % (weight.numel(), taps, k, nc))
+    from_src = isinstance(weight, WSrc)  # parameter in torch layout, or the packed [taps][K][N] operand
+    if not from_src:
+        _need(weight, "packed weight")
+    if weight.numel() != taps * k * nc or (from_src and (weight.taps, weight.k, weight.n) != (taps, k, nc)):
+        raise ValueError("weight has %d elements, expected %d*%d*%d" % (weight.numel(), taps, k, nc))
     if bias is not None and _need(bias, "bias").numel() != nc:
         raise ValueError("bias length mismatch")
     if stats_partial is not None and _need(stats_partial, "stats").numel() != gemm_pixel_blocks(n, h, w) * nc * 2:
         raise ValueError("stats_partial size mismatch")
-    d.weight = weight.data_ptr()
+    d.weight = None if from_src else weight.data_ptr()
     d.bias = None if bias is None else bias.data_ptr()
     d.stats_partial = None if stats_partial is None else stats_partial.data_ptr()
     d.weight_image = None
     if USE_FAST_GEMM:
         lib = _lib.lib()
         n_img = int(lib.unetpp_gemm_weight_image_floats(C.byref(d)))
-        if n_img > 0:  # plain aligned views: the register-prefetched kernel applies
+        if n_img > 0:  # aligned views: a fast kernel applies; its weight image is built in one launch
             image = torch.empty(n_img, dtype=torch.float32, device=weight.device)
-            check(lib.unetpp_gemm_pack_weight_image(C.byref(d), _ptr(image), _stream()), "unetpp_gemm_pack_weight_image")
+            if from_src:
+                ws = WeightSrc()
+                weight.fill(ws)
+                check(lib.unetpp_gemm_pack_weight_image_from(C.byref(d), C.byref(ws), _ptr(image), _stream()),
+                      "unetpp_gemm_pack_weight_image_from")
+            else:
+                check(lib.unetpp_gemm_pack_weight_image(C.byref(d), _ptr(image), _stream()),
+                      "unetpp_gemm_pack_weight_image")
             d.weight_image = image.data_ptr()
+    if d.weight_image is None and from_src:  # generic kernel: it reads the packed operand
+        packed = weight.packed()
+        d.weight = packed.data_ptr()
     _timed_call(None, 2.0 * n * h * w * taps * k * nc,
                 lambda: check(_lib.lib().unetpp_gemm_fwd(C.byref(d), _stream()), "unetpp_gemm_fwd"))
 
