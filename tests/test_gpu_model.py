@@ -276,3 +276,39 @@ def test_large_shape_properties(dev):
     for a, b in zip(g1, g2):
         assert torch.isfinite(a).all()
         assert rel_err(b, 2 * a) < 1e-5
+
+
+def test_batched_weight_images_track_parameter_updates(dev):
+    """ops.PackPlan: from the second pass on every weight image of a pass is packed by one launch.  Outputs and
+    gradients must equal the per-launch packing bit for bit, before and after an optimizer step, and a deep copy of the
+    model starts with an empty plan."""
+    import copy
+
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, UNet_Nested, engine, train_step
+    torch.manual_seed(21)
+    m = UNet_Nested(in_channels=1, n_classes=4, feature_scale=4).to(dev).train()
+    m.drop_out.p = 0.0
+    ref = copy.deepcopy(m)
+    assert "_pack_plan" not in ref.__dict__ or not ref.__dict__["_pack_plan"].entries
+    x = torch.randn(2, 1, 32, 32, device=dev)
+    t = torch.rand(2, 4, 32, 32, device=dev)
+    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+    opt_m, opt_r = torch.optim.SGD(m.parameters(), lr=0.1), torch.optim.SGD(ref.parameters(), lr=0.1)
+    for step in range(3):
+        outs_m, loss_m = train_step(m, opt_m, crit, x, t)
+        engine.USE_PACK_PLAN = False
+        try:
+            outs_r, loss_r = train_step(ref, opt_r, crit, x, t)
+        finally:
+            engine.USE_PACK_PLAN = True
+        assert all(torch.equal(a, b) for a, b in zip(outs_m, outs_r)), step
+        assert torch.equal(loss_m, loss_r)
+        for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+            assert torch.equal(p, q), (step, k)
+    plan = m.__dict__["_pack_plan"]
+    assert {e.phase for e in plan.entries.values()} == {"fwd", "bwd"} and len(plan.entries) > 20
+    m.eval()
+    with torch.no_grad():
+        a = m(x)
+        b = m(x)  # nothing changed: the plan skips the launch
+    assert all(torch.equal(u, v) for u, v in zip(a, b))

@@ -12,12 +12,17 @@ Layout: activations NHWC fp32; the dense-skip concatenation ``cat([up, X_i0, ..,
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional, Tuple
 
 import torch
 
 from . import ops
 from .ops import V
+
+
+USE_PACK_PLAN = os.environ.get("UNETPP_NO_PACK_PLAN") is None  # one batched weight-image launch per pass (ops.PackPlan)
 
 
 # ----------------------------------------------------------------------------- weight re-layouts
@@ -194,6 +199,26 @@ def _dropout_config(model, training):
 def forward_impl(model, x, training: bool, save: bool):
     """Runs the forward DAG of models/unet.py:255-300.  Returns (outputs, saved-for-backward or None)."""
     _check_input(model, x)
+    if not USE_PACK_PLAN:
+        return _forward_impl(model, x, training, save)
+    plan = _plan_of(model)
+    plan.begin("fwd")  # every weight image of the pass in one launch (after the first pass recorded the jobs)
+    ops.set_pack_plan(plan)
+    try:
+        return _forward_impl(model, x, training, save)
+    finally:
+        ops.set_pack_plan(None)
+
+
+def _plan_of(model) -> "ops.PackPlan":
+    plan = model.__dict__.get("_pack_plan")
+    if plan is None:
+        plan = ops.PackPlan()
+        model.__dict__["_pack_plan"] = plan
+    return plan
+
+
+def _forward_impl(model, x, training: bool, save: bool):
     b, _, h0, w0 = x.shape
     d = model.depth
     x_nhwc = ops.nchw_to_nhwc(x.detach().contiguous())
@@ -342,6 +367,18 @@ def _up_bwd(upmod, is_deconv, u: _UpRec, d_up, d_src, accumulate, gate, b, grads
 def backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=None):
     """Returns (dict param -> grad, dx NHWC or None).  grad_sink(list of (param, grad)) is called each time a
     node's parameter gradients are final (used by the data-parallel bucketed all-reduce)."""
+    if not USE_PACK_PLAN:
+        return _backward_impl(model, s, d_outs, want_input_grad, grad_sink)
+    plan = _plan_of(model)
+    plan.begin("bwd")
+    ops.set_pack_plan(plan)
+    try:
+        return _backward_impl(model, s, d_outs, want_input_grad, grad_sink)
+    finally:
+        ops.set_pack_plan(None)
+
+
+def _backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=None):
     b, h0, w0 = s.shape
     d = model.depth
     grads: Dict[torch.nn.Parameter, torch.Tensor] = {}

@@ -14,7 +14,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import MAX_VIEWS, GemmDesc, View, WeightSrc, WgradDesc, check
+from ._lib import MAX_VIEWS, GemmDesc, PackJob, View, WeightSrc, WgradDesc, check
 
 
 def _stream():
@@ -187,6 +187,85 @@ class WSrc:
         return self.pack()
 
 
+class PackPlan:
+    """All weight images of a forward (or backward) pass in ONE launch (unetpp_gemm_pack_weight_images).
+
+    The first time a launch is seen (engine pass `phase`, weight source, channel structure) its image is packed by
+    itself into a persistent buffer and a job is recorded; from then on `begin(phase)` packs every recorded image of
+    that pass with a single kernel before the pass starts and the launches just pick their buffer.  Nothing is
+    packed when no source parameter changed since the last run (inference, gradient accumulation).  Entries keep
+    their source tensor alive and are dropped when unused for a few passes."""
+
+    class _Entry:
+        __slots__ = ("image", "n_img", "job", "src", "phase", "fresh", "used")
+
+    def __init__(self):
+        self.entries = {}
+        self._tables = {}    # phase -> (device table, host array, signatures, max floats)
+        self._versions = {}  # phase -> parameter versions at the last run
+        self.phase = None
+        self.pass_id = 0
+
+    def __deepcopy__(self, memo):  # copies / pickles of a model start with an empty plan
+        return PackPlan()
+
+    def __reduce__(self):
+        return (PackPlan, ())
+
+    def begin(self, phase: str) -> None:
+        self.phase = phase
+        self.pass_id += 1
+        stale = [k for k, e in self.entries.items() if self.pass_id - e.used > 16]
+        for k in stale:
+            del self.entries[k]
+        sigs = tuple(k for k, e in self.entries.items() if e.phase == phase)
+        if not sigs:
+            return
+        ents = [self.entries[k] for k in sigs]
+        versions = tuple(e.src._version for e in ents)
+        tab = self._tables.get(phase)
+        if tab is None or tab[2] != sigs:
+            arr = (PackJob * len(ents))(*[e.job for e in ents])
+            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(ents[0].image.device)
+            tab = (dev, arr, sigs, max(e.n_img for e in ents))
+            self._tables[phase] = tab
+            self._versions.pop(phase, None)
+        if self._versions.get(phase) != versions:
+            check(_lib.lib().unetpp_gemm_pack_weight_images(_ptr(tab[0]), len(ents), tab[3], _stream()),
+                  "unetpp_gemm_pack_weight_images")
+            self._versions[phase] = versions
+        for e in ents:
+            e.fresh = self.pass_id
+
+    def image_for(self, sig, n_img: int, weight: "WSrc", d: GemmDesc):
+        """-> (image tensor, already packed for this pass)"""
+        e = self.entries.get(sig)
+        if e is None:
+            e = PackPlan._Entry()
+            e.image = torch.empty(n_img, dtype=torch.float32, device=weight.device)
+            e.n_img, e.src, e.phase, e.fresh = n_img, weight.t, self.phase, -1
+            job = PackJob()
+            weight.fill(job.src)
+            job.image = e.image.data_ptr()
+            job.taps, job.flags, job.n_in, job.n_out = d.taps, d.flags, d.n_in, d.n_out
+            for i in range(d.n_in):
+                job.in_len[i] = d.inp[i].c_len
+            for i in range(d.n_out):
+                job.out_len[i] = d.out[i].c_len
+            e.job = job
+            self.entries[sig] = e
+        e.used = self.pass_id
+        return e.image, e.fresh == self.pass_id
+
+
+_PLAN: Optional[PackPlan] = None
+
+
+def set_pack_plan(plan: Optional[PackPlan]) -> None:
+    global _PLAN
+    _PLAN = plan
+
+
 def gemm_pixel_blocks(n: int, h: int, w: int) -> int:
     return int(_lib.lib().unetpp_gemm_pixel_blocks(n, h, w))
 
@@ -220,8 +299,17 @@ def gemm_fwd(n: int, h: int, w: int, taps: int, ins: Sequence[V], outs: Sequence
         lib = _lib.lib()
         n_img = int(lib.unetpp_gemm_weight_image_floats(C.byref(d)))
         if n_img > 0:  # aligned views: a fast kernel applies; its weight image is built in one launch
-            image = torch.empty(n_img, dtype=torch.float32, device=weight.device)
-            if from_src:
+            ready = False
+            if from_src and _PLAN is not None and _PLAN.phase is not None:
+                sig = (weight.t.data_ptr(), weight.s_t, weight.s_k, weight.s_ko, weight.s_n, weight.s_no, weight.k_inner,
+                       weight.n_inner, weight.flip, taps, d.flags, tuple(v.c_len for v in d.inp[:d.n_in]),
+                       tuple(v.c_len for v in d.out[:d.n_out]))
+                image, ready = _PLAN.image_for(sig, n_img, weight, d)
+            else:
+                image = torch.empty(n_img, dtype=torch.float32, device=weight.device)
+            if ready:
+                pass  # packed by PackPlan.begin() together with the other images of this pass
+            elif from_src:
                 ws = WeightSrc()
                 weight.fill(ws)
                 check(lib.unetpp_gemm_pack_weight_image_from(C.byref(d), C.byref(ws), _ptr(image), _stream()),
