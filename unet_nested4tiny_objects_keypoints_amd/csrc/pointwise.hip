@@ -400,6 +400,79 @@ __global__ __launch_bounds__(64) void head_fwd_tiled_kernel(const float* __restr
   }
 }
 
+// Forward head, streaming form for power-of-two channel-quad counts (C = 4 .. 128): lane = (pixel, channel quad), one
+// coalesced 16-byte load per item, the class weights of the quad in registers.  The P per-class partial dot products
+// of a lane are summed over the C/4 lanes of the pixel by a reduce-scatter (each exchange step halves the classes a
+// lane still carries: P-1 + log2(G/P) shuffles instead of P log2 G), fixed order.  No LDS tile, no transposition.
+template <int LOG2G, int P>  // P = classes padded to a power of two (4 or 8), P <= G
+__global__ __launch_bounds__(kThreads) void head_fwd_stream_kernel(const float* __restrict__ x, const float* __restrict__ weight,
+                                                                   const float* __restrict__ bias, long pixels, int HW, int C,
+                                                                   int n_cls, float keep_scale, uint32_t thr16, uint64_t seed,
+                                                                   const uint8_t* __restrict__ mask, int use_drop,
+                                                                   float* __restrict__ out) {
+  constexpr int G = 1 << LOG2G;  // lanes (channel quads) per pixel
+  const int gq = threadIdx.x & (G - 1);
+  f32x4 wq[P];
+#pragma unroll
+  for (int k = 0; k < P; ++k)
+    wq[k] = (k < n_cls) ? *reinterpret_cast<const f32x4*>(weight + k * C + 4 * gq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const long ppb = kThreads >> LOG2G;  // pixels per block and slot
+  constexpr int U = 4;                 // pixels per thread and iteration: 4 loads in flight
+  const long span = static_cast<long>(gridDim.x) * ppb;
+  const long p_first = blockIdx.x * ppb + (threadIdx.x >> LOG2G);
+  for (long p0 = p_first; p0 - (threadIdx.x >> LOG2G) < pixels; p0 += U * span) {  // wave-uniform trip count
+    f32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long p = p0 + u * span;
+      v[u] = (p < pixels) ? *reinterpret_cast<const f32x4*>(x + p * C + 4 * gq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long p = p0 + u * span;
+      const bool valid = p < pixels;
+      if (use_drop && valid) {
+        const uint64_t bits = (mask == nullptr) ? keep_bits(seed, p, G, gq) : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool keep = (mask != nullptr) ? (mask[p * C + 4 * gq + q] != 0) : keep_one(bits, q, thr16);
+          v[u][q] = keep ? v[u][q] * keep_scale : 0.f;
+        }
+      }
+      float acc[P];
+#pragma unroll
+      for (int k = 0; k < P; ++k)
+        acc[k] = fmaf(v[u][0], wq[k][0], fmaf(v[u][1], wq[k][1], fmaf(v[u][2], wq[k][2], v[u][3] * wq[k][3])));
+      // reduce-scatter over the G lanes of the pixel: with `live` classes left, a lane keeps the half selected by its
+      // bit `off` and adds the partner's partials of that half; once one class is left, a plain butterfly sum
+      int cls = 0;  // class this lane ends up with
+#pragma unroll
+      for (int off = G >> 1, live = P; off >= 1; off >>= 1) {
+        if (live > 1) {
+          const int half = live >> 1;
+          const bool upper = (gq & off) != 0;
+#pragma unroll
+          for (int i = 0; i < half; ++i) {
+            const float send = upper ? acc[i] : acc[half + i];
+            const float keep = upper ? acc[half + i] : acc[i];
+            acc[i] = keep + __shfl_xor(send, off);
+          }
+          cls += upper ? half : 0;
+          live = half;
+        } else {
+          acc[0] += __shfl_xor(acc[0], off);
+        }
+      }
+      constexpr int kDup = (G > P) ? G / P : 1;  // lanes that end with the same class total
+      if (valid && cls < n_cls && (gq & (kDup - 1)) == 0) {
+        const unsigned pu = static_cast<unsigned>(p);  // pixels < 2^31 (launcher): 32-bit division
+        const unsigned n = pu / static_cast<unsigned>(HW), hw = pu - n * static_cast<unsigned>(HW);
+        out[(static_cast<long>(n) * n_cls + cls) * HW + hw] = 1.0f / (1.0f + __expf(-(acc[0] + bias[cls])));
+      }
+    }
+  }
+}
+
 // tile = 64 consecutive pixels.  LDS: x*keep*scale [64][C+1], dlogit [64][8], W [8][C].
 __global__ __launch_bounds__(kThreads) void head_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ outp,
                                                             const float* __restrict__ x, const float* __restrict__ weight,
@@ -900,6 +973,32 @@ extern "C" int unetpp_head_fwd(const float* x, const float* weight, const float*
   if (!x || !weight || !bias || !out_nchw || !head_args_ok(N, H, W, C, n_cls, p_drop)) return UNETPP_EINVAL;
   const long pixels = static_cast<long>(N) * H * W;
   const int use_drop = p_drop > 0.f;
+  const int g4 = C >> 2;
+  const int pcls = n_cls <= 4 ? 4 : 8;
+  if ((C & 3) == 0 && aligned16(x) && aligned16(weight) && (g4 & (g4 - 1)) == 0 && g4 <= 32 && pcls <= g4 && pixels < 0x7fffffffL) {
+    const long ppb = kThreads / g4;
+    const long want = (pixels + ppb - 1) / ppb;
+    const dim3 grid(static_cast<unsigned>(want < 256 * 16 ? want : 256 * 16));
+#define UNETPP_HEAD_STREAM(L, PC)                                                                                    \
+  hipLaunchKernelGGL((head_fwd_stream_kernel<L, PC>), grid, dim3(kThreads), 0, ST(stream), x, weight, bias, pixels,    \
+                     H * W, C, n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, use_drop, out_nchw)
+    if (pcls == 4) {
+      switch (g4) {
+        case 4: UNETPP_HEAD_STREAM(2, 4); break;
+        case 8: UNETPP_HEAD_STREAM(3, 4); break;
+        case 16: UNETPP_HEAD_STREAM(4, 4); break;
+        default: UNETPP_HEAD_STREAM(5, 4); break;
+      }
+    } else {
+      switch (g4) {
+        case 8: UNETPP_HEAD_STREAM(3, 8); break;
+        case 16: UNETPP_HEAD_STREAM(4, 8); break;
+        default: UNETPP_HEAD_STREAM(5, 8); break;
+      }
+    }
+#undef UNETPP_HEAD_STREAM
+    return launch_status();
+  }
   if ((C & 3) == 0 && aligned16(x)) {
     const long tiles = (pixels + 63) / 64;
     const unsigned blocks = static_cast<unsigned>(tiles < 256 * 16 ? tiles : 256 * 16);
