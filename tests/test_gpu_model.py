@@ -312,3 +312,42 @@ def test_batched_weight_images_track_parameter_updates(dev):
         a = m(x)
         b = m(x)  # nothing changed: the plan skips the launch
     assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
+def test_training_trajectory_tracks_oracle(dev):
+    """Fifteen optimizer steps (SGD with momentum, dropout off) of the HIP model and of the CPU oracle from the same
+    state on the same data: the loss curves must stay together (<= 2e-4 relative at every step) and go down -- an
+    end-to-end check of forward, backward, BatchNorm running statistics and parameter updates over many steps."""
+    from oracle.step_oracle import train_step_oracle
+    from oracle.unet_nested_oracle import UNetNestedOracle
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, UNet_Nested, train_step
+    ctor = dict(in_channels=1, n_classes=4, feature_scale=8)
+    torch.manual_seed(31)
+    ref = UNetNestedOracle(**ctor).train()
+    ref.drop_out.p = 0.0
+    hip = UNet_Nested(**ctor)
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to(dev).train()
+    hip.drop_out.p = 0.0
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(4, 1, 32, 32, generator=g)
+    t = torch.rand(4, 4, 32, 32, generator=g)
+    opt_r = torch.optim.SGD(ref.parameters(), lr=0.02, momentum=0.9)
+    opt_h = torch.optim.SGD(hip.parameters(), lr=0.02, momentum=0.9)
+    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+    xr, tr = x, t
+    xh, th = x.to(dev), t.to(dev)
+    losses_r, losses_h = [], []
+    for _ in range(15):
+        _, lr_ = train_step_oracle(ref, opt_r, xr, tr)
+        _, lh = train_step(hip, opt_h, crit, xh, th)
+        losses_r.append(float(lr_.detach()))
+        losses_h.append(float(lh.detach()))
+    for a, b in zip(losses_h, losses_r):
+        assert abs(a - b) <= 2e-4 * abs(b), (losses_h, losses_r)
+    assert losses_h[-1] < 0.9 * losses_h[0]
+    # BatchNorm running statistics followed the same path
+    sd_r, sd_h = ref.state_dict(), hip.state_dict()
+    for k in sd_r:
+        if k.endswith("running_var") or k.endswith("running_mean"):
+            assert rel_err(sd_h[k].cpu(), sd_r[k]) < 1e-3, k
