@@ -346,6 +346,39 @@ def test_batchnorm_relu_pool_fwd_bwd(dev, c):
     assert rel_err(nchw(acc), gy_pool.float()) < TOL
 
 
+@pytest.mark.parametrize("b,h,w,c,affine,relu", [(2, 8, 64, 32, True, True), (3, 6, 40, 20, True, True),
+                                                 (1, 4, 128, 64, False, False), (2, 4, 8, 8, True, True)])
+def test_pool_argmax_and_routing_exact(dev, b, h, w, c, affine, relu):
+    """Max-pool value, argmax (first maximum in scan order, ties from the ReLU zeros included) and the gradient
+    routing, bit-exact against torch on the same activation; covers the row-structured and the generic kernels."""
+    from unet_nested4tiny_objects_keypoints_amd import ops
+    g = torch.Generator().manual_seed(17)
+    y = torch.randn(b, h, w, c, generator=g).to(dev)
+    scale = (1 + 0.2 * torch.randn(c, generator=g)).to(dev) if affine else None
+    shift = (0.3 * torch.randn(c, generator=g)).to(dev) if affine else None
+    act = torch.empty_like(y)
+    pooled = torch.empty(b, h // 2, w // 2, c, device=dev)
+    idx = torch.empty(b, h // 2, w // 2, c, dtype=torch.uint8, device=dev)
+    ops.affine_relu_pool(y, scale, shift, relu, act, pooled, idx)
+    # the kernel's fused multiply-add: exact product, one rounding (via float64 here)
+    want = (y.double() * scale.double() + shift.double()).float() if affine else y.clone()
+    if relu:
+        want = want.clamp_min(0)
+    assert torch.equal(act, want)
+    ref_pool, ref_idx = F.max_pool2d(want.permute(0, 3, 1, 2), 2, return_indices=True)
+    assert torch.equal(pooled.permute(0, 3, 1, 2), ref_pool)
+    iy, ix = ref_idx // w - 2 * torch.arange(h // 2, device=dev).view(1, 1, -1, 1), ref_idx % w - 2 * torch.arange(
+        w // 2, device=dev).view(1, 1, 1, -1)
+    assert torch.equal(idx.permute(0, 3, 1, 2).long(), iy * 2 + ix)
+    d_pool = torch.randn(pooled.shape, generator=g).to(dev)
+    base = torch.randn(y.shape, generator=g).to(dev)
+    acc = base.clone()
+    ops.maxpool_bwd(d_pool, idx, acc)
+    ref = base.permute(0, 3, 1, 2).contiguous()
+    ref.view(b, c, -1).scatter_add_(2, ref_idx.view(b, c, -1), d_pool.permute(0, 3, 1, 2).reshape(b, c, -1))
+    assert torch.equal(acc.permute(0, 3, 1, 2), ref)
+
+
 @pytest.mark.parametrize("c,ncls", [(32, 4), (8, 5), (6, 3)])
 def test_head_fwd_bwd_with_mask(dev, c, ncls):
     from unet_nested4tiny_objects_keypoints_amd import ops

@@ -40,30 +40,53 @@ inline unsigned grid_for(long items, int cap = 2048 * 8) {
 }
 
 // ------------------------------------------------------------------ BatchNorm statistics
-// partial [n_blocks][C][2] -> per-channel totals in double; one workgroup per channel.
+// partial [n_blocks][C][2] -> per-channel totals in double; one workgroup (kFinThreads or fewer threads) per channel:
+// 8-byte loads, eight rows in flight per thread, wave shuffles, then the waves' totals in wave order.
+constexpr int kFinThreads = 1024;
 __device__ __forceinline__ void reduce_pair_over_blocks(const float* partial, long n_blocks, int C, int c,
                                                          double& s1, double& s2) {
-  __shared__ double red[2][kThreads];
+  __shared__ double red[2][kFinThreads / 64];
   double a = 0.0, b = 0.0;
-  for (long i = threadIdx.x; i < n_blocks; i += kThreads) {
-    a += static_cast<double>(partial[(i * C + c) * 2 + 0]);
-    b += static_cast<double>(partial[(i * C + c) * 2 + 1]);
-  }
-  red[0][threadIdx.x] = a;
-  red[1][threadIdx.x] = b;
-  __syncthreads();
-  for (int s = kThreads / 2; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      red[0][threadIdx.x] += red[0][threadIdx.x + s];
-      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+  const float2* p = reinterpret_cast<const float2*>(partial) + c;
+  const long step = blockDim.x;
+  long i = threadIdx.x;
+  for (; i + 7 * step < n_blocks; i += 8 * step) {
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(i + u * step) * C];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a += static_cast<double>(v[u].x);
+      b += static_cast<double>(v[u].y);
     }
-    __syncthreads();
   }
-  s1 = red[0][0];
-  s2 = red[1][0];
+  for (; i < n_blocks; i += step) {
+    const float2 v = p[i * C];
+    a += static_cast<double>(v.x);
+    b += static_cast<double>(v.y);
+  }
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    a += __shfl_xor(a, m);
+    b += __shfl_xor(b, m);
+  }
+  const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[0][wave] = a;
+    red[1][wave] = b;
+  }
+  __syncthreads();
+  a = 0.0;
+  b = 0.0;
+  for (int w = 0; w < n_waves; ++w) {
+    a += red[0][w];
+    b += red[1][w];
+  }
+  s1 = a;
+  s2 = b;
 }
 
-__global__ __launch_bounds__(kThreads) void bn_finalize_kernel(const float* partial, long n_blocks, int C, long count,
+__global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(const float* partial, long n_blocks, int C, long count,
                                                                const float* gamma, const float* beta, float eps,
                                                                float momentum, float* running_mean, float* running_var,
                                                                float* mean, float* invstd, float* scale, float* shift) {
@@ -98,7 +121,7 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
   shift[c] = beta[c] - rm[c] * sc;
 }
 
-__global__ __launch_bounds__(kThreads) void bn_bwd_finalize_kernel(const float* partial, long n_blocks, int C,
+__global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_kernel(const float* partial, long n_blocks, int C,
                                                                    float* dgamma, float* dbeta) {
   const int c = blockIdx.x;
   double s1, s2;
@@ -198,6 +221,81 @@ __global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const float* __re
       const int q = pool_idx[i * VEC + k];
       const long pix = (static_cast<long>(n) * H + (2 * yo + (q >> 1))) * W + (2 * xo + (q & 1));
       d_act[(pix * CG + cg) * VEC + k] += d_pooled[i * VEC + k];
+    }
+  }
+}
+
+// Row-structured forms of the two pool kernels for 4-aligned channels and tensors below 2^31 elements: a workgroup
+// walks whole rows of windows (row = n * Ho + yo), a thread the (window, channel quad) items j = xo * CG + cg of the
+// row, so the index arithmetic is 32-bit and division free (the item's two input rows sit at 2j - cg and
+// 2j - cg + CG quads from the row starts) and the four argmax bytes of a quad leave as one dword.
+__global__ __launch_bounds__(kThreads) void affine_relu_pool_rows_kernel(
+    const f32x4* __restrict__ y, const f32x4* __restrict__ scale, const f32x4* __restrict__ shift, int relu,
+    unsigned rows, unsigned Wo, unsigned CG, f32x4* __restrict__ act, f32x4* __restrict__ pooled,
+    uint32_t* __restrict__ pool_idx) {
+  const unsigned row_items = Wo * CG;  // quads per pooled row; an input row holds 2 * row_items quads
+  for (unsigned row = blockIdx.x; row < rows; row += gridDim.x) {
+    const unsigned in0 = row * 4u * row_items;  // input row 2 * row (rows of one image are consecutive: H = 2 Ho)
+    for (unsigned j = threadIdx.x; j < row_items; j += kThreads) {
+      const unsigned cg = j % CG;
+      const unsigned a = in0 + 2u * j - cg;
+      const unsigned off[4] = {a, a + CG, a + 2u * row_items, a + 2u * row_items + CG};
+      f32x4 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = y[off[q]];
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (scale != nullptr) {
+        sc = scale[cg];
+        sh = shift[cg];
+      }
+      f32x4 best;
+      uint32_t bi = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float t = fmaf(v[q][k], sc[k], sh[k]);
+          if (relu) t = fmaxf(t, 0.f);
+          v[q][k] = t;
+          if (q == 0) {
+            best[k] = t;
+          } else if (t > best[k]) {  // first maximum wins, scan order (0,0),(0,1),(1,0),(1,1)
+            best[k] = t;
+            bi = (bi & ~(0xffu << (8 * k))) | (static_cast<uint32_t>(q) << (8 * k));
+          }
+        }
+        if (act != nullptr) act[off[q]] = v[q];
+      }
+      pooled[row * row_items + j] = best;
+      if (pool_idx != nullptr) pool_idx[row * row_items + j] = bi;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void maxpool_bwd_rows_kernel(const f32x4* __restrict__ d_pooled,
+                                                                    const uint32_t* __restrict__ pool_idx, unsigned rows,
+                                                                    unsigned Wo, unsigned CG, f32x4* __restrict__ d_act) {
+  const unsigned row_items = Wo * CG;
+  for (unsigned row = blockIdx.x; row < rows; row += gridDim.x) {
+    const unsigned in0 = row * 4u * row_items;
+    for (unsigned j = threadIdx.x; j < row_items; j += kThreads) {
+      const unsigned cg = j % CG;
+      const unsigned a = in0 + 2u * j - cg;
+      const unsigned off[4] = {a, a + CG, a + 2u * row_items, a + 2u * row_items + CG};
+      const uint32_t bi = pool_idx[row * row_items + j];
+      const f32x4 d = d_pooled[row * row_items + j];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) any = any || ((bi >> (8 * k)) & 0xffu) == static_cast<uint32_t>(q);
+        if (any) {  // untouched quads are neither read nor written
+          f32x4 g = d_act[off[q]];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) g[k] += (((bi >> (8 * k)) & 0xffu) == static_cast<uint32_t>(q)) ? d[k] : 0.f;
+          d_act[off[q]] = g;
+        }
+      }
     }
   }
 }
@@ -812,6 +910,9 @@ __global__ __launch_bounds__(kThreads) void nhwc_to_nchw_kernel(const float* __r
   }
 }
 
+inline unsigned fin_threads(long n_blocks) {  // workgroup size of the per-channel reductions over partial rows
+  return n_blocks >= 4096 ? 1024u : n_blocks >= 1024 ? 512u : 256u;
+}
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -827,8 +928,9 @@ extern "C" int unetpp_bn_finalize(const float* partial, int64_t n_blocks, int32_
   if (!partial || n_blocks < 1 || C < 1 || count < 1 || !gamma || !beta || !mean || !invstd || !scale || !shift)
     return UNETPP_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return UNETPP_EINVAL;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(kThreads), 0, ST(stream), partial, n_blocks, C, count, gamma,
-                     beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  if ((reinterpret_cast<uintptr_t>(partial) & 7) != 0) return UNETPP_EINVAL;  // rows are read as (sum, sum of squares) pairs
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(fin_threads(n_blocks)), 0, ST(stream), partial, n_blocks, C,
+                     count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
   return launch_status();
 }
 
@@ -840,6 +942,13 @@ extern "C" int unetpp_bn_eval_coeffs(const float* gamma, const float* beta, cons
                      running_var, eps, C, scale, shift);
   return launch_status();
 }
+
+namespace {
+// the row-structured pool kernels: 32-bit element offsets, rows long enough to occupy a workgroup
+inline bool rows_form_ok(int N, int H, int W, int C) {
+  return static_cast<long>(N) * H * W * C < 0x7fffffffL && static_cast<long>(W / 2) * (C / 4) >= 64;
+}
+}  // namespace
 
 extern "C" int unetpp_affine_relu_pool(const float* y, const float* scale, const float* shift, int32_t relu, int32_t N,
                                        int32_t H, int32_t W, int32_t C, float* act, float* pooled, uint8_t* pool_idx,
@@ -863,7 +972,15 @@ extern "C" int unetpp_affine_relu_pool(const float* y, const float* scale, const
   }
   if ((H & 1) || (W & 1)) return UNETPP_EINVAL;
   const long windows = static_cast<long>(N) * (H / 2) * (W / 2);
-  if (vec)
+  const unsigned rows = static_cast<unsigned>(N * (H / 2)), row_items = static_cast<unsigned>((W / 2) * (C / 4));
+  if (vec && rows_form_ok(N, H, W, C) && (scale == nullptr || (aligned16(scale) && aligned16(shift))) &&
+      (reinterpret_cast<uintptr_t>(pool_idx) & 3) == 0)
+    hipLaunchKernelGGL(affine_relu_pool_rows_kernel, dim3(rows < 16384u ? rows : 16384u), dim3(kThreads), 0, ST(stream),
+                       reinterpret_cast<const f32x4*>(y), reinterpret_cast<const f32x4*>(scale),
+                       reinterpret_cast<const f32x4*>(shift), relu, rows, static_cast<unsigned>(W / 2),
+                       static_cast<unsigned>(C / 4), reinterpret_cast<f32x4*>(act), reinterpret_cast<f32x4*>(pooled),
+                       reinterpret_cast<uint32_t*>(pool_idx));
+  else if (vec)
     hipLaunchKernelGGL(affine_relu_pool_kernel<4>, dim3(grid_for(windows * (C / 4))), dim3(kThreads), 0, ST(stream), y,
                        scale, shift, relu, N, H, W, C / 4, act, pooled, pool_idx);
   else
@@ -876,7 +993,13 @@ extern "C" int unetpp_maxpool_bwd(const float* d_pooled, const uint8_t* pool_idx
                                   int32_t C, float* d_act, void* stream) {
   if (!d_pooled || !pool_idx || !d_act || N < 1 || H < 2 || W < 2 || C < 1 || (H & 1) || (W & 1)) return UNETPP_EINVAL;
   const long windows = static_cast<long>(N) * (H / 2) * (W / 2);
-  if (C % 4 == 0)
+  const unsigned rows = static_cast<unsigned>(N * (H / 2));
+  if (C % 4 == 0 && rows_form_ok(N, H, W, C) && aligned16(d_pooled) && aligned16(d_act) &&
+      (reinterpret_cast<uintptr_t>(pool_idx) & 3) == 0)
+    hipLaunchKernelGGL(maxpool_bwd_rows_kernel, dim3(rows < 16384u ? rows : 16384u), dim3(kThreads), 0, ST(stream),
+                       reinterpret_cast<const f32x4*>(d_pooled), reinterpret_cast<const uint32_t*>(pool_idx), rows,
+                       static_cast<unsigned>(W / 2), static_cast<unsigned>(C / 4), reinterpret_cast<f32x4*>(d_act));
+  else if (C % 4 == 0)
     hipLaunchKernelGGL(maxpool_bwd_kernel<4>, dim3(grid_for(windows * (C / 4))), dim3(kThreads), 0, ST(stream), d_pooled,
                        pool_idx, N, H, W, C / 4, d_act);
   else
@@ -931,8 +1054,9 @@ extern "C" int unetpp_bn_bwd_reduce(const float* d_act, const float* y, const fl
 extern "C" int unetpp_bn_bwd_finalize(const float* partial, int64_t n_blocks, int32_t C, float* dgamma, float* dbeta,
                                       void* stream) {
   if (!partial || n_blocks < 1 || C < 1 || !dgamma || !dbeta) return UNETPP_EINVAL;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(kThreads), 0, ST(stream), partial, n_blocks, C, dgamma,
-                     dbeta);
+  if ((reinterpret_cast<uintptr_t>(partial) & 7) != 0) return UNETPP_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(fin_threads(n_blocks)), 0, ST(stream), partial, n_blocks, C,
+                     dgamma, dbeta);
   return launch_status();
 }
 
