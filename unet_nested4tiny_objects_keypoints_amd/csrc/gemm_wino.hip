@@ -52,6 +52,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
   float* in_tile = smem;             // buffers of the chunk being computed
   float* w_tile = smem + IN_FLOATS;
+  __shared__ float stat_lds[4 * WNC * 2];  // the four waves' BatchNorm partial sums of the unit just finished
 
   const unetpp_gemm_desc& d = a.d;
   const int tid = threadIdx.x;
@@ -275,7 +276,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
       for (int nh = 0; nh < NH; ++nh) acc[xi][nh] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (want_stats) {  // the LDS tiles are free here (barrier after the MFMA loop)
+    if (want_stats) {
+      // Per-wave sums go to LDS here; flush_stats() adds the four waves and writes the row AFTER the barrier that
+      // follows every epilogue anyway (the next epilogue is at least one more barrier away).
 #pragma unroll
       for (int nh = 0; nh < NH; ++nh) {
         s1[nh] += __shfl_xor(s1[nh], 16);
@@ -283,24 +286,26 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
         s1[nh] += __shfl_xor(s1[nh], 32);
         s2[nh] += __shfl_xor(s2[nh], 32);
         if (g == 0) {
-          w_tile[(wave * 32 + t16 + 16 * nh) * 2 + 0] = s1[nh];  // weight tile as scratch: the input tile may still
-          w_tile[(wave * 32 + t16 + 16 * nh) * 2 + 1] = s2[nh];  // be another wave's transpose scratch
+          stat_lds[(wave * WNC + t16 + 16 * nh) * 2 + 0] = s1[nh];
+          stat_lds[(wave * WNC + t16 + 16 * nh) * 2 + 1] = s2[nh];
         }
       }
-      __syncthreads();
-      if (tid < tc.n_cnt) {
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          t1 += w_tile[(w * 32 + tid) * 2 + 0];
-          t2 += w_tile[(w * 32 + tid) * 2 + 1];
-        }
-        float* dst = d.stats_partial + (ug.patch * a.Ncols + tc.n0 + tid) * 2;
-        dst[0] = t1;
-        dst[1] = t2;
-      }
-      __syncthreads();  // before the next chunk overwrites the scratch
     }
+  };
+  auto flush_stats = [&](long k) {
+    if (d.stats_partial == nullptr || tid >= 16 * NH) return;
+    const UnitGeom ug = decode_unit<LOG2TW>(a, ur.first + k);
+    const TileCols tc = decode_tile(a, ug.group);
+    if (tid >= tc.n_cnt) return;
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      t1 += stat_lds[(w * WNC + tid) * 2 + 0];
+      t2 += stat_lds[(w * WNC + tid) * 2 + 1];
+    }
+    float* dst = d.stats_partial + (ug.patch * a.Ncols + tc.n0 + tid) * 2;
+    dst[0] = t1;
+    dst[1] = t2;
   };
 
   prefetch_unit(0);
@@ -390,6 +395,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     if (c_chunk + 1 == a.n_chunks) {
       epilogue(c_unit);  // the current buffers are its scratch; stores drain while the next unit computes
       __syncthreads();   // before the next chunk's staging overwrites that scratch
+      flush_stats(c_unit);
       ++c_unit;
       c_chunk = 0;
     } else {
