@@ -34,6 +34,22 @@ constexpr int WNC = 32;     // columns per unit
 constexpr int WP = 10;      // LDS pixel stride of the input patch (floats): 8 channels + 2 pad
 constexpr int WIMG = 4096;  // floats of one (column tile, chunk) weight image
 
+// In-kernel phase stamps (profiling builds only: -DUNETPP_WINO_STAMPS, see tools/wino_stamps.py): every wave adds the
+// s_memtime cycles it spent in each phase of its (unit, chunk) stream to a global table.
+#ifdef UNETPP_WINO_STAMPS
+__device__ unsigned long long g_wino_stamps[16];
+#define WINO_STAMP(i)                          \
+  do {                                         \
+    const unsigned long long now_ = clock64(); \
+    st_acc[i] += now_ - st_last;               \
+    st_last = now_;                            \
+  } while (0)
+#else
+#define WINO_STAMP(i) \
+  do {                \
+  } while (0)
+#endif
+
 // NH = 16-column halves of the tile that are computed: 2, or 1 when no output view is wider than 16 channels (narrow
 // networks, e.g. the reference's default base width 16) -- the second half would multiply zero weights.
 template <int LOG2TW, int NH>
@@ -83,9 +99,25 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   const float* p_wimg = nullptr;
   const int cc = (tid & 1) << 2;  // channel quad of every staging item of this thread (kThreads is even)
 
+  // The unit run is contiguous, so both cursors (prefetch side, compute side) are decoded once and then stepped:
+  // column group fastest, then the patch along x, y, image -- scalar adds and compares instead of four divisions.
+  auto step_unit = [&](UnitGeom& u) {
+    if (++u.group < a.n_groups) return;
+    u.group = 0;
+    ++u.patch;
+    u.tx0 += TW;
+    if (u.tx0 < a.tiles_x * TW) return;
+    u.tx0 = 0;
+    u.ty0 += TH;
+    if (u.ty0 < a.tiles_y * TH) return;
+    u.ty0 = 0;
+    ++u.n;
+  };
+  UnitGeom p_ug = decode_unit<LOG2TW>(a, ur.first), c_ug = p_ug;
+
   long p_patch = -1;
-  auto prefetch_unit = [&](long k) -> bool {  // returns true when the pixel patch is the previous unit's
-    const UnitGeom ug = decode_unit<LOG2TW>(a, ur.first + k);
+  auto prefetch_unit = [&]() -> bool {  // returns true when the pixel patch is the previous unit's
+    const UnitGeom& ug = p_ug;
     p_wimg = d.weight_image + static_cast<long>(ug.group) * a.n_chunks * WIMG;
     if (ug.patch == p_patch) return true;
     p_patch = ug.patch;
@@ -158,8 +190,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 
   // ---- epilogue of a finished unit: output transform, bias / ReLU / gate / accumulate, BatchNorm partial sums ----
   // Register rr of acc[xi][nh] of lane (t16, g) belongs to tile 16*wave + 4*g + rr and column t16 + 16*nh.
-  auto epilogue = [&](long k) {
-    const UnitGeom ug = decode_unit<LOG2TW>(a, ur.first + k);
+  auto epilogue = [&]() {
+    const UnitGeom& ug = c_ug;
     const TileCols tc = decode_tile(a, ug.group);
     const unetpp_view& O = d.out[tc.ov];
     const bool interior = (ug.ty0 + TH <= d.H) && (ug.tx0 + TW <= d.W);
@@ -292,9 +324,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       }
     }
   };
-  auto flush_stats = [&](long k) {
+  auto flush_stats = [&]() {
     if (d.stats_partial == nullptr || tid >= 16 * NH) return;
-    const UnitGeom ug = decode_unit<LOG2TW>(a, ur.first + k);
+    const UnitGeom& ug = c_ug;
     const TileCols tc = decode_tile(a, ug.group);
     if (tid >= tc.n_cnt) return;
     float t1 = 0.f, t2 = 0.f;
@@ -308,14 +340,18 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     dst[1] = t2;
   };
 
-  prefetch_unit(0);
+#ifdef UNETPP_WINO_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = clock64();
+#endif
+  prefetch_unit();
   view_offsets(d.in[0]);
   load_chunk();
   store_chunk(in_tile, w_tile);
   __syncthreads();
+  WINO_STAMP(0);  // 0: prologue
 
-  long c_unit = 0;  // compute side: unit and chunk currently in LDS
-  int c_chunk = 0;
+  int c_chunk = 0;  // compute side: chunk of unit c_ug currently in LDS
   int cur = 0;      // buffer being computed from
   while (true) {
     // ---- advance the prefetch cursor: next chunk of this unit, or chunk 0 of the next unit ----
@@ -339,12 +375,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
         const bool same_view = p_s == 0;
         p_s = 0;
         p_c0 = 0;
-        if (!prefetch_unit(p_unit) || !same_view) view_offsets(d.in[0]);  // same patch and view: offsets still valid
+        step_unit(p_ug);
+        if (!prefetch_unit() || !same_view) view_offsets(d.in[0]);  // same patch and view: offsets still valid
       } else {
         more = false;
       }
     }
     load_chunk();
+    WINO_STAMP(1);  // 1: cursor + load issue
 
     // ---- current chunk: per channel s the 4x4 window -> B^T d B in registers -> 32 MFMAs; every accumulator is
     // touched once per channel (no back-to-back dependence), the weight fragments are read AHEAD pairs early ----
@@ -386,17 +424,23 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
         if (NH == 2) acc[xi][NH - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi], uc[1], acc[xi][NH - 1], 0, 0, 0);
       }
       if (s == 0) {  // the next chunk's registers -> the other buffer, half way through this chunk's MFMAs
+        WINO_STAMP(2);  // 2: first half of the MFMA phase
         float* nxt = smem + (cur ^ 1) * BUF;
         store_chunk(nxt, nxt + IN_FLOATS);
+        WINO_STAMP(3);  // 3: staging store
       }
     }
     __builtin_amdgcn_s_setprio(0);
+    WINO_STAMP(4);  // 4: second half of the MFMA phase
     __syncthreads();  // all waves: done reading the current buffers, next buffers written
+    WINO_STAMP(5);  // 5: barrier
     if (c_chunk + 1 == a.n_chunks) {
-      epilogue(c_unit);  // the current buffers are its scratch; stores drain while the next unit computes
+      epilogue();  // the current buffers are its scratch; stores drain while the next unit computes
+      WINO_STAMP(6);  // 6: epilogue
       __syncthreads();   // before the next chunk's staging overwrites that scratch
-      flush_stats(c_unit);
-      ++c_unit;
+      flush_stats();
+      WINO_STAMP(7);  // 7: barrier after the epilogue
+      step_unit(c_ug);
       c_chunk = 0;
     } else {
       ++c_chunk;
@@ -406,9 +450,27 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     in_tile = smem + cur * BUF;
     w_tile = in_tile + IN_FLOATS;
   }
+#ifdef UNETPP_WINO_STAMPS
+  if (lane == 0) {
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_wino_stamps[i], st_acc[i]);
+    atomicAdd(&g_wino_stamps[8], 1ull);
+  }
+#endif
 }
 
 }  // namespace
+
+#ifdef UNETPP_WINO_STAMPS
+extern "C" int unetpp_debug_wino_stamps(unsigned long long* out16, int reset) {  // profiling builds only
+  if (out16 != nullptr && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wino_stamps), sizeof(g_wino_stamps)) != hipSuccess)
+    return UNETPP_ELAUNCH;
+  if (reset) {
+    const unsigned long long zero[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wino_stamps), zero, sizeof(zero)) != hipSuccess) return UNETPP_ELAUNCH;
+  }
+  return UNETPP_OK;
+}
+#endif
 
 bool wino_applies(const unetpp_gemm_desc* d) {
   return d != nullptr && d->taps == 9 && (d->flags & UNETPP_GEMM_DIRECT) == 0;
