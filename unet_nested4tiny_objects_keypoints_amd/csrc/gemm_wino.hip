@@ -18,9 +18,17 @@
 //   * all 16 xi of a (tile, column) land in the same lane and register index, so the output transform A^T M A is
 //     lane-local (24 add/sub per 2x2 tile); bias/ReLU/gate/accumulate/BatchNorm partial sums and 16-byte transposed
 //     stores follow as in the direct kernel;
-//   * K in chunks of 8 channels, staged global -> registers -> LDS one chunk ahead in a persistent, flattened
-//     (unit, chunk) stream; a workgroup walks a CONTIGUOUS run of units (column tile fastest), so the patch geometry
-//     (offsets, bounds mask) is only recomputed when the pixel patch changes; 30 KB LDS, two workgroups per CU.
+//   * K in chunks of 8 channels in a persistent, flattened (unit, chunk) stream: the inputs go global -> registers
+//     (two chunks ahead; BatchNorm fold, ReLU and zero padding are applied on the way) -> LDS, the weight image goes
+//     L2 -> LDS by LDS-DMA one chunk ahead; double-buffered LDS, one barrier per chunk; a workgroup walks a CONTIGUOUS
+//     run of units (column tile fastest) with a scalar cursor, so the patch geometry (offsets, bounds mask) is only
+//     recomputed when the pixel patch changes; 65 KB LDS, two workgroups per CU;
+//   * the LDS operand reads of the MFMA phase are placed by hand (inline asm, one group of 8 MFMAs ahead, one
+//     s_waitcnt per group, scheduling fences around each group): hipcc sinks every ds_read to just in front of its
+//     first use, which leaves a lone wave's matrix pipe idle for an LDS round trip 13 times per 32 MFMAs.
+#include <cstdlib>
+#include <utility>
+
 #include "common.h"
 #include "gemm_units.h"
 
@@ -28,6 +36,62 @@ namespace unetpp {
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// ---- hand-placed LDS reads of the MFMA phase.  hipcc sinks every ds_read to just before its first use (13 exposed
+// LDS latencies per 32 MFMAs); these are issued a whole group of 8 MFMAs ahead and collected by one s_waitcnt per
+// group.  The wait "modifies" the registers it guards, so no consumer can be scheduled above it. ----
+template <int I>
+struct IC {
+  static constexpr int v = I;
+};
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(IC<I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+__device__ __forceinline__ unsigned lds_offset(const float* p) {  // low half of a flat LDS address = LDS byte offset
+  return static_cast<unsigned>(reinterpret_cast<uintptr_t>(p));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_b32(float& v, unsigned addr) {
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+}
+template <int O0, int O1>  // two 8-byte reads 512 * O0 and 512 * O1 bytes above addr
+__device__ __forceinline__ void lds_read2st64_b64(f32x4& v, unsigned addr) {
+  asm volatile("ds_read2st64_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1));
+}
+__device__ __forceinline__ void lds_wait(f32x4& a, f32x4& b) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lds_wait16(float (&d)[16]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]));
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(d[8]), "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15]));
+}
+// input transform B^T d B of one 4x4 window (row major), 32 add/sub
+__device__ __forceinline__ void wino_input_transform(const float (&dd)[16], float (&V)[16]) {
+  float t[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    t[0][j] = dd[0 + j] - dd[8 + j];
+    t[1][j] = dd[4 + j] + dd[8 + j];
+    t[2][j] = dd[8 + j] - dd[4 + j];
+    t[3][j] = dd[4 + j] - dd[12 + j];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    V[4 * i + 0] = t[i][0] - t[i][2];
+    V[4 * i + 1] = t[i][1] + t[i][2];
+    V[4 * i + 2] = t[i][2] - t[i][1];
+    V[4 * i + 3] = t[i][1] - t[i][3];
+  }
+}
 
 constexpr int WKC = 8;      // channels per K chunk
 constexpr int WNC = 32;     // columns per unit
@@ -36,6 +100,13 @@ constexpr int WIMG = 4096;  // floats of one (column tile, chunk) weight image
 
 // In-kernel phase stamps (profiling builds only: -DUNETPP_WINO_STAMPS, see tools/wino_stamps.py): every wave adds the
 // s_memtime cycles it spent in each phase of its (unit, chunk) stream to a global table.
+#ifdef UNETPP_WINO_NO_FENCE  // A/B switch: leave the placement of the LDS reads to the scheduler
+#define WINO_FENCE() \
+  do {               \
+  } while (0)
+#else
+#define WINO_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 #ifdef UNETPP_WINO_STAMPS
 __device__ unsigned long long g_wino_stamps[16];
 #define WINO_STAMP(i)                          \
@@ -62,8 +133,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   constexpr int IN_ITEMS = (NPIX * 2 + kThreads - 1) / kThreads;  // 16-byte items, 2 per pixel (<= 3)
   constexpr int W_ITEMS = WIMG / 4 / kThreads;                    // 4
   static_assert(kMaxHaloPixels * WP <= IN_FLOATS, "input patch does not fit");
-  // Two (input patch, weight image) buffers: the next chunk is written into the other buffer in the MIDDLE of the
-  // current chunk's MFMA phase (its loads were issued at the top of the chunk), so a chunk costs one barrier.
+  // Two (input patch, weight image) buffers: the next chunk is written into the other buffer at the top of the
+  // current chunk (its loads were issued a whole chunk earlier), so a chunk costs one barrier.
   constexpr int BUF = IN_FLOATS + WIMG;
   __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
   float* in_tile = smem;             // buffers of the chunk being computed
@@ -76,6 +147,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 
   const UnitRange ur = my_contiguous_unit_range(a.total_blocks);
   if (ur.count == 0) return;
+  // Everything that steers the (unit, chunk) stream is wave uniform; readfirstlane moves it to scalar registers
+  // (hipcc computes the range with vector divisions and would keep the whole cursor in VGPRs otherwise).
+  const int n_units = __builtin_amdgcn_readfirstlane(static_cast<int>(ur.count));
 
   // compute side: this lane's tile (A operand / input transform) and weight-image slot (B operand)
   const int my_tile = 16 * wave + t16;
@@ -88,16 +162,30 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 #pragma unroll
     for (int nh = 0; nh < NH; ++nh) acc[xi][nh] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- prefetch side (same scheme as gemm_fast.hip): the chunk that is loaded next ----
-  f32x4 reg_in[IN_ITEMS], reg_w[W_ITEMS];
+  // ---- prefetch side: the cursor describes the chunk whose inputs sit in reg_in (two chunks ahead of the MFMAs) ----
+  f32x4 reg_in[IN_ITEMS];
   unsigned voff[IN_ITEMS];
   unsigned in_mask = 0;
   int pf_cnt = 0;
-  long p_unit = 0;
+  int p_unit = 0;
   int p_s = 0, p_c0 = 0, p_chunk = 0;
   int p_n = 0, p_ty0 = 0, p_tx0 = 0;
   const float* p_wimg = nullptr;
   const int cc = (tid & 1) << 2;  // channel quad of every staging item of this thread (kThreads is even)
+  // the cursor's input view, cached (d.in[p_s] is a kernarg read with a scalar-cache round trip at every use)
+  const float* v_ptr = nullptr;
+  const float* v_scale = nullptr;
+  const float* v_shift = nullptr;
+  int v_clen = 0;
+  bool v_relu = false;
+  auto cache_view = [&]() {
+    const unetpp_view& V = d.in[p_s];
+    v_ptr = V.ptr;
+    v_scale = V.scale;
+    v_shift = V.shift;
+    v_clen = V.c_len;
+    v_relu = V.relu != 0;
+  };
 
   // The unit run is contiguous, so both cursors (prefetch side, compute side) are decoded once and then stepped:
   // column group fastest, then the patch along x, y, image -- scalar adds and compares instead of four divisions.
@@ -113,7 +201,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     u.ty0 = 0;
     ++u.n;
   };
-  UnitGeom p_ug = decode_unit<LOG2TW>(a, ur.first), c_ug = p_ug;
+  UnitGeom p_ug = decode_unit<LOG2TW>(a, ur.first);
+  p_ug.n = __builtin_amdgcn_readfirstlane(p_ug.n);
+  p_ug.ty0 = __builtin_amdgcn_readfirstlane(p_ug.ty0);
+  p_ug.tx0 = __builtin_amdgcn_readfirstlane(p_ug.tx0);
+  p_ug.group = __builtin_amdgcn_readfirstlane(p_ug.group);
+  p_ug.patch = __builtin_amdgcn_readfirstlane(static_cast<int>(p_ug.patch));  // < 2^31 (fast_args)
+  UnitGeom c_ug = p_ug;
 
   long p_patch = -1;
   auto prefetch_unit = [&]() -> bool {  // returns true when the pixel patch is the previous unit's
@@ -144,30 +238,57 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       voff[q] = view_pixel_offset32(V, p_n, yy, xx);
     }
   };
-  // Unconditional, straight-line loads (the cursor stays on the last chunk when nothing is left): a conditional load
-  // sits under a branch and hipcc drains vmcnt at the join, which would expose the whole latency.
-  auto load_chunk = [&]() {
-    const unetpp_view& V = d.in[p_s];
-    pf_cnt = min(WKC, V.c_len - p_c0);
+  // next chunk of the unit, or chunk 0 of the next unit; stays on the last chunk when nothing is left (the loads and
+  // stores below are unconditional, straight-line code: a load under a branch makes hipcc drain vmcnt at the join)
+  auto advance = [&]() {
+    if (p_chunk + 1 < a.n_chunks) {
+      ++p_chunk;
+      p_c0 += WKC;
+      if (p_c0 >= v_clen) {
+        ++p_s;
+        p_c0 = 0;
+        cache_view();
+        view_offsets(d.in[p_s]);
+      }
+    } else if (p_unit + 1 < n_units) {
+      ++p_unit;
+      p_chunk = 0;
+      p_c0 = 0;
+      const bool same_view = p_s == 0;
+      if (!same_view) {
+        p_s = 0;
+        cache_view();
+      }
+      step_unit(p_ug);
+      if (!prefetch_unit() || !same_view) view_offsets(d.in[0]);  // same patch and view: offsets still valid
+    }
+  };
+  auto load_inputs = [&]() {
+    pf_cnt = min(WKC, v_clen - p_c0);
 #pragma unroll
     for (int q = 0; q < IN_ITEMS; ++q) {
       const unsigned off = voff[q] + static_cast<unsigned>(p_c0 + (cc < pf_cnt ? cc : 0));
-      reg_in[q] = *reinterpret_cast<const f32x4*>(V.ptr + off);
+      reg_in[q] = *reinterpret_cast<const f32x4*>(v_ptr + off);
     }
+  };
+  // The weight image of the cursor's chunk goes L2 -> LDS directly (LDS-DMA, 1 KB per wave and instruction, lane
+  // linear like the image itself): no staging registers.
+  auto dma_weights = [&](float* w_dst) {
     const float* wp = p_wimg + static_cast<long>(p_chunk) * WIMG;
 #pragma unroll
-    for (int q = 0; q < W_ITEMS; ++q) reg_w[q] = *reinterpret_cast<const f32x4*>(wp + (tid + q * kThreads) * 4);
+    for (int q = 0; q < W_ITEMS; ++q)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wp + (tid + q * kThreads) * 4),
+                                       (lptr_t)(w_dst + (q * kThreads + wave * 64) * 4), 16, 0, 0);
   };
-  auto store_chunk = [&](float* in_dst, float* w_dst) {
-    const unetpp_view& V = d.in[p_s];
-    const bool affine = V.scale != nullptr;  // BatchNorm apply + ReLU folded into the operand load
+  auto store_chunk = [&](float* in_dst) {
+    const bool affine = v_scale != nullptr;  // BatchNorm apply + ReLU folded into the operand load
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (affine) {
       const int ch = p_c0 + (cc < pf_cnt ? cc : 0);
-      sc = *reinterpret_cast<const f32x4*>(V.scale + ch);
-      sh = *reinterpret_cast<const f32x4*>(V.shift + ch);
+      sc = *reinterpret_cast<const f32x4*>(v_scale + ch);
+      sh = *reinterpret_cast<const f32x4*>(v_shift + ch);
     }
-    const float floor_v = V.relu ? 0.f : -__builtin_inff();
+    const float floor_v = v_relu ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int q = 0; q < IN_ITEMS; ++q) {
       const int it = tid + q * kThreads;
@@ -184,8 +305,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
         *reinterpret_cast<f32x2*>(&in_dst[(it >> 1) * WP + cc + 2]) = f32x2{v[2], v[3]};
       }
     }
-#pragma unroll
-    for (int q = 0; q < W_ITEMS; ++q) *reinterpret_cast<f32x4*>(&w_dst[(tid + q * kThreads) * 4]) = reg_w[q];
   };
 
   // ---- epilogue of a finished unit: output transform, bias / ReLU / gate / accumulate, BatchNorm partial sums ----
@@ -344,94 +463,83 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_last = clock64();
 #endif
+  // ---- pipeline: at the top of chunk c the registers hold the inputs of chunk c+1 (loaded a whole chunk ago); they
+  // go to the other LDS buffer, its weight image follows by DMA, the inputs of chunk c+2 are requested, and then the
+  // 64 MFMAs of chunk c run without interruption.  One barrier per chunk. ----
+  cache_view();
   prefetch_unit();
   view_offsets(d.in[0]);
-  load_chunk();
-  store_chunk(in_tile, w_tile);
+  load_inputs();
+  dma_weights(w_tile);
+  store_chunk(in_tile);
+  advance();
+  load_inputs();
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_ITEMS) : "memory");  // the weight DMA has landed (the loads are younger)
   __syncthreads();
   WINO_STAMP(0);  // 0: prologue
 
-  int c_chunk = 0;  // compute side: chunk of unit c_ug currently in LDS
-  int cur = 0;      // buffer being computed from
+  int c_chunk = 0, c_unit = 0;  // compute side: chunk of unit c_ug currently in LDS
+  int cur = 0;                  // buffer being computed from
   while (true) {
-    // ---- advance the prefetch cursor: next chunk of this unit, or chunk 0 of the next unit ----
-    bool more = true;
-    {
-      int s2 = p_s, c2 = p_c0 + WKC;
-      if (c2 >= d.in[p_s].c_len) {
-        ++s2;
-        c2 = 0;
-      }
-      if (p_chunk + 1 < a.n_chunks) {
-        ++p_chunk;
-        if (s2 != p_s) {
-          p_s = s2;
-          view_offsets(d.in[p_s]);
-        }
-        p_c0 = c2;
-      } else if (p_unit + 1 < ur.count) {
-        ++p_unit;
-        p_chunk = 0;
-        const bool same_view = p_s == 0;
-        p_s = 0;
-        p_c0 = 0;
-        step_unit(p_ug);
-        if (!prefetch_unit() || !same_view) view_offsets(d.in[0]);  // same patch and view: offsets still valid
-      } else {
-        more = false;
-      }
-    }
-    load_chunk();
-    WINO_STAMP(1);  // 1: cursor + load issue
+    // ---- this chunk's first LDS operands are requested before the staging work below, which covers their latency
+    const unsigned in_b = lds_offset(in_tile) + a_base * 4, w_b = lds_offset(w_tile) + b_base * 4;
+    float dd[16], ddn[16], V[16];
+    f32x4 us[2][2];  // two register sets of four weight fragments (steps 4g .. 4g+3), read one group ahead
+    static_for<16>([&](auto ic) {
+      constexpr int e = decltype(ic)::v;
+      lds_read_b32<((e / 4) * HWp + (e % 4)) * WP * 4>(dd[e], in_b);
+    });
+    lds_read2st64_b64<0, 1>(us[0][0], w_b);
+    lds_read2st64_b64<2, 3>(us[0][1], w_b);
 
-    // ---- current chunk: per channel s the 4x4 window -> B^T d B in registers -> 32 MFMAs; every accumulator is
-    // touched once per channel (no back-to-back dependence), the weight fragments are read AHEAD pairs early ----
-    // Raised wave priority for the MFMA phase: the co-resident workgroup's wave on this SIMD is usually in its staging
-    // or epilogue VALU code, and the matrix pipe should never wait behind that (+4 % measured).
+    float* other = smem + (cur ^ 1) * BUF;
+    store_chunk(other);
+    dma_weights(other + IN_FLOATS);
+    advance();
+    load_inputs();
+    WINO_STAMP(1);  // 1: staging store, cursor, load issue
+
+    // ---- per channel s the 4x4 window -> B^T d B in registers -> 32 MFMAs; every accumulator is touched once per
+    // channel (no back-to-back dependence).  Raised wave priority for the MFMA phase: the co-resident workgroup's wave
+    // on this SIMD is usually in its staging or epilogue VALU code, and the matrix pipe should never wait behind that.
     __builtin_amdgcn_s_setprio(2);
-    constexpr int AHEAD = 2;
-    f32x2 u[AHEAD + 1];
-#pragma unroll
-    for (int q = 0; q < AHEAD; ++q) u[q] = *reinterpret_cast<const f32x2*>(&w_tile[q * 128 + b_base]);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      float dd[4][4], t[4][4], V[16];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dd[i][j] = in_tile[a_base + (i * HWp + j) * WP + s];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        t[0][j] = dd[0][j] - dd[2][j];
-        t[1][j] = dd[1][j] + dd[2][j];
-        t[2][j] = dd[2][j] - dd[1][j];
-        t[3][j] = dd[1][j] - dd[3][j];
+    lds_wait16(dd);
+    lds_wait(us[0][0], us[0][1]);
+    wino_input_transform(dd, V);
+    static_for<8>([&](auto gc) {  // group g = steps 4g .. 4g+3 of the chunk's 32 ([s][xi]); 8 MFMAs each
+      constexpr int g = decltype(gc)::v, cs = g & 1, ns = cs ^ 1;
+      if constexpr (g + 1 < 8) {
+        lds_read2st64_b64<4 * (g + 1), 4 * (g + 1) + 1>(us[ns][0], w_b);
+        lds_read2st64_b64<4 * (g + 1) + 2, 4 * (g + 1) + 3>(us[ns][1], w_b);
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        V[4 * i + 0] = t[i][0] - t[i][2];
-        V[4 * i + 1] = t[i][1] + t[i][2];
-        V[4 * i + 2] = t[i][2] - t[i][1];
-        V[4 * i + 3] = t[i][1] - t[i][3];
+      if constexpr (g == 0) {  // the second channel's window, needed from group 4 on
+        static_for<16>([&](auto ic) {
+          constexpr int e = decltype(ic)::v;
+          lds_read_b32<(((e / 4) * HWp + (e % 4)) * WP + 1) * 4>(ddn[e], in_b);
+        });
       }
+      // fences: the group's MFMAs (and the transform arithmetic feeding them) stay between the reads issued above
+      // and the wait below -- left alone, the scheduler puts the reads straight in front of the wait again
+      WINO_FENCE();
 #pragma unroll
-      for (int xi = 0; xi < 16; ++xi) {
-        const int step = s * 16 + xi;  // fragment index inside the image: [s][xi]
-        if (step + AHEAD < 32)
-          u[(step + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const f32x2*>(&w_tile[(step + AHEAD) * 128 + b_base]);
-        const f32x2 uc = u[step % (AHEAD + 1)];
-        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi], uc[0], acc[xi][0], 0, 0, 0);
-        if (NH == 2) acc[xi][NH - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi], uc[1], acc[xi][NH - 1], 0, 0, 0);
+      for (int q = 0; q < 4; ++q) {
+        const int xi = (4 * g + q) & 15;
+        const f32x4 up = us[cs][q >> 1];
+        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi], up[(q & 1) * 2], acc[xi][0], 0, 0, 0);
+        if (NH == 2)
+          acc[xi][NH - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi], up[(q & 1) * 2 + 1], acc[xi][NH - 1], 0, 0, 0);
       }
-      if (s == 0) {  // the next chunk's registers -> the other buffer, half way through this chunk's MFMAs
+      WINO_FENCE();
+      if constexpr (g == 0) lds_wait16(ddn);
+      if constexpr (g + 1 < 8) lds_wait(us[ns][0], us[ns][1]);
+      if constexpr (g == 3) {
         WINO_STAMP(2);  // 2: first half of the MFMA phase
-        float* nxt = smem + (cur ^ 1) * BUF;
-        store_chunk(nxt, nxt + IN_FLOATS);
-        WINO_STAMP(3);  // 3: staging store
+        wino_input_transform(ddn, V);
       }
-    }
+    });
     __builtin_amdgcn_s_setprio(0);
     WINO_STAMP(4);  // 4: second half of the MFMA phase
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_ITEMS) : "memory");  // this wave's share of the next weight image is in
     __syncthreads();  // all waves: done reading the current buffers, next buffers written
     WINO_STAMP(5);  // 5: barrier
     if (c_chunk + 1 == a.n_chunks) {
@@ -442,10 +550,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       WINO_STAMP(7);  // 7: barrier after the epilogue
       step_unit(c_ug);
       c_chunk = 0;
+      if (++c_unit == n_units) break;
     } else {
       ++c_chunk;
     }
-    if (!more) break;
     cur ^= 1;
     in_tile = smem + cur * BUF;
     w_tile = in_tile + IN_FLOATS;
@@ -485,6 +593,9 @@ int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     return UNETPP_ELAUNCH;
   long workers = (2L * cus) & ~7L;  // persistent grid: two workgroups per CU (= the kernel's launch bounds)
+#ifdef UNETPP_WINO_STAMPS
+  if (const char* e = getenv("UNETPP_WINO_ONE_PER_CU"); e != nullptr && e[0] == '1') workers = cus & ~7L;  // waves alone on their SIMD
+#endif
   if (workers < 8) workers = 8;
   const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(kThreads);
   bool narrow = true;  // no output view wider than 16 channels: the second column half is never used
