@@ -16,7 +16,7 @@ from unet_nested4tiny_objects_keypoints_amd.ops import V  # noqa: E402
 ci, co, hw = (int(v) for v in (sys.argv[1:4] if len(sys.argv) >= 4 else (32, 32, 256)))
 B = int(os.environ.get("B", "32"))
 REPS = int(os.environ.get("REPS", "10"))
-PHASES = ["prologue", "cursor + load issue", "MFMA first half (s=0)", "staging store", "MFMA second half (s=1)",
+PHASES = ["prologue", "staging store + cursor + load issue", "MFMA first half (s=0)", "(unused)", "MFMA second half (s=1)",
           "barrier after MFMA", "epilogue", "barrier after epilogue + stats"]
 
 lib = _lib.lib()

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("UNETPP_LIB", os.path.join(_PKG_DIR, "libunetpp_hip.so
 CSRC = os.path.join(_PKG_DIR, "csrc")
 INCLUDE = os.path.join(_REPO, "include")
 SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_wino.hip", "weight_image.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "wgrad_wino.hip", "first_layer.hip", "pointwise.hip", "caller.hip")
-HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h")
+HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h", "lds_asm.h")
 MAX_VIEWS = 8
 ABI_VERSION = 3
 # packed-f32 VALU (SLP-vectorised add pairs) costs issue slots beside MFMAs: keep the Winograd transforms scalar

@@ -31,6 +31,7 @@
 
 #include "common.h"
 #include "gemm_units.h"
+#include "lds_asm.h"
 
 namespace unetpp {
 namespace {
@@ -39,41 +40,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// ---- hand-placed LDS reads of the MFMA phase.  hipcc sinks every ds_read to just before its first use (13 exposed
-// LDS latencies per 32 MFMAs); these are issued a whole group of 8 MFMAs ahead and collected by one s_waitcnt per
-// group.  The wait "modifies" the registers it guards, so no consumer can be scheduled above it. ----
-template <int I>
-struct IC {
-  static constexpr int v = I;
-};
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(IC<I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-__device__ __forceinline__ unsigned lds_offset(const float* p) {  // low half of a flat LDS address = LDS byte offset
-  return static_cast<unsigned>(reinterpret_cast<uintptr_t>(p));
-}
-template <int OFF>
-__device__ __forceinline__ void lds_read_b32(float& v, unsigned addr) {
-  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-}
-template <int O0, int O1>  // two 8-byte reads 512 * O0 and 512 * O1 bytes above addr
-__device__ __forceinline__ void lds_read2st64_b64(f32x4& v, unsigned addr) {
-  asm volatile("ds_read2st64_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1));
-}
-__device__ __forceinline__ void lds_wait(f32x4& a, f32x4& b) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ void lds_wait16(float (&d)[16]) {
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]));
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(d[8]), "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15]));
-}
 // input transform B^T d B of one 4x4 window (row major), 32 add/sub
 __device__ __forceinline__ void wino_input_transform(const float (&dd)[16], float (&V)[16]) {
   float t[4][4];
@@ -534,7 +500,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       if constexpr (g + 1 < 8) lds_wait(us[ns][0], us[ns][1]);
       if constexpr (g == 3) {
         WINO_STAMP(2);  // 2: first half of the MFMA phase
-        wino_input_transform(ddn, V);
+        wino_input_transform(ddn, V);  // (inside group 4's fences it interleaves with the MFMAs, and is 1 % slower)
       }
     });
     __builtin_amdgcn_s_setprio(0);
