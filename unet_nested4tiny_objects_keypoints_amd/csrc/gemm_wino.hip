@@ -254,18 +254,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       sc = *reinterpret_cast<const f32x4*>(v_scale + ch);
       sh = *reinterpret_cast<const f32x4*>(v_shift + ch);
     }
-    const float floor_v = v_relu ? 0.f : -__builtin_inff();
 #pragma unroll
     for (int q = 0; q < IN_ITEMS; ++q) {
       const int it = tid + q * kThreads;
       const bool keep = ((in_mask >> q) & 1u) && cc < pf_cnt;
       f32x4 v = reg_in[q];
-      if (affine) {
+      if (affine) {  // wave-uniform branches: plain views (most launches) only pay for the padding select
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
       }
+      if (v_relu) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = keep ? fmaxf(v[e], floor_v) : 0.f;  // zero padding AFTER the transform
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0.f;  // zero padding AFTER the transform
       if (it < NPIX * 2) {  // 40-byte pixel rows: two 8-byte stores
         *reinterpret_cast<f32x2*>(&in_dst[(it >> 1) * WP + cc]) = f32x2{v[0], v[1]};
         *reinterpret_cast<f32x2*>(&in_dst[(it >> 1) * WP + cc + 2]) = f32x2{v[2], v[3]};
