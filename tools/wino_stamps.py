@@ -13,23 +13,34 @@ import torch  # noqa: E402
 from unet_nested4tiny_objects_keypoints_amd import _lib, engine, ops  # noqa: E402
 from unet_nested4tiny_objects_keypoints_amd.ops import V  # noqa: E402
 
-ci, co, hw = (int(v) for v in (sys.argv[1:4] if len(sys.argv) >= 4 else (32, 32, 256)))
+WGRAD = "--wgrad" in sys.argv  # the weight-gradient kernel (wgrad_wino.hip built with -DUNETPP_WWINO_STAMPS)
+args = [v for v in sys.argv[1:] if not v.startswith("--")]
+ci, co, hw = (int(v) for v in (args[:3] if len(args) >= 3 else (32, 32, 256)))
 B = int(os.environ.get("B", "32"))
 REPS = int(os.environ.get("REPS", "10"))
 PHASES = ["prologue", "staging store + cursor + load issue", "MFMA first half (s=0)", "(unused)", "MFMA second half (s=1)",
           "barrier after MFMA", "epilogue", "barrier after epilogue + stats"]
 
+if WGRAD:
+    PHASES = ["prologue", "DMA issue (waves 0-3)", "MFMA half 0", "DMA issue (waves 4-7)", "MFMA half 1",
+              "wait for the DMAs", "barrier", "(unused)"]
 lib = _lib.lib()
-fn = lib.unetpp_debug_wino_stamps
+fn = lib.unetpp_debug_wwino_stamps if WGRAD else lib.unetpp_debug_wino_stamps
 fn.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
 fn.restype = ctypes.c_int
-x, y = torch.randn(B, hw, hw, ci, device="cuda"), torch.empty(B, hw, hw, co, device="cuda")
+x, y = torch.randn(B, hw, hw, ci, device="cuda"), torch.randn(B, hw, hw, co, device="cuda")
 w, bias = torch.randn(co, ci, 3, 3, device="cuda") * 0.05, torch.randn(co, device="cuda")
 wp = engine.pack_conv_fwd(w)
 
 
+dw, db = torch.empty(co, ci, 3, 3, device="cuda"), torch.empty(co, device="cuda")
+
+
 def run():
-    ops.gemm_fwd(B, hw, hw, 9, [V(x)], [V(y)], wp, bias, None)
+    if WGRAD:
+        ops.wgrad(B, hw, hw, 9, [V(x)], [V(y)], dw, (1, 9, ci * 9, 0), db)
+    else:
+        ops.gemm_fwd(B, hw, hw, 9, [V(x)], [V(y)], wp, bias, None)
 
 
 run()

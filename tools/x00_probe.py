@@ -62,6 +62,14 @@ def conv2_plain():
     ops.gemm_fwd(B, HW, HW, 9, [V(y1)], [V(y2)], wp2, b2, None)
 
 
+def conv2_fold_only():
+    ops.gemm_fwd(B, HW, HW, 9, [V(y1, scale=st1[2], shift=st1[3], relu=True)], [V(y2)], wp2, b2, None)
+
+
+def conv2_stats_only():
+    ops.gemm_fwd(B, HW, HW, 9, [V(y1)], [V(y2)], wp2, b2, part2)
+
+
 conv2()
 st2 = fin(part2)
 
@@ -87,8 +95,10 @@ def pool_bwd():
 
 rows = [("conv1 (1->32) + stats", conv1), ("bn_finalize", lambda: fin(part1)),
         ("conv2 (32->32) BN-fold + stats", conv2), ("conv2 plain, no stats", conv2_plain),
+        ("conv2 BN-fold, no stats", conv2_fold_only), ("conv2 plain + stats", conv2_stats_only),
         ("BN-apply + ReLU + pool", apply_pool), ("whole block", block),
         ("max-pool backward (not in block)", pool_bwd)]
-for name, fn in rows:
-    us = timeit(fn)
-    print("%-34s %8.1f us  %6.2f us/img" % (name, us, us / B))
+for rep in range(int(os.environ.get("PASSES", "1"))):  # PASSES=2: a second pass shows warm-up / clock drift
+    for name, fn in rows:
+        us = timeit(fn)
+        print("%-34s %8.1f us  %6.2f us/img" % (name, us, us / B))

@@ -21,9 +21,25 @@
 //   * epilogue: the 4 tile groups are summed in a fixed-order tree through LDS, one slab per workgroup; db comes
 //     from the (1,1) element of A dY A^T, which is the plain sum of the 2x2 tile.
 #include "common.h"
+#include "lds_asm.h"
 
 namespace unetpp {
 namespace {
+
+// In-kernel phase stamps (profiling builds only: -DUNETPP_WWINO_STAMPS, tools/wino_stamps.py --wgrad)
+#ifdef UNETPP_WWINO_STAMPS
+__device__ unsigned long long g_wwino_stamps[16];
+#define WW_STAMP(i)                            \
+  do {                                         \
+    const unsigned long long now_ = clock64(); \
+    st_acc[i] += now_ - st_last;               \
+    st_last = now_;                            \
+  } while (0)
+#else
+#define WW_STAMP(i) \
+  do {              \
+  } while (0)
+#endif
 
 constexpr int kWThreads = 512;
 constexpr int kTW = 32, kTH = 8, kHWp = kTW + 2, kHHp = kTH + 2;
@@ -124,12 +140,12 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
   }
   // Edge patches take two passes: zero fills of out-of-image pixels first (plain ds_writes), then the DMAs -- a
   // ds_write into an array with a DMA in flight makes hipcc drain vmcnt first (see wgrad_dma.hip).
-  auto issue_tile = [&](long tile, float* buf) {
-    long b = tile;
-    const int txi = static_cast<int>(b % a.tiles_x);
-    b /= a.tiles_x;
-    const int tyi = static_cast<int>(b % a.tiles_y);
-    const int n = static_cast<int>(b / a.tiles_y);
+  auto issue_tile = [&](unsigned tile, float* buf) {  // tile < 2^31 (launcher); uniform: the decode runs on the SALU
+    unsigned b = __builtin_amdgcn_readfirstlane(tile);
+    const int txi = static_cast<int>(b % static_cast<unsigned>(a.tiles_x));
+    b /= static_cast<unsigned>(a.tiles_x);
+    const int tyi = static_cast<int>(b % static_cast<unsigned>(a.tiles_y));
+    const int n = static_cast<int>(b / static_cast<unsigned>(a.tiles_y));
     const int ty0 = tyi * kTH, tx0 = txi * kTW;
     const char* xb = reinterpret_cast<const char*>(X.ptr + view_pixel_offset(X, n, ty0 - 1, tx0 - 1) + c0);
     const char* yb = reinterpret_cast<const char*>(DY.ptr + view_pixel_offset(DY, n, ty0, tx0) + nc0);
@@ -201,15 +217,33 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
     for (int rr = 0; rr < 2; ++rr) {
       const int r = 2 * half + rr;
       float t[4][4], V[16];
+      // all LDS operands of the k-step (x window, 2x2 dy values of both column halves) by hand-placed reads with ONE
+      // wait (lds_asm.h): left to hipcc, each of the three groups is read directly in front of its first use
+      float dyv[2][4];
       {
         float xa[4][4];
+        const unsigned xb = lds_offset(buf) + lane_x * 4, yb = lds_offset(buf) + lane_y * 4;
+        float xl[16];
+        if (r == 0) {
+          static_for<16>([&](auto ic) { constexpr int e = decltype(ic)::v, U = kXRow * (e / 4) + (e % 4) + 0; lds_read_b32<((U >> 3) * GX + (U & 7) * 32) * 4>(xl[e], xb); });
+          static_for<8>([&](auto ic) { constexpr int e = decltype(ic)::v, P = kTW * ((e & 3) / 2) + (e & 1) + 0; lds_read_b32<(16 * (e >> 2) + (P >> 3) * GY + (P & 7) * 32) * 4>(dyv[e >> 2][e & 3], yb); });
+        } else if (r == 1) {
+          static_for<16>([&](auto ic) { constexpr int e = decltype(ic)::v, U = kXRow * (e / 4) + (e % 4) + 2; lds_read_b32<((U >> 3) * GX + (U & 7) * 32) * 4>(xl[e], xb); });
+          static_for<8>([&](auto ic) { constexpr int e = decltype(ic)::v, P = kTW * ((e & 3) / 2) + (e & 1) + 2; lds_read_b32<(16 * (e >> 2) + (P >> 3) * GY + (P & 7) * 32) * 4>(dyv[e >> 2][e & 3], yb); });
+        } else if (r == 2) {
+          static_for<16>([&](auto ic) { constexpr int e = decltype(ic)::v, U = kXRow * (e / 4) + (e % 4) + 4; lds_read_b32<((U >> 3) * GX + (U & 7) * 32) * 4>(xl[e], xb); });
+          static_for<8>([&](auto ic) { constexpr int e = decltype(ic)::v, P = kTW * ((e & 3) / 2) + (e & 1) + 4; lds_read_b32<(16 * (e >> 2) + (P >> 3) * GY + (P & 7) * 32) * 4>(dyv[e >> 2][e & 3], yb); });
+        } else {
+          static_for<16>([&](auto ic) { constexpr int e = decltype(ic)::v, U = kXRow * (e / 4) + (e % 4) + 6; lds_read_b32<((U >> 3) * GX + (U & 7) * 32) * 4>(xl[e], xb); });
+          static_for<8>([&](auto ic) { constexpr int e = decltype(ic)::v, P = kTW * ((e & 3) / 2) + (e & 1) + 6; lds_read_b32<(16 * (e >> 2) + (P >> 3) * GY + (P & 7) * 32) * 4>(dyv[e >> 2][e & 3], yb); });
+        }
+        lds_wait16(xl);
+        lds_wait4(dyv[0]);
+        lds_wait4(dyv[1]);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int U = kXRow * i + j + 2 * r;
-            xa[i][j] = buf[lane_x + (U >> 3) * GX + (U & 7) * 32];
-          }
+          for (int j = 0; j < 4; ++j) xa[i][j] = xl[4 * i + j];
         if (XFORM) {  // BatchNorm apply + ReLU of the producer, folded into the operand read; max(NaN, 0) = 0 (padding)
 #pragma unroll
           for (int i = 0; i < 4; ++i)
@@ -237,10 +271,7 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
 #pragma unroll
         for (int ap = 0; ap < 2; ++ap)
 #pragma unroll
-          for (int bp = 0; bp < 2; ++bp) {
-            const int P = kTW * ap + bp + 2 * r;
-            dy[ap][bp] = buf[lane_y + 16 * nh + (P >> 3) * GY + (P & 7) * 32];
-          }
+          for (int bp = 0; bp < 2; ++bp) dy[ap][bp] = dyv[nh][2 * ap + bp];
         // A dY A^T with A's last row taken as (0, +1): rows (d0, d0 + d1, d0 - d1, d1); the finish kernel applies the
         // sign (-1)^[a == 3] (-1)^[b == 3]
         float rw[4][2];
@@ -269,31 +300,55 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
   };
 
   // tiles of this workgroup: blockIdx.x, +gridDim.x, ...   (buffer A holds even, buffer B odd local tiles)
-  const long stride = gridDim.x;
-  const long t0 = blockIdx.x;
-  const long n_my = (t0 < a.n_pix_tiles) ? (a.n_pix_tiles - t0 + stride - 1) / stride : 0;
+  const unsigned stride = gridDim.x;
+  const unsigned t0 = blockIdx.x;
+  const unsigned n_tiles_all = static_cast<unsigned>(a.n_pix_tiles);
+  const int n_my = (t0 < n_tiles_all) ? static_cast<int>((n_tiles_all - t0 + stride - 1) / stride) : 0;
+#ifdef UNETPP_WWINO_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = clock64();
+#endif
   if (n_my > 0) issue_tile(t0, buf_a);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  WW_STAMP(0);  // 0: prologue
   // Waves w and w+4 share a SIMD: waves 0-3 issue the next patch's DMAs before their MFMAs, waves 4-7 half way through.
   const bool late = wave >= 4;
-  for (long i = 0; i < n_my; i += 2) {
+  for (int i = 0; i < n_my; i += 2) {
     if (!late && i + 1 < n_my) issue_tile(t0 + (i + 1) * stride, buf_b);
+    WW_STAMP(1);  // 1: DMA issue (early waves)
     compute(buf_a, 0);
+    WW_STAMP(2);  // 2: MFMA half 0
     if (late && i + 1 < n_my) issue_tile(t0 + (i + 1) * stride, buf_b);
+    WW_STAMP(3);  // 3: DMA issue (late waves)
     compute(buf_a, 1);
+    WW_STAMP(4);  // 4: MFMA half 1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WW_STAMP(5);  // 5: wait for the DMAs
     __syncthreads();
+    WW_STAMP(6);  // 6: barrier
     if (i + 1 < n_my) {
       if (!late && i + 2 < n_my) issue_tile(t0 + (i + 2) * stride, buf_a);
+      WW_STAMP(1);
       compute(buf_b, 0);
+      WW_STAMP(2);
       if (late && i + 2 < n_my) issue_tile(t0 + (i + 2) * stride, buf_a);
+      WW_STAMP(3);
       compute(buf_b, 1);
+      WW_STAMP(4);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      WW_STAMP(5);
       __syncthreads();
+      WW_STAMP(6);
     }
   }
 
+#ifdef UNETPP_WWINO_STAMPS
+  if (lane == 0) {
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_wwino_stamps[i], st_acc[i]);
+    atomicAdd(&g_wwino_stamps[8], 1ull);
+  }
+#endif
   // ---- fixed-order tree over the 4 tile groups of each channel half: (tg0 + tg2) + (tg1 + tg3).  A region holds
   // the 32 float4 accumulators of a wave lane-linearly (32 KB); two regions per buffer. ----
   constexpr int R = 32 * 64 * 4;  // floats per region
@@ -447,6 +502,18 @@ bool x_view_ok(const unetpp_view& v) {
 
 }  // namespace
 
+#ifdef UNETPP_WWINO_STAMPS
+extern "C" int unetpp_debug_wwino_stamps(unsigned long long* out16, int reset) {  // profiling builds only
+  if (out16 != nullptr && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wwino_stamps), sizeof(g_wwino_stamps)) != hipSuccess)
+    return UNETPP_ELAUNCH;
+  if (reset) {
+    const unsigned long long zero[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wwino_stamps), zero, sizeof(zero)) != hipSuccess) return UNETPP_ELAUNCH;
+  }
+  return UNETPP_OK;
+}
+#endif
+
 // 3x3, Winograd not forbidden, 32-wide patches, every view plain and 16-byte aligned, 32-bit byte offsets inside a patch
 bool wgrad_wino_applies(const unetpp_wgrad_desc* d) {
   if (d == nullptr || d->taps != 9 || (d->flags & UNETPP_GEMM_DIRECT) != 0) return false;
@@ -478,6 +545,7 @@ int launch_wgrad_wino(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_til
   a.tiles_x = g.tiles_x;
   a.tiles_y = g.tiles_y;
   a.n_pix_tiles = static_cast<long>(d->N) * g.tiles_y * g.tiles_x;
+  if (a.n_pix_tiles >= 0x7fffffffL) return 1;  // 32-bit tile indices in the kernel
   const dim3 grid(static_cast<unsigned>(d->n_split), static_cast<unsigned>(static_cast<long>(k_tiles) * n_tiles_cols));
   if (d->x[0].scale != nullptr)
     hipLaunchKernelGGL(wgrad_wino_kernel<true>, grid, dim3(kWThreads), 0, st, a);
