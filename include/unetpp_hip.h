@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNETPP_ABI_VERSION 3
+#define UNETPP_ABI_VERSION 4
 #define UNETPP_MAX_VIEWS 8
 
 #define UNETPP_OK 0
@@ -190,6 +190,21 @@ int unetpp_bn_bwd_apply(const float* d_act, const float* y, const float* scale, 
                         const float* mean, const float* invstd, const float* gamma,
                         const float* dgamma, const float* dbeta, int64_t pixels, int32_t C,
                         float* dy, void* stream);
+
+/* BatchNorm backward of an encoder node whose output was also 2x2 max-pooled (models/unet.py:257-263): the pooled
+ * consumer's gradient d_pooled [N, H/2, W/2, C] is routed to the argmax recorded by unetpp_affine_relu_pool WHILE
+ * d_act is read, in both passes, instead of a separate unetpp_maxpool_bwd pass over d_act.  Needs
+ * unetpp_bn_bwd_pool_ok(N, H, W, C) (4-aligned C with a power-of-two C/4 <= 256, even H and W, < 2^31 elements);
+ * otherwise call unetpp_maxpool_bwd and the plain functions.  partial: unetpp_bn_bwd_blocks(N*H*W, C) rows, finished
+ * by unetpp_bn_bwd_finalize as usual. */
+int unetpp_bn_bwd_pool_ok(int32_t N, int32_t H, int32_t W, int32_t C);
+int unetpp_bn_bwd_reduce_pool(const float* d_act, const float* y, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, const float* d_pooled, const uint8_t* pool_idx,
+                              int32_t N, int32_t H, int32_t W, int32_t C, float* partial, void* stream);
+int unetpp_bn_bwd_apply_pool(const float* d_act, const float* y, const float* scale, const float* shift,
+                             const float* mean, const float* invstd, const float* gamma, const float* dgamma,
+                             const float* dbeta, const float* d_pooled, const uint8_t* pool_idx, int32_t N, int32_t H,
+                             int32_t W, int32_t C, float* dy, void* stream);
 
 /* ---- deep-supervision head: sigmoid(Conv1x1(Dropout(x))) (models/unet.py:242-244,254,283-286) ---- */
 /* x NHWC [P, C]; weight [n_cls, C]; out NCHW [N, n_cls, H, W].  Dropout: keep mask regenerated from

@@ -379,6 +379,36 @@ def test_pool_argmax_and_routing_exact(dev, b, h, w, c, affine, relu):
     assert torch.equal(acc.permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize("b,h,w,c", [(2, 8, 16, 32), (1, 4, 64, 128), (3, 6, 10, 8), (2, 4, 8, 20)])
+def test_batchnorm_backward_with_pool_routing(dev, b, h, w, c):
+    """bn_backward(pool=...) == maxpool_bwd into d_act followed by the plain bn_backward: the fused kernels where the
+    shape allows (power-of-two channel quads), the two-pass fallback otherwise (c = 20)."""
+    from unet_nested4tiny_objects_keypoints_amd import ops
+    g = torch.Generator().manual_seed(23)
+    y = (torch.randn(b, h, w, c, generator=g) * 1.5 + 0.2).to(dev)
+    gamma = (1 + 0.1 * torch.randn(c, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(c, generator=g)).to(dev)
+    part = torch.stack([y.view(-1, c).sum(0), (y.view(-1, c) ** 2).sum(0)], 1).reshape(1, c, 2).contiguous()
+    rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    mean, invstd, scale, shift = ops.bn_finalize(part.view(-1), 1, c, b * h * w, gamma, beta, 1e-5, 0.1, rm, rv)
+    act = torch.empty_like(y)
+    pooled = torch.empty(b, h // 2, w // 2, c, device=dev)
+    idx = torch.empty(b, h // 2, w // 2, c, dtype=torch.uint8, device=dev)
+    ops.affine_relu_pool(y, scale, shift, True, act, pooled, idx)
+    d_act = torch.randn(y.shape, generator=g).to(dev)
+    d_pool = torch.randn(pooled.shape, generator=g).to(dev)
+    # reference: two passes
+    ref_in = d_act.clone()
+    ops.maxpool_bwd(d_pool, idx, ref_in)
+    ref_dy = torch.empty_like(y)
+    ref_dg, ref_db = ops.bn_backward(ref_in, y, scale, shift, mean, invstd, gamma, ref_dy)
+    # fused (in place, as the engine calls it)
+    got = d_act.clone()
+    dg, db = ops.bn_backward(got, y, scale, shift, mean, invstd, gamma, got, pool=(d_pool, idx))
+    assert rel_err(got.cpu(), ref_dy.cpu()) < 1e-5
+    assert rel_err(dg.cpu(), ref_dg.cpu()) < 1e-5 and rel_err(db.cpu(), ref_db.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("c,ncls", [(32, 4), (8, 5), (6, 3)])
 def test_head_fwd_bwd_with_mask(dev, c, ncls):
     from unet_nested4tiny_objects_keypoints_amd import ops

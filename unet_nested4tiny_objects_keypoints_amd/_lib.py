@@ -18,7 +18,7 @@ INCLUDE = os.path.join(_REPO, "include")
 SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_wino.hip", "weight_image.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "wgrad_wino.hip", "first_layer.hip", "pointwise.hip", "caller.hip")
 HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h", "lds_asm.h")
 MAX_VIEWS = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 # packed-f32 VALU (SLP-vectorised add pairs) costs issue slots beside MFMAs: keep the Winograd transforms scalar
 EXTRA_FLAGS = {"gemm_wino.hip": ("-fno-slp-vectorize",), "wgrad_wino.hip": ("-fno-slp-vectorize",)}
 GEMM_DIRECT = 1  # unetpp_gemm_desc.flags: direct summation only (no Winograd)
@@ -104,6 +104,9 @@ SIGNATURES = {
     "unetpp_bn_bwd_reduce": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P]),
     "unetpp_bn_bwd_finalize": (C.c_int, [_P, _I64, _I32, _P, _P, _P]),
     "unetpp_bn_bwd_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P]),
+    "unetpp_bn_bwd_pool_ok": (C.c_int, [_I32, _I32, _I32, _I32]),
+    "unetpp_bn_bwd_reduce_pool": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
+    "unetpp_bn_bwd_apply_pool": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "unetpp_head_fwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _P]),
     "unetpp_head_bwd_blocks": (_I64, [_I64]),
     "unetpp_head_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _I32, _I32, _P, _P]),

@@ -384,6 +384,89 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(const float* __r
   }
 }
 
+// ---- BatchNorm backward of an encoder node whose output was also max-pooled: the pooled consumer's gradient is routed
+// to its argmax WHILE d_act is read (in both passes), which saves maxpool_bwd's read-modify-write pass over d_act.
+// Row structured like the pool kernels: a workgroup walks image rows, a thread the (pixel, channel quad) items of a row;
+// needs 4-aligned channels with a power-of-two quad count <= 256 (a thread keeps its quad), even H and W, tensors
+// below 2^31 elements.  The global row index r = n * H + y has y's parity, and r >> 1 is the pooled row.
+__device__ __forceinline__ f32x4 routed_grad(const f32x4* __restrict__ d_act, const f32x4* __restrict__ d_pooled,
+                                             const uint32_t* __restrict__ pool_idx, unsigned row, unsigned x,
+                                             unsigned cg, unsigned log2CG, unsigned row_items) {
+  f32x4 g = d_act[row * row_items + (x << log2CG) + cg];
+  const unsigned pitem = (row >> 1) * (row_items >> 1) + ((x >> 1) << log2CG) + cg;
+  const uint32_t bi = pool_idx[pitem];
+  const f32x4 dp = d_pooled[pitem];
+  const uint32_t q = ((row & 1u) << 1) | (x & 1u);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) g[k] += (((bi >> (8 * k)) & 0xffu) == q) ? dp[k] : 0.f;
+  return g;
+}
+
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_pool_kernel(
+    const f32x4* __restrict__ d_act, const f32x4* __restrict__ y, const f32x4* __restrict__ scale,
+    const f32x4* __restrict__ shift, const f32x4* __restrict__ mean, const f32x4* __restrict__ invstd,
+    const f32x4* __restrict__ d_pooled, const uint32_t* __restrict__ pool_idx, unsigned rows, unsigned W,
+    unsigned log2CG, float* __restrict__ partial) {
+  __shared__ float sm[kThreads][8];
+  const unsigned CG = 1u << log2CG, cg = threadIdx.x & (CG - 1), row_items = W << log2CG;
+  const f32x4 sc = scale[cg], sh = shift[cg], mu = mean[cg], is = invstd[cg];
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  for (unsigned row = blockIdx.x; row < rows; row += gridDim.x) {
+    for (unsigned j = threadIdx.x; j < row_items; j += kThreads) {
+      const f32x4 g = routed_grad(d_act, d_pooled, pool_idx, row, j >> log2CG, cg, log2CG, row_items);
+      const f32x4 v = y[row * row_items + j];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gg = (fmaf(v[k], sc[k], sh[k]) > 0.f) ? g[k] : 0.f;
+        s1[k] += gg;
+        s2[k] += gg * (v[k] - mu[k]) * is[k];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    sm[threadIdx.x][2 * k] = s1[k];
+    sm[threadIdx.x][2 * k + 1] = s2[k];
+  }
+  __syncthreads();
+  const unsigned C = CG * 4;
+  for (unsigned cc = threadIdx.x; cc < C; cc += kThreads) {
+    const unsigned g4 = cc >> 2, k = cc & 3;
+    float a = 0.f, b = 0.f;
+    for (unsigned t = g4; t < kThreads; t += CG) {
+      a += sm[t][2 * k];
+      b += sm[t][2 * k + 1];
+    }
+    partial[(static_cast<long>(blockIdx.x) * C + cc) * 2 + 0] = a;
+    partial[(static_cast<long>(blockIdx.x) * C + cc) * 2 + 1] = b;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_pool_kernel(
+    const f32x4* __restrict__ d_act, const f32x4* __restrict__ y, const f32x4* __restrict__ scale,
+    const f32x4* __restrict__ shift, const f32x4* __restrict__ mean, const f32x4* __restrict__ invstd,
+    const f32x4* __restrict__ gamma, const f32x4* __restrict__ dgamma, const f32x4* __restrict__ dbeta,
+    const f32x4* __restrict__ d_pooled, const uint32_t* __restrict__ pool_idx, float inv_count, unsigned rows, unsigned W,
+    unsigned log2CG, f32x4* __restrict__ dy) {
+  const unsigned CG = 1u << log2CG, cg = threadIdx.x & (CG - 1), row_items = W << log2CG;
+  const f32x4 sc = scale[cg], sh = shift[cg], mu = mean[cg], is = invstd[cg], ga = gamma[cg], dg = dgamma[cg],
+              db = dbeta[cg];
+  for (unsigned row = blockIdx.x; row < rows; row += gridDim.x) {
+    for (unsigned j = threadIdx.x; j < row_items; j += kThreads) {
+      const f32x4 g = routed_grad(d_act, d_pooled, pool_idx, row, j >> log2CG, cg, log2CG, row_items);
+      const f32x4 v = y[row * row_items + j];
+      f32x4 out;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gg = (fmaf(v[k], sc[k], sh[k]) > 0.f) ? g[k] : 0.f;
+        const float xhat = (v[k] - mu[k]) * is[k];
+        out[k] = ga[k] * is[k] * (gg - db[k] * inv_count - xhat * dg[k] * inv_count);
+      }
+      dy[row * row_items + j] = out;  // may alias d_act: the item was read by this thread above
+    }
+  }
+}
+
 // ------------------------------------------------------------------ dropout keep mask
 // Counter-based: one splitmix64 hash per group of 4 channels of one pixel gives four 16-bit
 // uniforms; forward and backward regenerate the same mask from (seed, pixel, group).
@@ -1076,6 +1159,74 @@ extern "C" int unetpp_bn_bwd_apply(const float* d_act, const float* y, const flo
     hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(grid_for(items)), dim3(kThreads), 0, ST(stream), d_act, y, scale,
                        shift, mean, invstd, gamma, dgamma, dbeta, inv_count, items, C, dy);
   }
+  return launch_status();
+}
+
+namespace {
+// eligibility of the pool-routing BatchNorm backward (see bn_bwd_reduce_pool_kernel)
+inline bool bn_bwd_pool_ok(int N, int H, int W, int C) {
+  if (N < 1 || H < 2 || W < 2 || C < 4 || (H & 1) || (W & 1) || (C & 3)) return false;
+  const int CG = C >> 2;
+  if ((CG & (CG - 1)) != 0 || CG > kThreads) return false;
+  return static_cast<long>(N) * H * W * C < 0x7fffffffL;
+}
+inline unsigned ilog2(unsigned v) {
+  unsigned l = 0;
+  while ((1u << l) < v) ++l;
+  return l;
+}
+}  // namespace
+
+extern "C" int unetpp_bn_bwd_pool_ok(int32_t N, int32_t H, int32_t W, int32_t C) { return bn_bwd_pool_ok(N, H, W, C) ? 1 : 0; }
+
+extern "C" int unetpp_bn_bwd_reduce_pool(const float* d_act, const float* y, const float* scale, const float* shift,
+                                         const float* mean, const float* invstd, const float* d_pooled,
+                                         const uint8_t* pool_idx, int32_t N, int32_t H, int32_t W, int32_t C,
+                                         float* partial, void* stream) {
+  if (!d_act || !y || !scale || !shift || !mean || !invstd || !d_pooled || !pool_idx || !partial) return UNETPP_EINVAL;
+  if (!bn_bwd_pool_ok(N, H, W, C)) return UNETPP_EINVAL;
+  if (!aligned16(d_act) || !aligned16(y) || !aligned16(scale) || !aligned16(shift) || !aligned16(mean) ||
+      !aligned16(invstd) || !aligned16(d_pooled) || (reinterpret_cast<uintptr_t>(pool_idx) & 3) != 0)
+    return UNETPP_EINVAL;
+  const long pixels = static_cast<long>(N) * H * W;
+  const long rows_buf = unetpp_bn_bwd_blocks(pixels, C);  // rows of the partial buffer; unused ones are zeroed
+  const long img_rows = static_cast<long>(N) * H;
+  const long grid = img_rows < rows_buf ? img_rows : rows_buf;
+  if (grid < rows_buf &&
+      hipMemsetAsync(partial + grid * C * 2, 0, sizeof(float) * (rows_buf - grid) * C * 2, ST(stream)) != hipSuccess)
+    return UNETPP_ELAUNCH;
+  hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, ST(stream),
+                     reinterpret_cast<const f32x4*>(d_act), reinterpret_cast<const f32x4*>(y),
+                     reinterpret_cast<const f32x4*>(scale), reinterpret_cast<const f32x4*>(shift),
+                     reinterpret_cast<const f32x4*>(mean), reinterpret_cast<const f32x4*>(invstd),
+                     reinterpret_cast<const f32x4*>(d_pooled), reinterpret_cast<const uint32_t*>(pool_idx),
+                     static_cast<unsigned>(img_rows), static_cast<unsigned>(W), ilog2(static_cast<unsigned>(C >> 2)),
+                     partial);
+  return launch_status();
+}
+
+extern "C" int unetpp_bn_bwd_apply_pool(const float* d_act, const float* y, const float* scale, const float* shift,
+                                        const float* mean, const float* invstd, const float* gamma, const float* dgamma,
+                                        const float* dbeta, const float* d_pooled, const uint8_t* pool_idx, int32_t N,
+                                        int32_t H, int32_t W, int32_t C, float* dy, void* stream) {
+  if (!d_act || !y || !scale || !shift || !mean || !invstd || !gamma || !dgamma || !dbeta || !d_pooled || !pool_idx || !dy)
+    return UNETPP_EINVAL;
+  if (!bn_bwd_pool_ok(N, H, W, C)) return UNETPP_EINVAL;
+  if (!aligned16(d_act) || !aligned16(y) || !aligned16(dy) || !aligned16(scale) || !aligned16(shift) ||
+      !aligned16(mean) || !aligned16(invstd) || !aligned16(gamma) || !aligned16(dgamma) || !aligned16(dbeta) ||
+      !aligned16(d_pooled) || (reinterpret_cast<uintptr_t>(pool_idx) & 3) != 0)
+    return UNETPP_EINVAL;
+  const long img_rows = static_cast<long>(N) * H;
+  const float inv_count = 1.0f / static_cast<float>(img_rows * W);
+  hipLaunchKernelGGL(bn_bwd_apply_pool_kernel, dim3(static_cast<unsigned>(img_rows < 16384 ? img_rows : 16384)),
+                     dim3(kThreads), 0, ST(stream), reinterpret_cast<const f32x4*>(d_act),
+                     reinterpret_cast<const f32x4*>(y), reinterpret_cast<const f32x4*>(scale),
+                     reinterpret_cast<const f32x4*>(shift), reinterpret_cast<const f32x4*>(mean),
+                     reinterpret_cast<const f32x4*>(invstd), reinterpret_cast<const f32x4*>(gamma),
+                     reinterpret_cast<const f32x4*>(dgamma), reinterpret_cast<const f32x4*>(dbeta),
+                     reinterpret_cast<const f32x4*>(d_pooled), reinterpret_cast<const uint32_t*>(pool_idx), inv_count,
+                     static_cast<unsigned>(img_rows), static_cast<unsigned>(W), ilog2(static_cast<unsigned>(C >> 2)),
+                     reinterpret_cast<f32x4*>(dy));
   return launch_status();
 }
 

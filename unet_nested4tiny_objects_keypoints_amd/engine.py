@@ -313,17 +313,18 @@ def _conv_wgrad(conv, xs, dys, b, h, w, grads):
     grads[conv.bias] = db
 
 
-def _pair_bwd(blk, r: _PairRec, d_out, in_targets: Optional[List[V]], b, grads, pre_gated=False):
+def _pair_bwd(blk, r: _PairRec, d_out, in_targets: Optional[List[V]], b, grads, pre_gated=False, pool_grad=None):
     """Backward of models/unet.py:150-156.  d_out (gradient of r.out) is consumed.  in_targets: output views
     for the gradient of every entry of r.ins (None = the inputs need no gradient).  pre_gated: the last
-    contributor already multiplied d_out by (r.out > 0)."""
+    contributor already multiplied d_out by (r.out > 0).  pool_grad = (d_pooled, pool_idx): gradient of the max-pooled
+    copy of r.out that has NOT been added to d_out yet (BatchNorm nodes only: routed inside BatchNorm backward)."""
     conv1, conv2 = getattr(blk.conv1, "0"), getattr(blk.conv2, "0")
     h, w = r.h, r.w
     if blk.is_batchnorm:
         bn1, bn2 = getattr(blk.conv1, "1"), getattr(blk.conv2, "1")
         mean, invstd, scale, shift = r.bn2
         dg, dbt = ops.bn_backward(d_out, r.y2, scale, shift, mean, invstd, bn2.weight.detach(), d_out,
-                                  _new_grad(bn2.weight), _new_grad(bn2.bias))
+                                  _new_grad(bn2.weight), _new_grad(bn2.bias), pool=pool_grad)
         grads[bn2.weight], grads[bn2.bias] = dg, dbt
         dy2 = V(d_out)
         mean, invstd, scale, shift = r.bn1
@@ -427,21 +428,29 @@ def _backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=No
             _up_bwd(mod.up, model.is_deconv, u, d_up, t, acc, gate, b, grads)
             flush()
     dx_in = None
+    pool_grad = None  # (d_pooled, pool_idx) of the node below, still to be added to this node's gradient
     for i in range(d - 1, -1, -1):  # encoder column, deepest first
         blk = getattr(model, "conv%d0" % i)
         r = s.pairs[(i, 0)]
         d_out, pre_gated = book.take((i, 0))
+        if pool_grad is not None and not model.is_batchnorm:
+            ops.maxpool_bwd(pool_grad[0], pool_grad[1], d_out)  # (is_batchnorm=False never gates encoder nodes early)
+            pool_grad = None
+        mine, pool_grad = pool_grad, None
         if i > 0:
             d_pooled = torch.empty_like(s.pairs[(i - 1, 0)].pooled)
-            _pair_bwd(blk, r, d_out, [V(d_pooled)], b, grads, pre_gated)
-            prev = s.pairs[(i - 1, 0)]
-            t, _, _ = book.target((i - 1, 0))  # the pool gradient is the node's last contribution (no gate here)
-            ops.maxpool_bwd(d_pooled, prev.pool_idx, t)
+            _pair_bwd(blk, r, d_out, [V(d_pooled)], b, grads, pre_gated, pool_grad=mine)
+            # the pool gradient is the last contribution to the node above: with BatchNorm it is routed to the argmax
+            # inside that node's BatchNorm backward, which reads the gradient anyway
+            t, acc, _ = book.target((i - 1, 0))  # counts as the node's last contribution (no gate here)
+            if not acc:
+                t.zero_()
+            pool_grad = (d_pooled, s.pairs[(i - 1, 0)].pool_idx)
         elif want_input_grad:
             dx_in = torch.empty_like(s.x_nhwc)
-            _pair_bwd(blk, r, d_out, [V(dx_in)], b, grads, pre_gated)
+            _pair_bwd(blk, r, d_out, [V(dx_in)], b, grads, pre_gated, pool_grad=mine)
         else:
-            _pair_bwd(blk, r, d_out, None, b, grads, pre_gated)
+            _pair_bwd(blk, r, d_out, None, b, grads, pre_gated, pool_grad=mine)
         flush()
     return grads, dx_in
 

@@ -389,11 +389,16 @@ def maxpool_bwd(d_pooled, pool_idx, d_act):
           "unetpp_maxpool_bwd")
 
 
-def bn_backward(d_act, y, scale, shift, mean, invstd, gamma, dy_out, dgamma=None, dbeta=None):
-    """Training-mode BatchNorm+ReLU backward.  Returns (dgamma, dbeta); dy_out may alias d_act."""
+def bn_backward(d_act, y, scale, shift, mean, invstd, gamma, dy_out, dgamma=None, dbeta=None, pool=None):
+    """Training-mode BatchNorm+ReLU backward.  Returns (dgamma, dbeta); dy_out may alias d_act.
+    pool = (d_pooled, pool_idx): the gradient of the 2x2 max-pool of this activation, routed to the argmax while
+    d_act is read (both passes) when the shape allows, else by a maxpool_bwd pass into d_act first."""
     lib = _lib.lib()
     n, h, w, c = y.shape
     pixels = n * h * w
+    if pool is not None and not lib.unetpp_bn_bwd_pool_ok(n, h, w, c):
+        maxpool_bwd(pool[0], pool[1], d_act)
+        pool = None
     blocks = int(lib.unetpp_bn_bwd_blocks(pixels, c))
     partial = torch.empty(blocks * c * 2, dtype=torch.float32, device=y.device)
     if dgamma is None:
@@ -401,11 +406,23 @@ def bn_backward(d_act, y, scale, shift, mean, invstd, gamma, dy_out, dgamma=None
     if dbeta is None:
         dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
     st = _stream()
-    check(lib.unetpp_bn_bwd_reduce(_ptr(d_act), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), pixels, c,
-                                   _ptr(partial), st), "unetpp_bn_bwd_reduce")
+    if pool is None:
+        check(lib.unetpp_bn_bwd_reduce(_ptr(d_act), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), pixels,
+                                       c, _ptr(partial), st), "unetpp_bn_bwd_reduce")
+    else:
+        d_pooled, pool_idx = _need(pool[0], "d_pooled"), _need(pool[1], "pool_idx", torch.uint8)
+        check(lib.unetpp_bn_bwd_reduce_pool(_ptr(d_act), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd),
+                                            _ptr(d_pooled), _ptr(pool_idx), n, h, w, c, _ptr(partial), st),
+              "unetpp_bn_bwd_reduce_pool")
     check(lib.unetpp_bn_bwd_finalize(_ptr(partial), blocks, c, _ptr(dgamma), _ptr(dbeta), st), "unetpp_bn_bwd_finalize")
-    check(lib.unetpp_bn_bwd_apply(_ptr(d_act), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _ptr(gamma),
-                                  _ptr(dgamma), _ptr(dbeta), pixels, c, _ptr(dy_out), st), "unetpp_bn_bwd_apply")
+    if pool is None:
+        check(lib.unetpp_bn_bwd_apply(_ptr(d_act), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd),
+                                      _ptr(gamma), _ptr(dgamma), _ptr(dbeta), pixels, c, _ptr(dy_out), st),
+              "unetpp_bn_bwd_apply")
+    else:
+        check(lib.unetpp_bn_bwd_apply_pool(_ptr(d_act), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd),
+                                           _ptr(gamma), _ptr(dgamma), _ptr(dbeta), _ptr(pool[0]), _ptr(pool[1]), n, h,
+                                           w, c, _ptr(dy_out), st), "unetpp_bn_bwd_apply_pool")
     return dgamma, dbeta
 
 
