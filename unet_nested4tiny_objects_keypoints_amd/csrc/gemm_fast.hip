@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : 3) : 3)) void
         more = false;
       }
     }
-    if (more) load_chunk();
+    load_chunk();  // unconditional (the cursor stays on the last chunk): a load under a branch drains vmcnt at the join
     // ---- LDS -> MFMA for the current chunk: the fragments of step k+1 are read while the 8 MFMAs of step k
     // issue (both 8-channel groups always run; a short last chunk is zero-padded in LDS) ----
     Frag cur = read_frag(0);
