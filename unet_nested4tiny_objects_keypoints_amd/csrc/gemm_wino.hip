@@ -512,6 +512,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     __syncthreads();  // all waves: done reading the current buffers, next buffers written
     WINO_STAMP(5);  // 5: barrier
     if (c_chunk + 1 == a.n_chunks) {
+      // Collect the prefetched inputs BEFORE the epilogue issues its stores: vmcnt counts in order, so a wait for
+      // these loads placed after the stores (hipcc puts vmcnt(0) in front of the next staging store) would also wait
+      // for the unit's stores to reach memory.  The loads are a whole MFMA phase old here.
+#pragma unroll
+      for (int q = 0; q < IN_ITEMS; ++q) asm volatile("" : "+v"(reg_in[q]));
       epilogue();  // the current buffers are its scratch; stores drain while the next unit computes
       WINO_STAMP(6);  // 6: epilogue
       __syncthreads();   // before the next chunk's staging overwrites that scratch
