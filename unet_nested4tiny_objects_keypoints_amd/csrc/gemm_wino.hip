@@ -462,6 +462,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     lds_read2st64_b64<2, 3>(us[0][1], w_b);
 
     float* other = smem + (cur ^ 1) * BUF;
+    // The staging code is a few hundred sequential instructions; at the highest priority it gets through the issue
+    // slots the co-resident wave's MFMA stream leaves and this wave is back at its own MFMAs sooner (+2 %).
+    __builtin_amdgcn_s_setprio(3);
     store_chunk(other);
     dma_weights(other + IN_FLOATS);
     advance();

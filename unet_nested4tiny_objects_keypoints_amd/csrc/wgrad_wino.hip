@@ -141,6 +141,7 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
   // Edge patches take two passes: zero fills of out-of-image pixels first (plain ds_writes), then the DMAs -- a
   // ds_write into an array with a DMA in flight makes hipcc drain vmcnt first (see wgrad_dma.hip).
   auto issue_tile = [&](unsigned tile, float* buf) {  // tile < 2^31 (launcher); uniform: the decode runs on the SALU
+    __builtin_amdgcn_s_setprio(3);
     unsigned b = __builtin_amdgcn_readfirstlane(tile);
     const int txi = static_cast<int>(b % static_cast<unsigned>(a.tiles_x));
     b /= static_cast<unsigned>(a.tiles_x);
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
         if ((yin >> q) & 1u) __builtin_amdgcn_global_load_lds((gptr_t)(yb + ydelta[q]), (lptr_t)lbase, 16, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
   };
 
   f32x4 acc[16][2];
