@@ -12,11 +12,20 @@ One "step" is the reference's loop body (trainer/trainer.py:114-136): zero_grad 
 + FocalLoss_BCE_2d on the 3 heads + mean + backward + Adam step (+ gradient all-reduce when N > 1).
 Weak scaling: the per-GPU batch is fixed; `value` is global images/sec.
 
+`python bench.py --gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself: the parent never touches the
+GPU, spawns N children of this script with RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, relays rank 0's JSON line and exits
+non-zero if any rank failed (the reference's multi-GPU entry is in-process nn.DataParallel: one command, N GPUs,
+trainer/trainer.py:281-287,336-340).
+
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline      the dominant kernel (most device time) timed live with HIP events on the launch stream over the
-                timed steps: achieved = algorithmic FLOP of its launches / their summed duration, against the
-                dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).  `traffic` (HBM bytes from PMC
-                counters) cannot be collected from inside the process: see profiles/ for the rocprofv3 runs.
+                timed steps.  `achieved` = multiply-adds the matrix pipe EXECUTES (x2) / summed launch duration,
+                `frac` = achieved / dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md) -- a fraction of a
+                hardware limit, <= 1.  For the Winograd kernels the executed work is 16/36 of the algorithmic
+                2*9*Cin*Cout per pixel; the algorithmic rate is reported beside it (`achieved_algorithmic`).
+                `traffic` (HBM bytes per launch from PMC counters) cannot be collected from inside the process: it is
+                read from profiles/pmc_hbm_traffic_latest.json when that file was made from THIS build (build hash),
+                next to `traffic_algorithmic` (every operand read/written once) and their ratio.
   roofline_x00  the X_0,0 conv block forward (1.2457 GFLOP and 42.2 MB algorithmic per image):
                 frac = max(compute floor, HBM floor) / measured block time.
   cpu_baseline  the CPU oracle (oracle/, a PyTorch restatement of the reference proven equal to it on golden
@@ -50,7 +59,8 @@ def parse():
     ap.add_argument("--in-channels", type=int, default=1)
     ap.add_argument("--n-classes", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps (BASELINE.md section 4: >= 3)")
+    ap.add_argument("--prewarm", type=int, default=10, help="untimed steps before the W warm-up steps (see main)")
     ap.add_argument("--no-launch-timing", action="store_true", help="skip per-launch HIP events (roofline = null)")
     return ap.parse_args()
 
@@ -81,14 +91,18 @@ def usable_cores():
     return min(n, int(os.environ.get("UNETPP_CPU_THREADS", "16")))
 
 
-def pmc_traffic(kernel_label):
+def pmc_traffic(kernel_label, build_hash):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (counters cannot be read from
-    inside the process: tools/pmc_traffic.py makes the file from two rocprofv3 --pmc passes of this workload)."""
+    inside the process: tools/pmc_traffic.py makes the file from two rocprofv3 --pmc passes of this workload).
+    A summary stamped with another build's hash is refused (None): it describes other kernels."""
     path = os.path.join(ROOT, "profiles", "pmc_hbm_traffic_latest.json")
     try:
         with open(path) as f:
-            rows = json.load(f)["kernels"]
+            doc = json.load(f)
+        rows = doc["kernels"]
     except (OSError, ValueError, KeyError):
+        return None
+    if doc.get("build_hash") != build_hash:
         return None
     stem = kernel_label.rstrip(">")  # "gemm_fast_kernel<9" matches "gemm_fast_kernel<9, 5, 1>"
     hits = [r for r in rows if r["kernel"].startswith(stem)]
@@ -123,7 +137,7 @@ def cpu_baseline(args, n_cls):
 
     step()  # warm-up
     t0 = time.perf_counter()
-    for _ in range(args.cpu_steps):
+    for _ in range(max(3, args.cpu_steps)):
         step()
     dt = time.perf_counter() - t0
     model.eval()
@@ -133,16 +147,42 @@ def cpu_baseline(args, n_cls):
         model(x)
         fwd = time.perf_counter() - t1
     return {
-        "value": round(b * args.cpu_steps / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+        "value": round(b * max(3, args.cpu_steps) / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
         "torch_threads": torch.get_num_threads(),
         "fwd_ms_per_img": round(1e3 * fwd / b, 3),
         "sample": "%d timed train steps (+1 warm-up) of the CPU oracle at batch %d, %dx%d, base width %d, fp32, Adam"
-                  % (args.cpu_steps, b, args.size, args.size, int(32 / args.feature_scale)),
+                  % (max(3, args.cpu_steps), b, args.size, args.size, int(32 / args.feature_scale)),
     }
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) and relay rank 0's line.
+    Runs before anything in this process touches the GPU (no torch import at all) and never execs."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(codes):
+        print("bench.py: rank exit codes %s" % codes, file=sys.stderr)
+        raise SystemExit(1)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
     import torch
     import torch.distributed as dist
 
@@ -193,9 +233,10 @@ def main():
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
 
-    # W untimed warm-up steps as the contract says, after a fixed untimed pre-warm: the first ~10 steps of a process
-    # run up to 10 % slower (allocator growth, code-object loading, clock ramp), whatever W the caller picks.
-    for _ in range(10 + args.warmup):
+    # W untimed warm-up steps as the contract says, after `--prewarm` more untimed steps (printed as `prewarm_steps`):
+    # the first ~10 steps of a process run up to 10 % slower (allocator growth, code-object loading, clock ramp),
+    # whatever W the caller picks.
+    for _ in range(args.prewarm + args.warmup):
         train_step(model, opt, crit, x, target)
 
     # Per-launch HIP events (for the roofline object) on every 4th timed step only: an event pair around each of the
@@ -225,6 +266,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    replicas_identical = None
+    if distributed:  # every rank must hold bit-identical parameters after the run (DataParallel keeps ONE copy)
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).view(torch.int32)
+        hi, lo = flat.clone(), flat.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        replicas_identical = bool(torch.equal(hi, lo))
+
     # eval-mode forward latency (the reference's "high-speed inference" claim; BASELINE metric part 2)
     model.eval()
     with torch.no_grad():
@@ -253,22 +302,30 @@ def main():
         kernels = {k: {"launches_per_step": v["launches"] / sampled_steps, "ms_per_step": round(v["ms"] / sampled_steps, 3),
                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in launches.items()}
         dom = max(launches.items(), key=lambda kv: kv[1]["ms"])
-        ach = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
-        roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                    "traffic": pmc_traffic(dom[0]) if (args.size == 256 and fs == 1 and args.batch == 32 and args.depth == 4) else None,
+        alg = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
+        # what the matrix pipe executes: Winograd F(2x2,3x3) runs 16 multiply-adds per 36 algorithmic ones
+        wino = dom[0].startswith("gemm_wino") or dom[0].startswith("wgrad_wino")
+        executed = alg / 2.25 if wino else alg
+        c2 = args.size == 256 and fs == 1 and args.batch == 32 and args.depth == 4
+        from unet_nested4tiny_objects_keypoints_amd import _lib as _l
+        traffic = pmc_traffic(dom[0], _l.source_hash()) if c2 else None
+        traffic_alg = dom[1]["bytes"] / dom[1]["launches"]
+        roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
+                    "achieved_note": "multiply-adds executed on the matrix pipe x2 / launch time (HIP events)",
+                    "achieved_algorithmic": round(alg, 2),
+                    "algorithm": ("winograd F(2x2,3x3), fp32: 16 MFMA multiply-adds per 36 algorithmic ones"
+                                  if wino else "direct summation, fp32 MFMA"),
+                    "traffic": traffic,
+                    "traffic_algorithmic": round(traffic_alg),
+                    "traffic_over_algorithmic": None if traffic is None else round(traffic / traffic_alg, 3),
                     "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes "
-                                    "of this command; profiles/pmc_hbm_traffic_latest.json)",
+                                    "of this command; profiles/pmc_hbm_traffic_latest.json, null when that file is "
+                                    "from another build); traffic_algorithmic = 4 B x (Cin + Cout) x pixels",
                     "launches_per_step": dom[1]["launches"] / sampled_steps,
                     "timed_steps_with_launch_events": sampled_steps,
                     "avg_launch_ms": round(dom[1]["ms"] / dom[1]["launches"], 4),
                     "flop_per_launch_avg": dom[1]["flops"] / dom[1]["launches"]}
-        if dom[0].startswith("gemm_wino"):
-            # `achieved` counts ALGORITHMIC FLOPs (2*9*Cin*Cout per pixel).  The Winograd F(2x2,3x3) kernel
-            # executes 16/36 of those multiply-adds on the MFMA pipe, so the pipe itself runs at achieved/2.25.
-            roofline["algorithm"] = "winograd F(2x2,3x3), fp32: 16 MFMA multiply-adds per 36 algorithmic ones"
-            roofline["mfma_executed_tflops"] = round(ach / 2.25, 2)
-            roofline["mfma_pipe_frac"] = round(ach / 2.25 / PEAK_F32_MFMA_TFLOPS, 4)
         if "X00.fwd" in regions and args.size == 256 and fs == 1 and args.in_channels == 1:
             t_img_us = 1e3 * regions["X00.fwd"]["ms"] / regions["X00.fwd"]["count"] / args.batch
             floor_c = X00_GFLOP_PER_IMG * 1e9 / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e6
@@ -287,6 +344,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "prewarm_steps": args.prewarm,
         "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True,
         "scaling": "weak",
@@ -299,7 +357,10 @@ def main():
                                   args.batch, args.depth - 1),
                    "global_batch": world * args.batch, "per_gpu_batch": args.batch,
                    "parallelism": "dp%d" % world if distributed else "single",
-                   "grad_allreduce_buckets": None if averager is None else len(averager.buckets_last_step)},
+                   "world_size": dist.get_world_size() if distributed else 1,
+                   "backend": dist.get_backend() if distributed else None,
+                   "grad_allreduce_buckets": None if averager is None else len(averager.buckets_last_step),
+                   "replicas_bit_identical": replicas_identical},
         "fwd_ms_per_img": round(fwd_ms_per_img, 4),
         "roofline": roofline,
         "roofline_x00": roofline_x00,

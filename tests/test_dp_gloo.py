@@ -1,6 +1,7 @@
 """Data-parallel path on CPU: two processes over gloo (world_size 2) drive the GradientAverager exactly as the
 engine's backward does (gradient-ready order, node by node) and must end with the average of the two ranks'
-gradients in every parameter's slot of the flat buffer; plus host-side checks of the ready order."""
+gradients in every parameter's ``.grad`` -- set when it was None, accumulated when it was kept (gradient accumulation,
+``zero_grad(set_to_none=False)``); plus host-side checks of the ready order."""
 import os
 import socket
 
@@ -14,6 +15,10 @@ from oracle.unet_nested_oracle import UNetNestedOracle
 from unet_nested4tiny_objects_keypoints_amd import UNet_Nested, dp
 
 CTOR = dict(in_channels=1, n_classes=4, feature_scale=8)
+
+
+def _close(a, b):
+    return float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-30
 
 
 def _free_port():
@@ -53,19 +58,42 @@ def _worker(rank, world, port, state, bucket_bytes, result_dir):
         grads = _rank_grads(rank, state)
         named = dict(model.named_parameters())
         names = {id(p): k for k, p in named.items()}
-        # play the engine's role: write every gradient into its flat-buffer slot, report node by node
         order = dp.ready_order(model)
-        step = 4
-        for i in range(0, len(order), step):
-            fresh = []
-            for p in order[i:i + step]:
-                slot = model._grad_alloc(p)
-                slot.copy_(grads[names[id(p)]])
-                fresh.append((p, slot))
-            model._grad_sink(fresh)
-        model._grad_done()
-        out = {names[id(p)]: avg.alloc(p).clone() for p in order}
-        torch.save({"avg": out, "mine": grads, "buckets": avg.buckets_last_step}, os.path.join(result_dir, "r%d.pt" % rank))
+
+        def backward(scale):
+            # play the engine's role: write every gradient into its flat-buffer slot, report node by node
+            step = 4
+            for i in range(0, len(order), step):
+                fresh = []
+                for p in order[i:i + step]:
+                    slot = model._grad_alloc(p)
+                    slot.copy_(scale * grads[names[id(p)]])
+                    fresh.append((p, slot))
+                model._grad_sink(fresh)
+            assert model._grad_done() is True  # the averager delivers into p.grad itself
+
+        backward(1.0)
+        out = {names[id(p)]: p.grad.clone() for p in order}
+        buckets = list(avg.buckets_last_step)
+        # gradient accumulation: a second backward without zero_grad must ADD (p.grad used to alias the
+        # flat work buffer, so the wgrad kernels overwrote it and autograd then doubled it)
+        backward(2.0)
+        acc = {names[id(p)]: p.grad.clone() for p in order}
+        # zero_grad(set_to_none=False): p.grad stays the same tensor, zeroed in place
+        model.zero_grad(set_to_none=False)
+        backward(3.0)
+        zeroed = {names[id(p)]: p.grad.clone() for p in order}
+        # the default zero_grad (set_to_none=True) again
+        model.zero_grad()
+        backward(0.5)
+        fresh2 = {names[id(p)]: p.grad.clone() for p in order}
+        # a mixed state: one gradient dropped by hand, the others kept
+        order[3].grad = None
+        backward(1.0)
+        mixed = {names[id(p)]: p.grad.clone() for p in order}
+        torch.save({"avg": out, "acc": acc, "zeroed": zeroed, "fresh2": fresh2, "mixed": mixed,
+                    "mixed_none": names[id(order[3])], "mine": grads, "buckets": buckets},
+                   os.path.join(result_dir, "r%d.pt" % rank))
     finally:
         dist.destroy_process_group()
 
@@ -82,6 +110,11 @@ def test_gradient_average_world2(tmp_path, bucket_bytes):
         want = (r0["mine"][k] + r1["mine"][k]) / 2
         assert torch.allclose(r0["avg"][k], want, rtol=1e-6, atol=1e-12), k
         assert torch.equal(r0["avg"][k], r1["avg"][k]), k
+        assert _close(r0["acc"][k], 3 * want), k        # 1x then 2x accumulated
+        assert _close(r0["zeroed"][k], 3 * want), k     # zeroed in place, then 3x
+        assert _close(r0["fresh2"][k], 0.5 * want), k
+        f = 1.0 if k == r0["mixed_none"] else 1.5
+        assert _close(r0["mixed"][k], f * want), k
     n_buckets = len(r0["buckets"])
     assert n_buckets == (1 if bucket_bytes == 1 << 30 else n_buckets) and n_buckets >= 1
     if bucket_bytes == 1 << 12:

@@ -135,6 +135,22 @@ def _rccl_worker(rank, port, state, out_dir):
                 buckets = len(avg.buckets_last_step)
             res[tag] = {k: p.detach().cpu() for k, p in m.named_parameters()}
             res[tag + "_buckets"] = buckets
+            # gradient accumulation / zero_grad(set_to_none=False) through the real backward (p.grad must
+            # never alias the flat work buffer the next backward writes into)
+            crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+
+            def bwd(scale):
+                outs = m(x)
+                (scale * sum(crit(o, t) for o in outs) / len(outs)).backward()
+
+            m.zero_grad()
+            bwd(1.0)
+            bwd(2.0)
+            res[tag + "_acc"] = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
+            m.zero_grad(set_to_none=False)
+            bwd(1.0)
+            torch.cuda.synchronize()
+            res[tag + "_zeroed"] = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()}
         torch.save(res, os.path.join(out_dir, "rccl.pt"))
     finally:
         dist.destroy_process_group()
@@ -155,3 +171,7 @@ def test_rccl_backend_collective_path_world_of_one(tmp_path):
     assert r["rccl_buckets"] >= 2
     for k in r["plain"]:
         assert torch.equal(r["plain"][k], r["rccl"][k]), k
+        assert torch.equal(r["plain_acc"][k], r["rccl_acc"][k]), k
+        assert torch.equal(r["plain_zeroed"][k], r["rccl_zeroed"][k]), k
+    k = "final_3.weight"
+    assert float((r["rccl_acc"][k] - 3 * r["rccl_zeroed"][k]).abs().max()) < 1e-5 * float(r["rccl_acc"][k].abs().max())

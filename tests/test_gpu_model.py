@@ -8,7 +8,7 @@ GPU only (pytest -m gpu).  Bar: <= 1e-4 relative fp32 (north_star).
 import pytest
 import torch
 
-from tests.helpers import GOLDEN_CASES, assert_grads_close, is_pre_bn_bias, load_golden, rel_err, sub
+from tests.helpers import DEPTH_CASES, GOLDEN_CASES, assert_grads_close, is_pre_bn_bias, load_golden, rel_err, sub
 
 pytestmark = pytest.mark.gpu
 
@@ -35,13 +35,13 @@ def _loss(outs, target):
     return sum(crit(o, target) for o in outs) / len(outs)
 
 
-def _check_grads_gate_aware(m, ctor, state, x, target, golden_grads=None, masks=None):
+def _check_grads_gate_aware(m, ctor, state, x, target, golden_grads=None, masks=None, label=""):
     """Parameter gradients of the HIP model `m` (already back-propagated) against the oracle run with the
     HIP forward's ReLU gates (see tests/helpers.py).  When no gate differs from the oracle's own, the
     reference-generated golden gradients must match to TOL as well; with flips they can only match loosely."""
     from oracle.step_oracle import focal_bce_2d_oracle
     from oracle.unet_nested_oracle import UNetNestedOracle
-    from tests.helpers import install_hip_gates
+    from tests.helpers import check_flips, install_hip_gates
     ref = UNetNestedOracle(**ctor)
     ref.load_state_dict(state)
     ref.train()
@@ -51,7 +51,7 @@ def _check_grads_gate_aware(m, ctor, state, x, target, golden_grads=None, masks=
     gated = install_hip_gates(ref, m._debug_saved)
     ro = ref(x)
     (sum(focal_bce_2d_oracle(o, target) for o in ro) / len(ro)).backward()
-    flips = sum(g.flips for g in gated)
+    flips = check_flips(gated, label)
     got = {k: p.grad.cpu() for k, p in m.named_parameters()}
     assert_grads_close(got, {k: p.grad for k, p in ref.named_parameters()}, ctor, TOL)
     if golden_grads is not None:
@@ -65,19 +65,19 @@ def _check_grads_gate_aware(m, ctor, state, x, target, golden_grads=None, masks=
     return flips, ro
 
 
-@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("name", GOLDEN_CASES + DEPTH_CASES)
 def test_golden_eval_forward(dev, name):
     z, ctor = load_golden(name)
     m = _hip_model(ctor, sub(z, "state0"), dev).eval()
     with torch.no_grad():
         outs = m(torch.from_numpy(z["x"]).to(dev))
-    assert isinstance(outs, tuple) and len(outs) == 3
+    assert isinstance(outs, tuple) and len(outs) == ctor.get("depth", 4) - 1
     for i, o in enumerate(outs):
         assert o.shape == z["eval_out/%d" % i].shape
         assert rel_err(o.cpu(), z["eval_out/%d" % i]) < TOL
 
 
-@pytest.mark.parametrize("name", GOLDEN_CASES)
+@pytest.mark.parametrize("name", GOLDEN_CASES + DEPTH_CASES)
 def test_golden_train_step(dev, name):
     """train mode, dropout disabled: outputs, loss, every parameter gradient, BN running stats."""
     z, ctor = load_golden(name)
@@ -91,7 +91,7 @@ def test_golden_train_step(dev, name):
     for i, o in enumerate(outs):
         assert rel_err(o.detach().cpu(), z["train_out/%d" % i]) < TOL
     assert abs(float(loss.detach()) - float(z["loss"])) <= TOL * abs(float(z["loss"]))
-    _check_grads_gate_aware(m, ctor, sub(z, "state0"), x.cpu(), target.cpu(), sub(z, "grad"))
+    _check_grads_gate_aware(m, ctor, sub(z, "state0"), x.cpu(), target.cpu(), sub(z, "grad"), label="golden:" + name)
     bufs = sub(z, "state1_buffers")
     for k, b in m.named_buffers():
         if b.dtype.is_floating_point:
@@ -138,6 +138,11 @@ ORACLE_CASES = [
     (dict(in_channels=1, n_classes=4, feature_scale=8, depth=5, is_deconv=False), 1, 32, 32),
     (dict(in_channels=1, n_classes=4, feature_scale=1), 2, 64, 64),               # configs[1] widths (base 32)
     (dict(in_channels=1, n_classes=4, feature_scale=2, is_batchnorm=False), 1, 32, 32),
+    # BASELINE.json's configurations at their REAL geometry and widths, reduced batch (fp32; the CPU oracle takes
+    # seconds at these sizes): outputs, loss, BatchNorm running statistics and gate-aware gradients
+    (dict(in_channels=1, n_classes=4, feature_scale=1), 4, 256, 256),             # configs[1]: base 32, 256x256
+    (dict(in_channels=1, n_classes=4, feature_scale=1), 1, 512, 512),             # configs[3]: 512x512, base 32
+    (dict(in_channels=3, n_classes=5, feature_scale=0.5, depth=5), 1, 384, 384),  # configs[4]: depth 5, base 64, 3->5
 ]
 
 
@@ -165,7 +170,7 @@ def test_train_step_vs_oracle(dev, case):
     for o, r in zip(outs, ro):
         assert rel_err(o.detach().cpu(), r) < TOL
     assert abs(float(loss.detach()) - float(rl)) <= TOL * abs(float(rl))
-    _check_grads_gate_aware(m, ctor, state, x, target)
+    _check_grads_gate_aware(m, ctor, state, x, target, label="oracle:%s b%d %dx%d" % (sorted(ctor.items()), b, h, w))
     for (k, bh), (_, br) in zip(m.named_buffers(), ref.named_buffers()):
         if bh.dtype.is_floating_point:
             assert rel_err(bh.cpu(), br) < TOL, k
@@ -309,9 +314,120 @@ def test_batched_weight_images_track_parameter_updates(dev):
     assert {e.phase for e in plan.entries.values()} == {"fwd", "bwd"} and len(plan.entries) > 20
     m.eval()
     with torch.no_grad():
+        n0 = plan.launches
         a = m(x)
-        b = m(x)  # nothing changed: the plan skips the launch
+        b = m(x)  # not frozen: the images are rebuilt on every pass
+        assert plan.launches == n0 + 2
+        m.freeze_weight_images()
+        c = m(x)
+        n1 = plan.launches
+        d = m(x)  # frozen: nothing is packed
+        assert plan.launches == n1
     assert all(torch.equal(u, v) for u, v in zip(a, b))
+    assert all(torch.equal(u, v) for u, v in zip(a, c))
+    assert all(torch.equal(u, v) for u, v in zip(a, d))
+
+
+class _DataAdamW(torch.optim.Optimizer):
+    """Test-local restatement of the reference's default optimizer (tools/optimizers/adamw.py:50-98): every update
+    goes through ``p.data`` (addcdiv_ / sub_), which never bumps ``p._version``."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    def step(self):
+        import math
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                grad = p.grad.data
+                state = self.state[p]
+                if len(state) == 0:
+                    state["step"] = 0
+                    state["exp_avg"] = torch.zeros_like(p.data)
+                    state["exp_avg_sq"] = torch.zeros_like(p.data)
+                exp_avg, exp_avg_sq = state["exp_avg"], state["exp_avg_sq"]
+                beta1, beta2 = group["betas"]
+                state["step"] += 1
+                exp_avg.mul_(beta1).add_(grad, alpha=1 - beta1)
+                exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+                denom = exp_avg_sq.sqrt().add_(group["eps"])
+                step_size = group["lr"] * math.sqrt(1 - beta2 ** state["step"]) / (1 - beta1 ** state["step"])
+                decayed = torch.mul(p.data, group["weight_decay"])
+                p.data.addcdiv_(exp_avg, denom, value=-step_size)
+                p.data.sub_(decayed)
+
+
+def test_weight_images_follow_updates_through_dot_data(dev):
+    """The reference's default AdamW updates through p.data (tools/optimizers/adamw.py:95-98; trainer/trainer.py:358-363),
+    which leaves p._version alone.  Four such steps with the batched weight images must be bit-identical to the
+    per-launch packing (engine.USE_PACK_PLAN = False), and the parameter versions must indeed not have moved."""
+    import copy
+
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, UNet_Nested, engine, train_step
+    torch.manual_seed(22)
+    m = UNet_Nested(in_channels=1, n_classes=4, feature_scale=4).to(dev).train()
+    m.drop_out.p = 0.0
+    ref = copy.deepcopy(m)
+    x = torch.randn(2, 1, 32, 32, device=dev)
+    t = torch.rand(2, 4, 32, 32, device=dev)
+    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+    opt_m, opt_r = _DataAdamW(m.parameters(), lr=1e-2), _DataAdamW(ref.parameters(), lr=1e-2)
+    v0 = [p._version for p in m.parameters()]
+    losses = []
+    for step in range(4):
+        outs_m, loss_m = train_step(m, opt_m, crit, x, t)
+        engine.USE_PACK_PLAN = False
+        try:
+            outs_r, loss_r = train_step(ref, opt_r, crit, x, t)
+        finally:
+            engine.USE_PACK_PLAN = True
+        assert all(torch.equal(a, b) for a, b in zip(outs_m, outs_r)), step
+        assert torch.equal(loss_m, loss_r), step
+        for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+            assert torch.equal(p, q), (step, k)
+        losses.append(float(loss_m))
+    assert [p._version for p in m.parameters()] == v0   # the hole the old version-keyed cache fell into
+    assert len(set(losses)) == 4
+
+
+def test_eval_forward_sees_dot_data_writes(dev):
+    """p.data.mul_ / copy_ between two eval forwards (EMA, clipping, init.kaiming_normal_(m.weight.data),
+    models/unet.py:167): the second forward must change exactly as the oracle's does."""
+    from oracle.unet_nested_oracle import UNetNestedOracle
+    ctor = dict(in_channels=1, n_classes=4, feature_scale=4)
+    torch.manual_seed(23)
+    ref = UNetNestedOracle(**ctor).eval()
+    m = _hip_model(ctor, ref.state_dict(), dev).eval()
+    x = torch.randn(2, 1, 32, 32)
+    with torch.no_grad():
+        a = m(x.to(dev))
+        ra = ref(x)
+        for mod in (m, ref):
+            getattr(mod.conv10.conv2, "0").weight.data.mul_(2.0)
+            mod.up_concat01.up.weight.data.mul_(-1.5)
+            w = getattr(mod.up_concat02.conv.conv1, "0").weight
+            w.data.copy_(torch.full_like(w, 0.01))
+        b = m(x.to(dev))
+        rb = ref(x)
+    for o, r in zip(a, ra):
+        assert rel_err(o.cpu(), r) < TOL
+    for o, r in zip(b, rb):
+        assert rel_err(o.cpu(), r) < TOL
+    assert max(rel_err(p.cpu(), q.cpu()) for p, q in zip(a, b)) > 1e-2   # the write mattered
+    # frozen images are an explicit opt-in and need an explicit invalidation
+    with torch.no_grad():
+        m.freeze_weight_images()
+        c = m(x.to(dev))
+        getattr(m.conv10.conv2, "0").weight.data.mul_(0.5)
+        getattr(ref.conv10.conv2, "0").weight.data.mul_(0.5)
+        m.invalidate_weight_images()
+        d = m(x.to(dev))
+        rd = ref(x)
+    assert all(torch.equal(u, v) for u, v in zip(b, c))
+    for o, r in zip(d, rd):
+        assert rel_err(o.cpu(), r) < TOL
 
 
 def test_training_trajectory_tracks_oracle(dev):
@@ -351,3 +467,37 @@ def test_training_trajectory_tracks_oracle(dev):
     for k in sd_r:
         if k.endswith("running_var") or k.endswith("running_mean"):
             assert rel_err(sd_h[k].cpu(), sd_r[k]) < 1e-3, k
+
+
+@pytest.mark.parametrize("fmt", ["pth", "tar", "pth_module_prefix"])
+def test_resumed_checkpoint_runs_the_hip_path(dev, tmp_path, fmt):
+    """SURVEY 8 row f2 on the GPU: a trainer-format file (trainer/trainer.py:240-249 .pth, :403-413 .tar, with or
+    without DataParallel's `module.` prefix) written from the reference's own state (golden fixture) is resumed into
+    the HIP model, which must then reproduce the reference's eval outputs."""
+    from unet_nested4tiny_objects_keypoints_amd import UNet_Nested, checkpoint
+    z, ctor = load_golden("c1_fs4_64x64_b2_seed1")
+    state = sub(z, "state0")
+    if fmt == "pth":
+        path = str(tmp_path / checkpoint.best_model_name(3, 0.25, 0.5))
+        torch.save(state, path)
+    elif fmt == "pth_module_prefix":
+        path = str(tmp_path / "dp.pth")
+        torch.save({"module." + k: v for k, v in state.items()}, path)
+    else:
+        path = str(tmp_path / "ckpt.tar")
+        torch.save({"model_state_dict": state, "optimizer_state_dict": None, "epoch": 7}, path)
+    m = UNet_Nested(**ctor).to(dev).eval()
+    x = torch.from_numpy(z["x"]).to(dev)
+    with torch.no_grad():
+        before = m(x)                               # warm pass with the random initial weights (packs weight images)
+        assert checkpoint.resume(m, path, map_location="cpu") == 0
+        outs = m(x)
+    assert next(m.parameters()).is_cuda
+    for i, o in enumerate(outs):
+        assert rel_err(o.cpu(), z["eval_out/%d" % i]) < TOL
+    assert max(rel_err(a.cpu(), b.cpu()) for a, b in zip(before, outs)) > 1e-3
+    # and back: what the HIP model saves is what the reference would read (names, shapes, values)
+    saved = checkpoint.save_best(m, str(tmp_path), 0, 1.0, 1.0)
+    back = torch.load(saved, map_location="cpu")
+    assert list(back.keys()) == list(state.keys())
+    assert all(torch.equal(back[k], state[k]) for k in state)

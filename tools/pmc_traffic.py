@@ -12,14 +12,22 @@ calibrates it).  The counters are collected in separate passes as that guide pre
 import collections
 import csv
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def key(name):
     name = name.replace("void ", "").replace("unetpp::(anonymous namespace)::", "")
     m = re.match(r"([A-Za-z_0-9:]+(<[^>]*>)?)", name)
     return m.group(1) if m else name[:40]
+
+
+def _build_hash():
+    from unet_nested4tiny_objects_keypoints_amd import _lib
+    return _lib.source_hash()
 
 
 def main(fetch_dir, write_dir, out_path):
@@ -46,7 +54,7 @@ def main(fetch_dir, write_dir, out_path):
                     "fetch_bytes_x2_per_launch": round(f), "write_bytes_per_launch": round(w)})
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --steps 2 --warmup 1 "
                        "--no-cpu-baseline --no-launch-timing` (3 train steps + 7 eval forwards); KB x1024; FETCH_SIZE "
-                       "doubled per MI355X_MICROARCH.md", "kernels": out}, open(out_path, "w"), indent=1)
+                       "doubled per MI355X_MICROARCH.md", "build_hash": _build_hash(), "kernels": out}, open(out_path, "w"), indent=1)
 
 
 if __name__ == "__main__":

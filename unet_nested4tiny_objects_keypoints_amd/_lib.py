@@ -124,6 +124,17 @@ SIGNATURES = {
 _LIB = None
 
 
+def source_hash() -> str:
+    """Hash of every source the library is built from: stamps PMC summaries so that bench.py can tell a profile of
+    another build from one of this build (tools/pmc_traffic.py, bench.py roofline.traffic)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(INCLUDE, "unetpp_hip.h")]:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP sources for gfx950 into the in-tree shared object (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]

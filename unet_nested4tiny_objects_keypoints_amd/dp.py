@@ -11,7 +11,11 @@ and the only exchange per step is the gradient average:
     it (engine._new_grad), so a bucket is a contiguous slice and needs no packing copy;
   * whenever the engine reports a node's gradients final and the open bucket has reached ``bucket_bytes``,
     the slice is all-reduced on a side stream behind an event; backward keeps launching kernels meanwhile;
-  * the compute stream joins the side stream once, at the end of backward.
+  * the compute stream joins the side stream once, at the end of backward;
+  * the averager -- not autograd -- then delivers the gradients: ``p.grad`` becomes the parameter's slice of the flat
+    buffer when it was None (the buffers alternate between two homes, so the next backward never writes into a
+    live ``p.grad``), and is ADDED to when it already exists (gradient accumulation, ``zero_grad(set_to_none=False)``),
+    exactly as autograd's AccumulateGrad would.  The engine returns no parameter gradients to autograd in this mode.
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): 8.8 MB of gradients (BASELINE configs[1]/[2]) is
 latency-bound, so the default is few, large buckets (2 MiB) rather than many small ones.
@@ -67,7 +71,14 @@ class GradientAverager:
         dev = self.params[0].device
         self.cuda = dev.type == "cuda"
         total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        # two homes for the flat gradient vector: backward writes into `flat`; when its slices are handed out as
+        # p.grad the other home becomes the work buffer, so a live p.grad is never overwritten by the next backward
+        self._homes = [torch.zeros(total, dtype=torch.float32, device=dev), None]
+        self._cur = 0
+        self.flat = self._homes[0]
+        self._avg_op = dist.ReduceOp.SUM
+        if dist.get_backend(process_group) == "nccl":
+            self._avg_op = dist.ReduceOp.AVG  # RCCL averages in the collective: no divide kernel per bucket
         self.offset = {}
         off = 0
         for p in self.params:
@@ -100,7 +111,8 @@ class GradientAverager:
             self._launch(self._ready_upto)
 
     def done(self):
-        """End of backward: flush the tail bucket and make the compute stream wait for the averages."""
+        """End of backward: flush the tail bucket, make the compute stream wait for the averages and deliver them
+        into ``p.grad``.  Returns True: the engine must not hand the same tensors to autograd as well."""
         if self._frontier_index != len(self.params):
             raise RuntimeError("backward finished but %d parameter gradients were never reported"
                                % (len(self.params) - self._frontier_index))
@@ -113,6 +125,29 @@ class GradientAverager:
                 w.wait()
         self._works = []
         self._begin()
+        self._deliver()
+        return True
+
+    def _deliver(self):
+        held = [p.grad for p in self.params]
+        if all(g is None for g in held):
+            for p in self.params:
+                p.grad = self.alloc(p)
+            self._cur ^= 1  # the slices are live now: the next backward works in the other home
+            if self._homes[self._cur] is None:
+                self._homes[self._cur] = torch.zeros_like(self.flat)
+            self.flat = self._homes[self._cur]
+            return
+        other = self._homes[self._cur ^ 1]
+        if other is not None and all(g is not None and g.data_ptr() == other.data_ptr() + 4 * self.offset[id(p)]
+                                     for p, g in zip(self.params, held)):
+            other.add_(self.flat)  # every p.grad is its slice of the other home: one add for all of them
+            return
+        for p, g in zip(self.params, held):
+            if g is None:
+                p.grad = self.alloc(p).clone()
+            else:
+                g.add_(self.alloc(p))
 
     # ---- internals --------------------------------------------------------------------------------
     def _begin(self):
@@ -130,8 +165,9 @@ class GradientAverager:
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream())  # the slice's wgrad kernels are enqueued before this
             with torch.cuda.stream(self.stream):
-                dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
-                chunk.div_(self.world)
+                dist.all_reduce(chunk, op=self._avg_op, group=self.group)
+                if self._avg_op == dist.ReduceOp.SUM:
+                    chunk.div_(self.world)
         else:
             w = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             w.wait()

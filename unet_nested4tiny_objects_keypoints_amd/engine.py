@@ -482,8 +482,10 @@ class _UNetNestedFn(torch.autograd.Function):
         if dx is not None:
             dx_nchw = ops.nhwc_to_nchw(dx)
         done = getattr(model, "_grad_done", None)
-        if done is not None:
-            done()
+        if done is not None and done():
+            # data parallel: the averager has put (or accumulated) the averaged gradients into p.grad itself; handing
+            # the flat-buffer views to autograd as well would let AccumulateGrad alias p.grad with the work buffer
+            return (None, dx_nchw) + (None,) * len(ctx.params)
         return (None, dx_nchw) + tuple(grads.get(p) if need else None
                                       for p, need in zip(ctx.params, ctx.needs_input_grad[2:]))
 

@@ -35,11 +35,12 @@ class LaunchTimer:
 
     def summary(self):
         out = {}
-        for kind, flops, s, e in self.launches:
-            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "flops": 0.0})
+        for kind, flops, nbytes, s, e in self.launches:
+            d = out.setdefault(kind, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
             d["flops"] += flops
+            d["bytes"] += nbytes
         reg = {}
         for name, s, e in self.regions:
             d = reg.setdefault(name, {"count": 0, "ms": 0.0})
@@ -75,8 +76,9 @@ class region:
         return False
 
 
-def _timed_call(kind, flops, fn):
-    """kind = label of the launch, or None to ask the library which kernel it picked (unetpp_last_kernel_name)."""
+def _timed_call(kind, flops, fn, nbytes=0.0):
+    """kind = label of the launch, or None to ask the library which kernel it picked (unetpp_last_kernel_name).
+    flops / nbytes: ALGORITHMIC work of the launch (every operand element read or written once)."""
     if _TIMER is None:
         return fn()
     s, e = _TIMER._pair()
@@ -85,7 +87,7 @@ def _timed_call(kind, flops, fn):
     e.record()
     if kind is None:
         kind = _lib.lib().unetpp_last_kernel_name().decode()
-    _TIMER.launches.append((kind, flops, s, e))
+    _TIMER.launches.append((kind, flops, nbytes, s, e))
     return r
 
 
@@ -192,9 +194,15 @@ class PackPlan:
 
     The first time a launch is seen (engine pass `phase`, weight source, channel structure) its image is packed by
     itself into a persistent buffer and a job is recorded; from then on `begin(phase)` packs every recorded image of
-    that pass with a single kernel before the pass starts and the launches just pick their buffer.  Nothing is
-    packed when no source parameter changed since the last run (inference, gradient accumulation).  Entries keep
-    their source tensor alive and are dropped when unused for a few passes."""
+    that pass with a single kernel before the pass starts and the launches just pick their buffer.
+
+    The images are rebuilt on EVERY pass: nothing observable from Python says that a parameter's storage kept its
+    contents (the reference's own optimizers update through ``p.data`` -- tools/optimizers/adamw.py:95-98,
+    sgdw.py:108, adabound.py:120 -- which leaves ``p._version`` untouched, as do ``init.*_(m.weight.data)``,
+    ``dist.broadcast(p.data)`` or EMA/clipping through ``.data``).  Skipping is an explicit opt-in for serving:
+    ``frozen = True`` (UNet_Nested.freeze_weight_images) keeps the images until ``invalidate()``, which the module
+    calls from ``load_state_dict``, ``_apply`` (.to()/.float()/.cuda()) and ``train()``.  Entries keep their source
+    tensor alive and are dropped when unused for a few passes."""
 
     class _Entry:
         __slots__ = ("image", "n_img", "job", "src", "phase", "fresh", "used")
@@ -202,9 +210,15 @@ class PackPlan:
     def __init__(self):
         self.entries = {}
         self._tables = {}    # phase -> (device table, host array, signatures, max floats)
-        self._versions = {}  # phase -> parameter versions at the last run
+        self._packed = set()  # phases whose images are current (only consulted while frozen)
+        self.frozen = False
         self.phase = None
         self.pass_id = 0
+        self.launches = 0     # batched pack launches issued (tests)
+
+    def invalidate(self) -> None:
+        """The parameters may have changed: the next pass of every phase rebuilds its images."""
+        self._packed.clear()
 
     def __deepcopy__(self, memo):  # copies / pickles of a model start with an empty plan
         return PackPlan()
@@ -222,18 +236,18 @@ class PackPlan:
         if not sigs:
             return
         ents = [self.entries[k] for k in sigs]
-        versions = tuple(e.src._version for e in ents)
         tab = self._tables.get(phase)
         if tab is None or tab[2] != sigs:
             arr = (PackJob * len(ents))(*[e.job for e in ents])
             dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(ents[0].image.device)
             tab = (dev, arr, sigs, max(e.n_img for e in ents))
             self._tables[phase] = tab
-            self._versions.pop(phase, None)
-        if self._versions.get(phase) != versions:
+            self._packed.discard(phase)
+        if not (self.frozen and phase in self._packed):
             check(_lib.lib().unetpp_gemm_pack_weight_images(_ptr(tab[0]), len(ents), tab[3], _stream()),
                   "unetpp_gemm_pack_weight_images")
-            self._versions[phase] = versions
+            self.launches += 1
+            self._packed.add(phase)
         for e in ents:
             e.fresh = self.pass_id
 
@@ -321,8 +335,10 @@ def gemm_fwd(n: int, h: int, w: int, taps: int, ins: Sequence[V], outs: Sequence
     if d.weight_image is None and from_src:  # generic kernel: it reads the packed operand
         packed = weight.packed()
         d.weight = packed.data_ptr()
+    acc = sum(v.c_len for v in d.out[:d.n_out] if v.accumulate)  # accumulated outputs are read as well
     _timed_call(None, 2.0 * n * h * w * taps * k * nc,
-                lambda: check(_lib.lib().unetpp_gemm_fwd(C.byref(d), _stream()), "unetpp_gemm_fwd"))
+                lambda: check(_lib.lib().unetpp_gemm_fwd(C.byref(d), _stream()), "unetpp_gemm_fwd"),
+                4.0 * n * h * w * (k + nc + acc))
 
 
 def pack_weight(dst: torch.Tensor, src: torch.Tensor, t: int, k: int, n: int, dstr, sstr, flip: bool = False) -> None:
@@ -353,7 +369,8 @@ def wgrad(n: int, h: int, w: int, taps: int, xs: Sequence[V], dys: Sequence[V], 
     slabs = torch.empty(split * (planes * k + 1) * nc, dtype=torch.float32, device=xs[0].t.device)
     d.slabs = slabs.data_ptr()
     _timed_call(None, 2.0 * n * h * w * taps * k * nc,
-                lambda: check(lib.unetpp_wgrad(C.byref(d), _stream()), "unetpp_wgrad"))
+                lambda: check(lib.unetpp_wgrad(C.byref(d), _stream()), "unetpp_wgrad"),
+                4.0 * n * h * w * (k + nc))
     if n_inner is None:
         n_inner = nc
     check(lib.unetpp_wgrad_finish(_ptr(slabs), split, planes, k, nc, n_inner, _ptr(dw), dw_strides[0], dw_strides[1],

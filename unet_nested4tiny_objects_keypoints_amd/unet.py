@@ -146,6 +146,35 @@ class UNet_Nested(nn.Module):
     def forward(self, inputs):
         return engine.run(self, inputs)
 
+    # ---- weight-image cache control (ops.PackPlan) ------------------------------------------------
+    def freeze_weight_images(self, frozen: bool = True):
+        """Serving opt-in: keep the kernels' LDS weight images between passes instead of rebuilding them from the
+        parameters every pass (one launch).  Only for weights that really do not change: anything that writes the
+        parameters behind the module's back (``p.data`` updates) must be followed by ``invalidate_weight_images()``."""
+        plan = engine._plan_of(self)
+        plan.frozen = bool(frozen)
+        plan.invalidate()
+        return self
+
+    def invalidate_weight_images(self):
+        plan = self.__dict__.get("_pack_plan")
+        if plan is not None:
+            plan.invalidate()
+
+    def _apply(self, fn, *args, **kwargs):  # .to() / .cuda() / .float(): new storages
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_weight_images()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_weight_images()
+        return out
+
+    def train(self, mode: bool = True):
+        self.invalidate_weight_images()
+        return super().train(mode)
+
 
 def count_param(model):
     """models/unet.py:176-180"""
