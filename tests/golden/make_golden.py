@@ -226,8 +226,10 @@ def main():
     if only in (None, "depth"):
         # depth generalisation: level 5 = the reference's commented-out lines; 2/3 = truncations
         run_depth_case("d5_fs8_rgb5_32x32_b2", 5, dict(in_channels=3, n_classes=5, feature_scale=8), 2, (32, 32), 0)
-        run_depth_case("d5_fs8_bilinear_16x32_b1", 5, dict(in_channels=1, n_classes=4, feature_scale=8, is_deconv=False),
-                       1, (16, 32), 1)
+        # (batch 2 at 32x48: the deepest BatchNorm still sees 2*2*3 = 12 values per channel; with 2 values its
+        # normalisation is +-1 whatever the input and the gradients are ill-conditioned in fp32)
+        run_depth_case("d5_fs8_bilinear_32x48_b2", 5, dict(in_channels=1, n_classes=4, feature_scale=8, is_deconv=False),
+                       2, (32, 48), 1)
         run_depth_case("d3_fs8_32x48_b2", 3, dict(in_channels=1, n_classes=4, feature_scale=8), 2, (32, 48), 0)
         run_depth_case("d2_fs4_64x64_b4", 2, dict(in_channels=1, n_classes=4, feature_scale=4), 4, (64, 64), 0)
         if only == "depth":

@@ -20,7 +20,7 @@ GOLDEN_CASES = [
 # fixture-time subclass, depth 2/3 as truncations of its graph (tests/golden/make_golden.py)
 DEPTH_CASES = [
     "d5_fs8_rgb5_32x32_b2",
-    "d5_fs8_bilinear_16x32_b1",
+    "d5_fs8_bilinear_32x48_b2",
     "d3_fs8_32x48_b2",
     "d2_fs4_64x64_b4",
 ]
