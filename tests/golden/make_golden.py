@@ -218,6 +218,65 @@ def run_depth_case(name, depth, ctor_kwargs, batch, hw, seed):
     print("%-28s %8.1f KB  loss=%.6f" % (name, os.path.getsize(path) / 1024, float(loss)))
 
 
+def run_plain_unet_case(name, widths, n_classes, n_channels, batch, hw, seed, seeded):
+    """The reference's classic UNet (models/unet.py:8-117).  widths=None: the reference class itself (13.4 M
+    parameters -> state from tests.helpers.seeded_state, gradients subsampled); else a fixture-time subclass that
+    wires the reference's own inconv/down/up/outconv blocks with narrower widths (full state and gradients)."""
+    import torch
+    from models.unet import UNet, down, inconv, outconv, up
+    from tools.losses.focal_loss import FocalLoss_BCE_2d
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+    from tests.helpers import GRAD_STRIDE, seeded_state
+
+    torch.manual_seed(seed)
+    torch.set_num_threads(1)
+    if widths is None:
+        model = UNet(n_classes=n_classes, n_channels=n_channels)
+    else:
+        class Narrow(UNet):
+            def __init__(self):
+                torch.nn.Module.__init__(self)
+                w0, w1, w2, w3, w4 = widths
+                self.inc = inconv(n_channels, w0)
+                self.down1, self.down2, self.down3, self.down4 = down(w0, w1), down(w1, w2), down(w2, w3), down(w3, w4)
+                self.up1, self.up2, self.up3, self.up4 = up(w4 + w3, w2), up(w2 + w2, w1), up(w1 + w1, w0), up(w0 + w0, w0)
+                self.outc = outconv(w0, n_classes)
+        model = Narrow()
+    if seeded:
+        model.load_state_dict(seeded_state(model, seed))
+    h, w = hw
+    x = torch.randn(batch, n_channels, h, w)
+    target = torch.rand(batch, n_classes, h, w)
+    blob = {"x": x.numpy(), "target": target.numpy(),
+            "meta/ctor": np.array(repr(sorted(dict(n_classes=n_classes, n_channels=n_channels,
+                                                   widths=tuple(widths or (64, 128, 256, 512, 512))).items()))),
+            "meta/seeded_state": np.array(seed if seeded else -1)}
+    if not seeded:
+        blob.update(_flat("state0", model.state_dict()))
+    model.eval()
+    with torch.no_grad():
+        blob["eval_out/0"] = model(x).numpy()
+    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+    model.train()
+    model.zero_grad()
+    out = model(x)
+    loss = crit(out, target)  # trainer/trainer.py:133: a non-tuple output goes to the criterion as it is
+    loss.backward()
+    blob["train_out/0"] = out.detach().numpy()
+    blob["loss"] = loss.detach().numpy()
+    for k, p in model.named_parameters():
+        g = p.grad.detach()
+        if seeded and g.numel() > 4096:
+            blob["grad_sub/" + k] = g.reshape(-1)[::GRAD_STRIDE].numpy().copy()
+            blob["grad_norm/" + k] = np.array(float(g.double().norm()))
+        else:
+            blob["grad/" + k] = g.numpy().copy()
+    blob.update(_flat("state1_buffers", dict(model.named_buffers())))
+    path = os.path.join(OUT, name + ".npz")
+    np.savez(path, **blob)
+    print("%-28s %8.1f KB  loss=%.6f" % (name, os.path.getsize(path) / 1024, float(loss)))
+
+
 def main():
     sys.path.insert(0, REF)
     sys.dont_write_bytecode = True
@@ -233,6 +292,11 @@ def main():
         run_depth_case("d3_fs8_32x48_b2", 3, dict(in_channels=1, n_classes=4, feature_scale=8), 2, (32, 48), 0)
         run_depth_case("d2_fs4_64x64_b4", 2, dict(in_channels=1, n_classes=4, feature_scale=4), 4, (64, 64), 0)
         if only == "depth":
+            return
+    if only in (None, "plain"):
+        run_plain_unet_case("unet_w8_rgb5_32x48_b2", (8, 16, 32, 64, 64), 5, 3, 2, (32, 48), 0, seeded=False)
+        run_plain_unet_case("unet_ref_rgb5_64x64_b1", None, 5, 3, 1, (64, 64), 3, seeded=True)
+        if only == "plain":
             return
     # configs[0]-sized: the reference-instantiable 4-level net at base width 8
     run_case("c1_fs4_64x64_b4_seed0", dict(in_channels=1, n_classes=4, feature_scale=4),

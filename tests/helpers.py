@@ -26,6 +26,33 @@ DEPTH_CASES = [
 ]
 
 
+# the reference's classic U-Net: a small-width instance built from the reference's own blocks with
+# its full state, and the reference's UNet() itself (13.4 M parameters: the state comes from `seeded_state`, the
+# fixture keeps the seed, outputs, loss, BatchNorm buffers and subsampled gradients)
+PLAIN_CASES = ["unet_w8_rgb5_32x48_b2", "unet_ref_rgb5_64x64_b1"]
+GRAD_STRIDE = 1009  # large gradients are stored as flat[::GRAD_STRIDE]
+
+
+def seeded_state(module, seed):
+    """A deterministic, well-scaled state_dict for `module` (same values for any module with the same keys/shapes):
+    conv weights N(0, 2/fan_in), biases and BatchNorm offsets N(0, 0.1^2), gamma 1 + N(0, 0.1^2), running_var in [1, 1.1)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in module.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            out[k] = torch.zeros_like(v)
+        elif k.endswith("running_var"):
+            out[k] = 1 + 0.1 * torch.rand(v.shape, generator=g)
+        elif v.dim() == 4:
+            fan_in = v.shape[1] * v.shape[2] * v.shape[3]
+            out[k] = torch.randn(v.shape, generator=g) * (2.0 / fan_in) ** 0.5
+        elif k.endswith(".weight"):  # BatchNorm gamma
+            out[k] = 1 + 0.1 * torch.randn(v.shape, generator=g)
+        else:
+            out[k] = 0.1 * torch.randn(v.shape, generator=g)
+    return out
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
     ctor = dict(ast.literal_eval(str(z["meta/ctor"])))
@@ -205,4 +232,29 @@ def install_hip_gates(oracle_model, hip_saved):
     pool = RoutedMaxPool([hip_saved.pairs[(i, 0)].pool_idx.cpu() for i in range(d - 1)])
     oracle_model.maxpool = pool
     gated.append(pool)
+    return gated
+
+
+def install_hip_gates_plain(oracle_model, hip_saved):
+    """The same stand-ins for the classic U-Net oracle (oracle/unet_plain_oracle.py): the ReLUs sit at indices 2 and 5
+    of every double_conv's Sequential, every `down` owns its MaxPool2d (mpconv[0])."""
+    gated = []
+
+    def nchw_mask(t):
+        return (t.permute(0, 3, 1, 2) > 0).cpu()
+
+    enc = [oracle_model.inc.conv, oracle_model.down1.mpconv[1], oracle_model.down2.mpconv[1],
+           oracle_model.down3.mpconv[1], oracle_model.down4.mpconv[1]]
+    dec = [oracle_model.up1.conv, oracle_model.up2.conv, oracle_model.up3.conv, oracle_model.up4.conv]
+    for dc, rec in list(zip(enc, hip_saved.enc)) + list(zip(dec, hip_saved.dec)):
+        scale, shift = rec.bn1[2].double(), rec.bn1[3].double()
+        a1 = (rec.y1.double() * scale + shift).float()  # BN1-apply + ReLU is folded into conv2's load: only the sign
+        for idx, act in ((2, a1), (5, rec.out)):
+            mod = GatedReLU(nchw_mask(act))
+            dc.conv[idx] = mod
+            gated.append(mod)
+    for i, d in enumerate((oracle_model.down1, oracle_model.down2, oracle_model.down3, oracle_model.down4)):
+        pool = RoutedMaxPool([hip_saved.enc[i].pool_idx.cpu()])
+        d.mpconv[0] = pool
+        gated.append(pool)
     return gated

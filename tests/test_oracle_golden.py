@@ -96,3 +96,55 @@ def test_generalised_depth_shapes(depth):
     assert len(outs) == depth - 1
     assert all(o.shape == (1, 4, side, side) for o in outs)
     assert ("up_concat04.up.weight" in model.state_dict()) == (depth == 5)
+
+
+# ---------------------------------------------------------------- classic U-Net
+def _plain_from_golden(name):
+    from oracle.unet_plain_oracle import UNetOracle
+    from tests.helpers import seeded_state
+    z, ctor = load_golden(name)
+    model = UNetOracle(**ctor)
+    seed = int(z["meta/seeded_state"])
+    state = seeded_state(model, seed) if seed >= 0 else sub(z, "state0")
+    assert list(model.state_dict().keys()) == list(state.keys()), "state-dict key order/names differ"
+    model.load_state_dict(state)
+    return z, ctor, model
+
+
+def plain_grads_close(got, z, tol):
+    """got: name -> gradient tensor; z: fixture with full ('grad/') or subsampled ('grad_sub/', 'grad_norm/') gradients."""
+    from tests.helpers import GRAD_STRIDE
+    bad = []
+    for k in [f[len("grad/"):] for f in z.files if f.startswith("grad/")]:
+        if k.endswith(".bias") and ".conv." in k and k.split(".")[-2] in ("0", "3"):
+            continue  # conv bias in front of a BatchNorm: analytically zero gradient (tests/helpers.is_pre_bn_bias)
+        if not rel_err(got[k], z["grad/" + k]) < tol:
+            bad.append((k, rel_err(got[k], z["grad/" + k])))
+    for k in [f[len("grad_sub/"):] for f in z.files if f.startswith("grad_sub/")]:
+        sub_got = got[k].reshape(-1)[::GRAD_STRIDE]
+        scale = float(z["grad_norm/" + k]) / got[k].numel() ** 0.5  # rms of the whole gradient
+        err = float((sub_got.double() - torch.from_numpy(z["grad_sub/" + k]).double()).abs().max()) / scale
+        nrm = abs(float(got[k].double().norm()) - float(z["grad_norm/" + k])) / float(z["grad_norm/" + k])
+        if not (err < 10 * tol and nrm < tol):
+            bad.append((k, err, nrm))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("name", ["unet_w8_rgb5_32x48_b2", "unet_ref_rgb5_64x64_b1"])
+def test_plain_unet_oracle_matches_reference(name):
+    z, ctor, model = _plain_from_golden(name)
+    model.eval()
+    with torch.no_grad():
+        out = model(torch.from_numpy(z["x"]))
+    assert rel_err(out, z["eval_out/0"]) < TOL_FWD
+    model.train()
+    out = model(torch.from_numpy(z["x"]))
+    loss = focal_bce_2d_oracle(out, torch.from_numpy(z["target"]))
+    loss.backward()
+    assert rel_err(out.detach(), z["train_out/0"]) < TOL_FWD
+    assert abs(float(loss) - float(z["loss"])) <= 1e-5 * abs(float(z["loss"]))
+    plain_grads_close({k: p.grad for k, p in model.named_parameters()}, z, TOL_GRAD)
+    bufs = sub(z, "state1_buffers")
+    for k, b in model.named_buffers():
+        if b.dtype.is_floating_point:
+            assert rel_err(b, bufs[k]) < TOL_FWD, k

@@ -10,9 +10,9 @@ All arithmetic of the path runs in the in-tree HIP library (csrc/ -> libunetpp_h
 include/unetpp_hip.h).  There is no CPU or eager-PyTorch fallback: using the model without the
 library, or with CPU tensors, raises.
 """
-from .unet import UNet_Nested, count_param  # noqa: F401
+from .unet import UNet, UNet_Nested, count_param  # noqa: F401
 from .losses import FocalLoss_BCE_2d  # noqa: F401
 from .step import train_step  # noqa: F401
 from .targets import create_heatmap  # noqa: F401
 
-__all__ = ["UNet_Nested", "count_param", "FocalLoss_BCE_2d", "train_step", "create_heatmap"]
+__all__ = ["UNet_Nested", "UNet", "count_param", "FocalLoss_BCE_2d", "train_step", "create_heatmap"]

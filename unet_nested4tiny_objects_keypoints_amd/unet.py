@@ -176,6 +176,103 @@ class UNet_Nested(nn.Module):
         return super().train(mode)
 
 
+class double_conv(nn.Module):
+    """Parameters of models/unet.py:8-25: `conv` = Sequential(conv, BN, ReLU, conv, BN, ReLU) -> children 0,1,3,4."""
+
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.conv = _numbered(ConvParams(in_ch, out_ch, 3), BatchNormParams(out_ch), _Slot(),
+                              ConvParams(out_ch, out_ch, 3), BatchNormParams(out_ch), _Slot())
+        # torch's default initialisation (the reference never re-initialises UNet): BN gamma = 1, conv weights
+        # kaiming-uniform(a = sqrt(5)) = U(+-1/sqrt(fan_in)), like the bias
+        with torch.no_grad():
+            for m in self.conv.children():
+                if isinstance(m, BatchNormParams):
+                    m.weight.fill_(1.0)
+                elif isinstance(m, ConvParams):
+                    bound = 1.0 / math.sqrt(m.in_channels * 9)
+                    m.weight.uniform_(-bound, bound)
+
+
+class inconv(nn.Module):
+    """models/unet.py:28-35"""
+
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.conv = double_conv(in_ch, out_ch)
+
+
+class down(nn.Module):
+    """models/unet.py:38-48: mpconv = Sequential(MaxPool2d(2), double_conv)"""
+
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.mpconv = _numbered(_Slot(), double_conv(in_ch, out_ch))
+
+
+class up(nn.Module):
+    """models/unet.py:51-82, bilinear=True (what UNet builds): `up` has no parameters."""
+
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.up = _Slot()
+        self.conv = double_conv(in_ch, out_ch)
+
+
+class outconv(nn.Module):
+    """models/unet.py:85-92"""
+
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.conv = ConvParams(in_ch, out_ch, 1)
+        with torch.no_grad():
+            bound = 1.0 / math.sqrt(in_ch)
+            self.conv.weight.uniform_(-bound, bound)
+
+
+class UNet(nn.Module):
+    """Drop-in for the reference's classic U-Net (models/unet.py:94-117): same constructor
+    ``UNet(n_classes=5, n_channels=3)``, same ``state_dict`` keys/shapes, ``forward(x) -> sigmoid map [B, n_classes, H, W]``.
+    Parameter holders only; the arithmetic runs in libunetpp_hip.so (engine_unet.py).  ``widths`` generalises the
+    reference's hard-coded (64, 128, 256, 512, 512)."""
+
+    def __init__(self, n_classes=5, n_channels=3, widths=(64, 128, 256, 512, 512)):
+        super().__init__()
+        w0, w1, w2, w3, w4 = widths
+        self.n_classes, self.n_channels, self.widths = n_classes, n_channels, tuple(widths)
+        self.inc = inconv(n_channels, w0)
+        self.down1 = down(w0, w1)
+        self.down2 = down(w1, w2)
+        self.down3 = down(w2, w3)
+        self.down4 = down(w3, w4)
+        self.up1 = up(w4 + w3, w2)
+        self.up2 = up(w2 + w2, w1)
+        self.up3 = up(w1 + w1, w0)
+        self.up4 = up(w0 + w0, w0)
+        self.outc = outconv(w0, n_classes)
+
+    def forward(self, x):
+        from . import engine_unet
+        return engine_unet.run(self, x)
+
+    freeze_weight_images = UNet_Nested.freeze_weight_images
+    invalidate_weight_images = UNet_Nested.invalidate_weight_images
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_weight_images()
+        return out
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate_weight_images()
+        return out
+
+    def train(self, mode: bool = True):
+        self.invalidate_weight_images()
+        return super().train(mode)
+
+
 def count_param(model):
     """models/unet.py:176-180"""
     return sum(p.numel() for p in model.parameters())
