@@ -62,6 +62,12 @@ typedef struct unetpp_view {
 #define UNETPP_GEMM_DIRECT 1 /* flags: direct summation only.  Without it 3x3 launches on the fast path use the
                               * Winograd F(2x2,3x3) form: same fp32 result up to rounding (~1e-7 relative), 2.25x
                               * fewer multiplies.  The flag must be the same when the weight image is packed. */
+#define UNETPP_GEMM_BF16 2   /* flags (GEMM and weight-gradient descriptors): bf16 STORAGE -- every activation pointer of
+                              * the descriptor (view ptr and gate) addresses bf16 NHWC data although it is typed
+                              * float*; C, c_off, c_len count bf16 channels and must be multiples of 8.  bias, scale,
+                              * shift, stats_partial and slabs stay fp32; the arithmetic is v_mfma_f32_32x32x16_bf16
+                              * with fp32 accumulation (BASELINE configs[3]/[4]).  There is no generic bf16 kernel:
+                              * a descriptor the MFMA kernels cannot take returns UNETPP_EINVAL. */
 typedef struct unetpp_gemm_desc {
   int32_t N, H, W;
   int32_t taps;

@@ -7,6 +7,7 @@
 //             stores whole 128-byte pixel rows; fused bias, ReLU, BatchNorm partial sums
 //   wgrad   : thread = (pixel stripe, 4 output channels) keeps 9*Cin float4 accumulators in registers over a
 //             grid-stride loop of patches; fixed-order LDS reduction; one slab per workgroup (wgrad_finish sums them)
+#include "bf16_common.h"
 #include "common.h"
 
 namespace unetpp {
@@ -40,7 +41,8 @@ __device__ __forceinline__ void stage_patch(const SmallArgs& a, float* xs, int n
   }
 }
 
-template <int CIN>
+// BF: the output (forward) / the output gradient (wgrad) is bf16 storage (UNETPP_GEMM_BF16); the input stays fp32
+template <int CIN, bool BF = false>
 __global__ __launch_bounds__(kThreads) void small_cin_fwd_kernel(const SmallArgs a) {
   __shared__ float xs[kMaxHaloPixels * CIN];
   __shared__ __attribute__((aligned(16))) float ws[9 * CIN * kMaxCout];
@@ -82,12 +84,20 @@ __global__ __launch_bounds__(kThreads) void small_cin_fwd_kernel(const SmallArgs
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
       }
+      if (BF) {  // the statistics describe the stored (rounded) tensor
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = bf_round(acc[e]);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         s1[e] += acc[e];
         s2[e] += acc[e] * acc[e];
       }
-      *reinterpret_cast<f32x4*>(a.y + ((static_cast<long>(n) * a.H + y) * a.W + x) * a.yC + 4 * quad) = acc;
+      const long o = ((static_cast<long>(n) * a.H + y) * a.W + x) * a.yC + 4 * quad;
+      if (BF)
+        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(a.y) + o) = u32x2{pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])};
+      else
+        *reinterpret_cast<f32x4*>(a.y + o) = acc;
     }
   }
   if (a.stats != nullptr) {
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(kThreads) void small_cin_fwd_kernel(const SmallArgs
   }
 }
 
-template <int CIN>
+template <int CIN, bool BF = false>
 __global__ __launch_bounds__(kThreads) void small_cin_wgrad_kernel(const SmallArgs a) {
   __shared__ float xs[kMaxHaloPixels * CIN];
   __shared__ float red[kThreads][4];
@@ -137,8 +147,14 @@ __global__ __launch_bounds__(kThreads) void small_cin_wgrad_kernel(const SmallAr
       const int py = p >> a.log2tw, px = p & (TW - 1);
       const int y = ty0 + py, x = tx0 + px;
       if (y < a.H && x < a.W) {
-        const f32x4 g =
-            *reinterpret_cast<const f32x4*>(a.dy + ((static_cast<long>(n) * a.H + y) * a.W + x) * a.yC + 4 * quad);
+        const long o = ((static_cast<long>(n) * a.H + y) * a.W + x) * a.yC + 4 * quad;
+        f32x4 g;
+        if (BF) {
+          const u32x2 u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(a.dy) + o);
+          g = f32x4{bf_lo(u[0]), bf_hi(u[0]), bf_lo(u[1]), bf_hi(u[1])};
+        } else {
+          g = *reinterpret_cast<const f32x4*>(a.dy + o);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) db[e] += g[e];
 #pragma unroll
@@ -208,21 +224,30 @@ int launch_small_cin_fwd(const unetpp_gemm_desc* d, hipStream_t st) {
   SmallArgs a = {};
   fill_geom(a, d->N, d->H, d->W);
   if (a.n_patches > 0x7fffffffL) return 1;
+  const bool bf = (d->flags & UNETPP_GEMM_BF16) != 0;
+  if (d->weight == nullptr) return 1;
   a.x = X.ptr;
   a.w = d->weight;
   a.bias = d->bias;
-  a.y = Y.ptr + Y.c_off;
+  a.y = bf ? reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(Y.ptr) + Y.c_off) : Y.ptr + Y.c_off;
   a.stats = d->stats_partial;
   a.COUT = Y.c_len;
   a.yC = Y.C;
   a.relu = Y.relu;
   const dim3 grid(static_cast<unsigned>(a.n_patches)), block(kThreads);
-  switch (X.C) {
-    case 1: hipLaunchKernelGGL(small_cin_fwd_kernel<1>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(small_cin_fwd_kernel<2>, grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL(small_cin_fwd_kernel<3>, grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL(small_cin_fwd_kernel<4>, grid, block, 0, st, a); break;
+#define UNETPP_SMALL_FWD(B)                                                                          \
+  switch (X.C) {                                                                                     \
+    case 1: hipLaunchKernelGGL((small_cin_fwd_kernel<1, B>), grid, block, 0, st, a); break;          \
+    case 2: hipLaunchKernelGGL((small_cin_fwd_kernel<2, B>), grid, block, 0, st, a); break;          \
+    case 3: hipLaunchKernelGGL((small_cin_fwd_kernel<3, B>), grid, block, 0, st, a); break;          \
+    default: hipLaunchKernelGGL((small_cin_fwd_kernel<4, B>), grid, block, 0, st, a); break;         \
   }
+  if (bf) {
+    UNETPP_SMALL_FWD(true)
+  } else {
+    UNETPP_SMALL_FWD(false)
+  }
+#undef UNETPP_SMALL_FWD
   note_kernel("small_cin_fwd_kernel");
   return launch_status();
 }
@@ -236,18 +261,26 @@ int launch_small_cin_wgrad(const unetpp_wgrad_desc* d, hipStream_t st) {
   SmallArgs a = {};
   fill_geom(a, d->N, d->H, d->W);
   if (d->n_split < 1 || d->n_split > a.n_patches) return 1;
+  const bool bf = (d->flags & UNETPP_GEMM_BF16) != 0;
   a.x = X.ptr;
-  a.dy = DY.ptr + DY.c_off;
+  a.dy = bf ? reinterpret_cast<const float*>(reinterpret_cast<const bf16_t*>(DY.ptr) + DY.c_off) : DY.ptr + DY.c_off;
   a.slabs = d->slabs;
   a.COUT = DY.c_len;
   a.yC = DY.C;
   const dim3 grid(static_cast<unsigned>(d->n_split)), block(kThreads);
-  switch (X.C) {
-    case 1: hipLaunchKernelGGL(small_cin_wgrad_kernel<1>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(small_cin_wgrad_kernel<2>, grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL(small_cin_wgrad_kernel<3>, grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL(small_cin_wgrad_kernel<4>, grid, block, 0, st, a); break;
+#define UNETPP_SMALL_WGRAD(B)                                                                        \
+  switch (X.C) {                                                                                     \
+    case 1: hipLaunchKernelGGL((small_cin_wgrad_kernel<1, B>), grid, block, 0, st, a); break;        \
+    case 2: hipLaunchKernelGGL((small_cin_wgrad_kernel<2, B>), grid, block, 0, st, a); break;        \
+    case 3: hipLaunchKernelGGL((small_cin_wgrad_kernel<3, B>), grid, block, 0, st, a); break;        \
+    default: hipLaunchKernelGGL((small_cin_wgrad_kernel<4, B>), grid, block, 0, st, a); break;       \
   }
+  if (bf) {
+    UNETPP_SMALL_WGRAD(true)
+  } else {
+    UNETPP_SMALL_WGRAD(false)
+  }
+#undef UNETPP_SMALL_WGRAD
   note_kernel("small_cin_wgrad_kernel");
   return launch_status();
 }

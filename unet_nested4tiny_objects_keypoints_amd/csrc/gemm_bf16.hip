@@ -1,0 +1,373 @@
+// bf16-storage twin of the multi-view pixel GEMM (forward and input gradient of the 3x3 convolutions, the pointwise
+// GEMMs of the 2x2 transposed convolution) for BASELINE configs[3]/[4]: activations in HBM are bf16 NHWC, the GEMM
+// runs as a direct implicit GEMM on v_mfma_f32_32x32x16_bf16 with fp32 accumulators (no Winograd: its transforms
+// need more than 8 mantissa bits), bias / BatchNorm coefficients / BatchNorm partial sums stay fp32.
+//
+// Same skeleton as gemm_fast.hip (persistent workgroups over (256-pixel patch, 32*NT-column) units, K in chunks, the
+// next chunk's global loads issued into registers before the MFMA loop of the current one and written to LDS after
+// it, LDS weight image per (column tile, chunk) packed once per pass) with the bf16 geometry:
+//   * K chunk = 32 channels = 64 bytes per pixel: a 16-byte staging item carries 8 channels, four items per pixel,
+//     LDS pixel stride 80 bytes (conflict-free ds_read_b128, every tap's address = lane base + immediate);
+//   * MFMA operands: lane (j = lane & 31, h = lane >> 5) holds A[pixel j][k = 8h..8h+7] and B[k = 8h..8h+7][column j],
+//     i.e. ONE 16-byte LDS read per operand and MFMA (32x32x16: 16 K per instruction, 32 cycles);
+//   * weight image [tap][g 2][column 32][h 2][8 bf16]: the 64 lanes of a B read cover 1 KB contiguously;
+//   * the BatchNorm-apply + ReLU load transform runs in fp32 between the global load and the LDS store and is
+//     rounded to bf16 there (the MFMA takes bf16 operands); zero padding is applied after it;
+//   * epilogue: bias, ReLU, rounding to bf16, BatchNorm partial sums OF THE ROUNDED VALUES (the statistics describe
+//     the tensor that is stored), ReLU gate / accumulate / gate-of-the-sum read-modify-write in fp32; the accumulator
+//     tile is transposed through LDS so that a lane stores 8 consecutive channels (16 bytes) of one pixel.
+#include "bf16_common.h"
+#include "common.h"
+#include "gemm_units.h"
+
+namespace unetpp {
+namespace {
+
+constexpr int BKC = 32;        // channels per K chunk
+constexpr int BPIX = 80;       // LDS bytes per staged pixel (64 + 16 pad)
+constexpr int BSTEP = 1024;    // bytes of one (tap, g) weight step: 32 columns x 16 k x 2 B
+
+template <int TAPS, int LOG2TW, int NT>
+__global__ __launch_bounds__(kThreads, 3) void gemm_bf16_kernel(const FastArgs a) {
+  constexpr int HALO = (TAPS == 9) ? 1 : 0;
+  constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;
+  constexpr int HWp = TW + 2 * HALO, HHp = TH + 2 * HALO;
+  constexpr int NPIX = HWp * HHp;
+  constexpr int MAXPIX = (TAPS == 9) ? kMaxHaloPixels : kBlockPixels;
+  constexpr int IN_BYTES = MAXPIX * BPIX;  // 27200 / 20480: also >= the 4 x 4 KB transpose scratch of the epilogue
+  constexpr int IMG = TAPS * 2 * BSTEP;    // bytes of one (column tile, chunk) image
+  constexpr int IN_ITEMS = (NPIX * 4 + kThreads - 1) / kThreads;
+  constexpr int W_ITEMS = (NT * IMG / 16 + kThreads - 1) / kThreads;
+  static_assert(IN_BYTES >= 4 * 4096, "epilogue scratch does not fit");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[IN_BYTES + NT * IMG];
+  unsigned char* in_tile = smem;
+  unsigned char* w_tile = smem + IN_BYTES;
+
+  const unetpp_gemm_desc& d = a.d;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+
+  const UnitRange ur = my_unit_range(a.total_blocks);
+  const long first_unit = ur.first, unit_step = ur.step, my_units = ur.count;
+  if (my_units == 0) return;
+
+  int apix[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int p = 64 * wave + 32 * mt + j;
+    apix[mt] = ((p >> LOG2TW) * HWp + (p & (TW - 1))) * BPIX + h * 16;
+  }
+  const int wb = (j * 2 + h) * 16;
+
+  f32x16 acc[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][mt][r] = 0.f;
+
+  // ---- prefetch side ----
+  u32x4 reg_in[IN_ITEMS], reg_w[W_ITEMS];
+  unsigned voff[IN_ITEMS];  // bf16 element offsets (< 2^31, fast_args)
+  unsigned in_mask = 0;
+  int pf_cnt = 0;
+  long p_unit = 0;
+  int p_s = 0, p_c0 = 0, p_chunk = 0;
+  int p_n = 0, p_ty0 = 0, p_tx0 = 0;
+  const unsigned char* p_wimg = nullptr;
+  const unsigned char* wimg_base = reinterpret_cast<const unsigned char*>(d.weight_image);
+
+  auto prefetch_unit = [&](long k) {
+    const UnitGeom g = decode_unit<LOG2TW>(a, first_unit + k * unit_step);
+    p_n = g.n;
+    p_ty0 = g.ty0;
+    p_tx0 = g.tx0;
+    p_wimg = wimg_base + static_cast<long>(g.group) * NT * a.n_chunks * IMG;
+    in_mask = 0;
+#pragma unroll
+    for (int q = 0; q < IN_ITEMS; ++q) {
+      const int it = tid + q * kThreads;
+      const int hp = it >> 2;
+      const int hy = hp / HWp, hx = hp - hy * HWp;
+      const int y = p_ty0 + hy - HALO, x = p_tx0 + hx - HALO;
+      if ((it < NPIX * 4) && y >= 0 && y < d.H && x >= 0 && x < d.W) in_mask |= 1u << q;
+    }
+  };
+  auto view_offsets = [&](const unetpp_view& V) {  // clamped: every item loads from a valid address
+#pragma unroll
+    for (int q = 0; q < IN_ITEMS; ++q) {
+      const int hp = min((tid + q * kThreads) >> 2, NPIX - 1);
+      const int hy = hp / HWp, hx = hp - hy * HWp;
+      const int yy = min(max(p_ty0 + hy - HALO, 0), d.H - 1), xx = min(max(p_tx0 + hx - HALO, 0), d.W - 1);
+      voff[q] = static_cast<unsigned>(view_pixel_offset(V, p_n, yy, xx));
+    }
+  };
+  auto load_chunk = [&]() {
+    const unetpp_view& V = d.in[p_s];
+    const bf16_t* vp = reinterpret_cast<const bf16_t*>(V.ptr);
+    pf_cnt = min(BKC, V.c_len - p_c0);
+#pragma unroll
+    for (int q = 0; q < IN_ITEMS; ++q) {
+      const int cc = ((tid + q * kThreads) & 3) << 3;
+      const unsigned off = voff[q] + static_cast<unsigned>(p_c0 + (cc < pf_cnt ? cc : 0));
+      reg_in[q] = *reinterpret_cast<const u32x4*>(vp + off);
+    }
+    const unsigned char* wp = p_wimg + static_cast<long>(p_chunk) * IMG;
+#pragma unroll
+    for (int q = 0; q < W_ITEMS; ++q) {
+      const unsigned it = min(tid + q * kThreads, NT * IMG / 16 - 1);
+      const unsigned t = it / (IMG / 16), r = it - t * (IMG / 16);
+      reg_w[q] = *reinterpret_cast<const u32x4*>(wp + static_cast<long>(t) * a.n_chunks * IMG + r * 16u);
+    }
+  };
+  auto store_chunk = [&]() {
+    const unetpp_view& V = d.in[p_s];
+    const bool affine = V.scale != nullptr;
+    const int cq = (tid & 3) << 3;  // all items of a thread share one channel octet
+    float sc[8], sh[8];
+    if (affine) {
+      const int ch = p_c0 + (cq < pf_cnt ? cq : 0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sc[e] = V.scale[ch + e];
+        sh[e] = V.shift[ch + e];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < IN_ITEMS; ++q) {
+      const int it = tid + q * kThreads;
+      const int hp = it >> 2, q4 = it & 3;
+      const bool keep = ((in_mask >> q) & 1u) && (q4 << 3) < pf_cnt;
+      u32x4 v = reg_in[q];
+      if (affine || V.relu) {  // fp32 transform, rounded back to bf16 for the MFMA
+        float f[8];
+        unpack8(v, f);
+        if (affine) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
+        }
+        if (V.relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+        }
+        v = pack8(f);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0u;  // zero padding AFTER the transform
+      if (it < NPIX * 4) *reinterpret_cast<u32x4*>(&in_tile[hp * BPIX + (q4 << 4)]) = v;
+    }
+#pragma unroll
+    for (int q = 0; q < W_ITEMS; ++q) {
+      const int it = tid + q * kThreads;
+      if (it < NT * IMG / 16) *reinterpret_cast<u32x4*>(&w_tile[it * 16]) = reg_w[q];
+    }
+  };
+  struct Frag {
+    u32x4 b[NT], a0, a1;
+  };
+  auto read_frag = [&](int step) {  // step = tap * 2 + g: the 16 channels [16g, 16g + 16) of the chunk at one tap
+    const int tap = step >> 1, g = step & 1;
+    const int tpix = (TAPS == 9) ? ((tap / 3) * HWp + (tap % 3)) * BPIX : 0;
+    Frag f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) f.b[t] = *reinterpret_cast<const u32x4*>(&w_tile[t * IMG + step * BSTEP + wb]);
+    f.a0 = *reinterpret_cast<const u32x4*>(&in_tile[apix[0] + tpix + g * 32]);
+    f.a1 = *reinterpret_cast<const u32x4*>(&in_tile[apix[1] + tpix + g * 32]);
+    return f;
+  };
+
+  // Accumulator register r of lane (j, h): pixel 64*wave + 32*mt + 4h + c(r), c(r) = (r&3) + 8*(r>>2), column j.
+  auto epilogue = [&](long k) {
+    const UnitGeom g = decode_unit<LOG2TW>(a, first_unit + k * unit_step);
+    const bool interior = (g.ty0 + TH <= d.H) && (g.tx0 + TW <= d.W);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const TileCols tc = decode_tile(a, g.group * NT + t);
+      const unetpp_view& O = d.out[tc.ov];
+      bf16_t* optr = reinterpret_cast<bf16_t*>(O.ptr);
+      const bf16_t* gptr = reinterpret_cast<const bf16_t*>(O.gate);
+      const bool col_ok = j < tc.n_cnt;
+      const float bj = (d.bias != nullptr && col_ok) ? d.bias[tc.n0 + j] : 0.f;
+      const long row_stride = static_cast<long>(O.sy) * O.Ws * O.C, col_stride = static_cast<long>(O.sx) * O.C;
+      const long tile_base = view_pixel_offset(O, g.n, g.ty0, g.tx0) + tc.nt * 32;  // column 0 of the tile
+      float s1 = 0.f, s2sum = 0.f;
+      float* scratch = reinterpret_cast<float*>(in_tile) + wave * 1024;  // [32 pixels][32 columns] fp32
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int prow = (64 * wave + 32 * mt) >> LOG2TW;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2);
+          const int dy = c >> LOG2TW, dx = c & (TW - 1);
+          float v = acc[t][mt][r] + bj;
+          if (O.relu) v = fmaxf(v, 0.f);
+          v = bf_round(v);
+          const bool ok = col_ok && (interior || ((g.ty0 + prow + dy < d.H) && (g.tx0 + 4 * h + dx < d.W)));
+          if (ok) {
+            s1 += v;
+            s2sum = fmaf(v, v, s2sum);
+          }
+          scratch[(c + 4 * h) * 32 + (j ^ ((c & 3) << 3))] = v;  // column XOR by pixel: conflict-free 32-byte reads below
+          acc[t][mt][r] = 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const int pi = (lane >> 2) + 16 * pass, q8 = (lane & 3) << 3;  // pixel inside the MFMA tile, first column
+          const int p = 64 * wave + 32 * mt + pi;
+          const int py = p >> LOG2TW, px = p & (TW - 1);
+          const int sw = ((pi & 3) << 3);
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(&scratch[pi * 32 + (q8 ^ sw)]);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(&scratch[pi * 32 + ((q8 ^ sw) + 4)]);
+          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          if (q8 < tc.n_cnt && (interior || ((g.ty0 + py < d.H) && (g.tx0 + px < d.W)))) {
+            const long off = tile_base + py * row_stride + px * col_stride + q8;
+            float gt[8];
+            if (gptr != nullptr) unpack8(*reinterpret_cast<const u32x4*>(gptr + off), gt);
+            if (gptr != nullptr && !O.gate_sum) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (gt[e] > 0.f) ? v[e] : 0.f;
+            }
+            if (O.accumulate) {
+              float old[8];
+              unpack8(*reinterpret_cast<const u32x4*>(optr + off), old);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += old[e];
+            }
+            if (gptr != nullptr && O.gate_sum) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (gt[e] > 0.f) ? v[e] : 0.f;
+            }
+            *reinterpret_cast<u32x4*>(optr + off) = pack8(v);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (d.stats_partial != nullptr) {
+        s1 += __shfl_xor(s1, 32);
+        s2sum += __shfl_xor(s2sum, 32);
+        float* wsc = reinterpret_cast<float*>(w_tile);  // weight tile as scratch (the input tile is transpose scratch)
+        if (h == 0) {
+          wsc[(wave * 32 + j) * 2 + 0] = s1;
+          wsc[(wave * 32 + j) * 2 + 1] = s2sum;
+        }
+        __syncthreads();
+        if (tid < tc.n_cnt) {
+          float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            t1 += wsc[(w * 32 + tid) * 2 + 0];
+            t2 += wsc[(w * 32 + tid) * 2 + 1];
+          }
+          float* dst = d.stats_partial + (g.patch * a.Ncols + tc.n0 + tid) * 2;
+          dst[0] = t1;
+          dst[1] = t2;
+        }
+        __syncthreads();
+      }
+    }
+  };
+
+  prefetch_unit(0);
+  view_offsets(d.in[0]);
+  load_chunk();
+  store_chunk();
+  __syncthreads();
+
+  long c_unit = 0;
+  int c_chunk = 0;
+  while (true) {
+    bool more = true;
+    {
+      int s2 = p_s, c2 = p_c0 + BKC;
+      if (c2 >= d.in[p_s].c_len) {
+        ++s2;
+        c2 = 0;
+      }
+      if (p_chunk + 1 < a.n_chunks) {
+        ++p_chunk;
+        if (s2 != p_s) {
+          p_s = s2;
+          view_offsets(d.in[p_s]);
+        }
+        p_c0 = c2;
+      } else if (p_unit + 1 < my_units) {
+        ++p_unit;
+        p_chunk = 0;
+        p_s = 0;
+        p_c0 = 0;
+        prefetch_unit(p_unit);
+        view_offsets(d.in[0]);
+      } else {
+        more = false;
+      }
+    }
+    load_chunk();  // unconditional (the cursor stays on the last chunk)
+    Frag cur = read_frag(0);
+#pragma unroll
+    for (int step = 0; step < TAPS * 2; ++step) {
+      Frag nxt = cur;
+      if (step + 1 < TAPS * 2) nxt = read_frag(step + 1);
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+        acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.a0),
+                                                             __builtin_bit_cast(bf16x8, cur.b[ct]), acc[ct][0], 0, 0, 0);
+        acc[ct][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.a1),
+                                                             __builtin_bit_cast(bf16x8, cur.b[ct]), acc[ct][1], 0, 0, 0);
+      }
+      cur = nxt;
+    }
+    __syncthreads();
+    if (c_chunk + 1 == a.n_chunks) {
+      epilogue(c_unit);
+      __syncthreads();
+      ++c_unit;
+      c_chunk = 0;
+    } else {
+      ++c_chunk;
+    }
+    if (!more) break;
+    store_chunk();
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+bool bf16_gemm_args(const unetpp_gemm_desc* d, FastArgs& a) {
+  if (d == nullptr || (d->flags & UNETPP_GEMM_BF16) == 0) return false;
+  if (!fast_args(d, a, BKC, 32)) return false;
+  for (int i = 0; i < d->n_in; ++i)
+    if (!bf16_view_aligned(d->in[i])) return false;
+  for (int i = 0; i < d->n_out; ++i)
+    if (!bf16_view_aligned(d->out[i])) return false;
+  return true;
+}
+
+int launch_gemm_bf16(const unetpp_gemm_desc* d, hipStream_t st) {
+  FastArgs a;
+  if (!bf16_gemm_args(d, a) || d->weight_image == nullptr) return UNETPP_EINVAL;
+  if (d->stats_partial != nullptr && d->n_out != 1) return UNETPP_EINVAL;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return UNETPP_ELAUNCH;
+  long workers = (3L * cus) & ~7L;
+  if (workers < 8) workers = 8;
+  const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(kThreads);
+#define UNETPP_LAUNCH_BF16(T, NTU)                                                                      \
+  do {                                                                                                  \
+    if (a.log2tw == 5) hipLaunchKernelGGL((gemm_bf16_kernel<T, 5, NTU>), grid, block, 0, st, a);        \
+    else if (a.log2tw == 4) hipLaunchKernelGGL((gemm_bf16_kernel<T, 4, NTU>), grid, block, 0, st, a);   \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<T, 3, NTU>), grid, block, 0, st, a);                      \
+  } while (0)
+  if (d->taps == 9) UNETPP_LAUNCH_BF16(9, 1);
+  else if (a.nt_unit == 2) UNETPP_LAUNCH_BF16(1, 2);
+  else UNETPP_LAUNCH_BF16(1, 1);
+#undef UNETPP_LAUNCH_BF16
+  note_kernel(d->taps == 9 ? "gemm_bf16_kernel<9>" : "gemm_bf16_kernel<1>");
+  return launch_status();
+}
+
+}  // namespace unetpp

@@ -206,6 +206,11 @@ extern "C" int unetpp_gemm_fwd(const unetpp_gemm_desc* d, void* stream) {
   if (d->n_in < 1 || d->n_in > UNETPP_MAX_VIEWS || d->n_out < 1 || d->n_out > UNETPP_MAX_VIEWS) return UNETPP_EINVAL;
   if (d->weight == nullptr && d->weight_image == nullptr) return UNETPP_EINVAL;
   if (d->stats_partial != nullptr && d->n_out != 1) return UNETPP_EINVAL;
+  if (d->flags & UNETPP_GEMM_BF16) {  // bf16 storage: the MFMA kernel, or the VALU first layer (fp32 input, bf16 output)
+    if (d->weight_image != nullptr) return launch_gemm_bf16(d, static_cast<hipStream_t>(stream));
+    const int small = launch_small_cin_fwd(d, static_cast<hipStream_t>(stream));
+    return small == 1 ? UNETPP_EINVAL : small;  // no generic bf16 kernel: unaligned views are refused
+  }
   if (d->weight_image != nullptr)  // the image was packed for the algorithm the same descriptor selects
     return wino_applies(d) ? launch_gemm_wino(d, static_cast<hipStream_t>(stream))
                            : launch_gemm_fast(d, static_cast<hipStream_t>(stream));

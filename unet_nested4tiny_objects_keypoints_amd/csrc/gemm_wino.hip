@@ -558,7 +558,7 @@ extern "C" int unetpp_debug_wino_stamps(unsigned long long* out16, int reset) { 
 #endif
 
 bool wino_applies(const unetpp_gemm_desc* d) {
-  return d != nullptr && d->taps == 9 && (d->flags & UNETPP_GEMM_DIRECT) == 0;
+  return d != nullptr && d->taps == 9 && (d->flags & (UNETPP_GEMM_DIRECT | UNETPP_GEMM_BF16)) == 0;
 }
 
 int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {

@@ -10,13 +10,14 @@
 // with N = 4 phases x co, input gradient with K = 4 phases x co) parameters -- no intermediate re-layout launch.
 // unetpp_gemm_pack_weight_images builds the images of many launches (a whole forward or backward pass) in ONE launch
 // from a table of jobs in device memory.
+#include "bf16_common.h"
 #include "common.h"
 #include "gemm_units.h"
 
 namespace unetpp {
 namespace {
 
-constexpr int kKindFast = 0, kKindWino = 1;
+constexpr int kKindFast = 0, kKindWino = 1, kKindBf16 = 2;  // bf16: gemm_bf16.hip, [tap][g 2][col 32][h 2][8 bf16], 32-channel chunks
 
 struct PackGeom {  // what the image layout depends on: the channel structure of the launch
   int kind, taps, kc, ncol;  // kc = channels per K chunk, ncol = columns per tile
@@ -53,6 +54,13 @@ __device__ __forceinline__ float image_element(const PackGeom& g, const unetpp_w
     kk = 2 * gq + s;
     cin_local = 16 * nh + col;
     r = i >> 12;
+  } else if (g.kind == kKindBf16) {  // i counts bf16 elements: [tap][g 2][col 32][h 2][8]
+    const int e = i & 7, hs = (i >> 3) & 1, j = (i >> 4) & 31, gq = (i >> 9) & 1;
+    r = i >> 10;
+    tap = static_cast<int>(r % g.taps);
+    r /= g.taps;
+    kk = 16 * gq + 8 * hs + e;
+    cin_local = j;
   } else {  // [tap][g 2][col 32][half' 2][4], half' = half ^ ((col>>3)&1)
     const int e = i & 3, hs = (i >> 2) & 1, j = (i >> 3) & 31, gq = (i >> 8) & 1;
     r = i >> 9;
@@ -93,9 +101,15 @@ __device__ __forceinline__ float image_element(const PackGeom& g, const unetpp_w
   return rb == 0 ? t[0] : (rb == 1 ? 0.5f * (t[0] + t[1] + t[2]) : (rb == 2 ? 0.5f * (t[0] - t[1] + t[2]) : t[2]));
 }
 
+// slot i of the image: one float, or two bf16 (elements 2i, 2i+1) in the same 4 bytes
+__device__ __forceinline__ float image_slot(const PackGeom& g, const unetpp_weight_src& w, long i) {
+  if (g.kind != kKindBf16) return image_element(g, w, i);
+  return __uint_as_float(pack_bf2(image_element(g, w, 2 * i), image_element(g, w, 2 * i + 1)));
+}
+
 __global__ void pack_image_one_kernel(const PackGeom g, const unetpp_weight_src w, float* __restrict__ img) {
   const long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x;
-  if (i < g.floats) img[i] = image_element(g, w, i);
+  if (i < g.floats) img[i] = image_slot(g, w, i);
 }
 
 // blockIdx.y = job; every job derives its geometry from its own channel lists
@@ -103,10 +117,11 @@ __global__ void pack_image_jobs_kernel(const unetpp_pack_job* __restrict__ jobs)
   const unetpp_pack_job& j = jobs[blockIdx.y];
   __shared__ PackGeom g;
   if (threadIdx.x == 0) {
-    const bool wino = j.taps == 9 && (j.flags & UNETPP_GEMM_DIRECT) == 0;
-    g.kind = wino ? kKindWino : kKindFast;
+    const bool bf = (j.flags & UNETPP_GEMM_BF16) != 0;
+    const bool wino = !bf && j.taps == 9 && (j.flags & UNETPP_GEMM_DIRECT) == 0;
+    g.kind = bf ? kKindBf16 : (wino ? kKindWino : kKindFast);
     g.taps = j.taps;
-    g.kc = wino ? 8 : 16;
+    g.kc = bf ? 32 : (wino ? 8 : 16);
     g.ncol = 32;
     g.n_in = j.n_in;
     g.n_out = j.n_out;
@@ -119,16 +134,17 @@ __global__ void pack_image_jobs_kernel(const unetpp_pack_job* __restrict__ jobs)
   __syncthreads();
   for (long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x; i < g.floats;
        i += static_cast<long>(gridDim.x) * blockDim.x)
-    j.image[i] = image_element(g, j.src, i);
+    j.image[i] = image_slot(g, j.src, i);
 }
 
 bool geom_of(const unetpp_gemm_desc* d, PackGeom& g) {
   FastArgs a;
+  const bool bf = d != nullptr && (d->flags & UNETPP_GEMM_BF16) != 0;
   const bool wino = wino_applies(d);
-  if (!fast_args(d, a, wino ? 8 : 16, 32)) return false;
-  g.kind = wino ? kKindWino : kKindFast;
+  if (bf ? !bf16_gemm_args(d, a) : !fast_args(d, a, wino ? 8 : 16, 32)) return false;
+  g.kind = bf ? kKindBf16 : (wino ? kKindWino : kKindFast);
   g.taps = d->taps;
-  g.kc = wino ? 8 : 16;
+  g.kc = bf ? 32 : (wino ? 8 : 16);
   g.ncol = 32;
   g.n_in = d->n_in;
   g.n_out = d->n_out;

@@ -248,6 +248,7 @@ extern "C" int32_t unetpp_wgrad_slab_planes(const unetpp_wgrad_desc* d) {
   if (d == nullptr) return 0;
   // the 1..4-channel first layer keeps its own kernel (tap slabs) whatever the flags say
   const bool small = d->taps == 9 && d->n_x == 1 && d->x[0].c_len <= 4;
+  if (d->flags & UNETPP_GEMM_BF16) return d->taps;  // bf16 storage: direct summation only
   return (!small && wgrad_wino_applies(d)) ? 16 : d->taps;
 }
 
@@ -284,6 +285,7 @@ extern "C" int unetpp_wgrad(const unetpp_wgrad_desc* d, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int small = launch_small_cin_wgrad(d, st);  // 1..4-channel first layer
   if (small != 1) return small;
+  if (d->flags & UNETPP_GEMM_BF16) return launch_wgrad_bf16(d, a.Ktot, a.Ncols, a.n_tiles_cols, k_tiles, st);
   {
     const int wino = launch_wgrad_wino(d, a.Ktot, a.Ncols, a.n_tiles_cols, k_tiles, st);  // 16-plane slabs
     if (wino != 1) return wino;

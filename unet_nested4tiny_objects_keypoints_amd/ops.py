@@ -105,9 +105,25 @@ def _need(t: torch.Tensor, what: str, dtype=torch.float32):
     return t
 
 
+_ACT_DTYPES = (torch.float32, torch.bfloat16)  # storage types of activations (bf16: UNETPP_GEMM_BF16 launches)
+
+
+def _storage_flag(outs, ins):
+    """UNETPP_GEMM_BF16 when the launch's activations are bf16.  All views of a launch share the storage type, except
+    that the 1..4-channel network input of the first convolution stays fp32."""
+    bf = outs[0].t.dtype == torch.bfloat16
+    for v in outs:
+        if (v.t.dtype == torch.bfloat16) != bf:
+            raise TypeError("mixed fp32 / bf16 output views in one launch")
+    for v in ins:
+        if (v.t.dtype == torch.bfloat16) != bf and not (bf and len(ins) == 1 and v.t.shape[3] <= 4):
+            raise TypeError("mixed fp32 / bf16 views in one launch")
+    return _lib.GEMM_BF16 if bf else 0
+
+
 @dataclass
 class V:
-    """A channel slice of an NHWC tensor, optionally on a strided pixel grid (struct unetpp_view)."""
+    """A channel slice of an NHWC tensor (fp32 or bf16 storage), optionally on a strided pixel grid (struct unetpp_view)."""
     t: torch.Tensor
     c_off: int = 0
     c_len: Optional[int] = None
@@ -123,7 +139,7 @@ class V:
     gate_sum: bool = False
 
     def fill(self, dst: View) -> int:
-        t = _need(self.t, "view tensor")
+        t = _need(self.t, "view tensor", self.t.dtype if self.t.dtype in _ACT_DTYPES else torch.float32)
         if t.dim() != 4:
             raise ValueError("view tensor must be NHWC [N,H,W,C]")
         c = t.shape[3]
@@ -135,7 +151,7 @@ class V:
         dst.scale = None if self.scale is None else _need(self.scale, "scale").data_ptr()
         dst.shift = None if self.shift is None else _need(self.shift, "shift").data_ptr()
         if self.gate is not None:
-            g = _need(self.gate, "gate")
+            g = _need(self.gate, "gate", t.dtype)
             if g.shape != t.shape:
                 raise ValueError("gate must have the geometry of the gated tensor")
             dst.gate = g.data_ptr()
@@ -292,7 +308,7 @@ def gemm_fwd(n: int, h: int, w: int, taps: int, ins: Sequence[V], outs: Sequence
         raise ValueError("too many views")
     d = GemmDesc()
     d.N, d.H, d.W, d.taps = n, h, w, taps
-    d.flags = _lib.GEMM_DIRECT if (direct or not USE_WINOGRAD) else 0
+    d.flags = (_lib.GEMM_DIRECT if (direct or not USE_WINOGRAD) else 0) | _storage_flag(outs, ins)
     d.n_in, d.n_out = len(ins), len(outs)
     k = sum(v.fill(d.inp[i]) for i, v in enumerate(ins))
     nc = sum(v.fill(d.out[i]) for i, v in enumerate(outs))
@@ -338,7 +354,7 @@ def gemm_fwd(n: int, h: int, w: int, taps: int, ins: Sequence[V], outs: Sequence
     acc = sum(v.c_len for v in d.out[:d.n_out] if v.accumulate)  # accumulated outputs are read as well
     _timed_call(None, 2.0 * n * h * w * taps * k * nc,
                 lambda: check(_lib.lib().unetpp_gemm_fwd(C.byref(d), _stream()), "unetpp_gemm_fwd"),
-                4.0 * n * h * w * (k + nc + acc))
+                (2.0 if d.flags & _lib.GEMM_BF16 else 4.0) * n * h * w * (k + nc + acc))
 
 
 def pack_weight(dst: torch.Tensor, src: torch.Tensor, t: int, k: int, n: int, dstr, sstr, flip: bool = False) -> None:
@@ -364,13 +380,13 @@ def wgrad(n: int, h: int, w: int, taps: int, xs: Sequence[V], dys: Sequence[V], 
         target_blocks = 2048  # the 1..4-channel first layer runs an HBM-bound VALU kernel: many small workgroups
     split = max(1, min(int(lib.unetpp_wgrad_max_split(n, h, w)), target_blocks // max(1, pairs)))
     d.n_split = split
-    d.flags = _lib.GEMM_DIRECT if (direct or not USE_WINOGRAD) else 0
+    d.flags = (_lib.GEMM_DIRECT if (direct or not USE_WINOGRAD) else 0) | _storage_flag(dys, xs)
     planes = int(lib.unetpp_wgrad_slab_planes(C.byref(d)))  # taps, or 16 for the Winograd kernel
     slabs = torch.empty(split * (planes * k + 1) * nc, dtype=torch.float32, device=xs[0].t.device)
     d.slabs = slabs.data_ptr()
     _timed_call(None, 2.0 * n * h * w * taps * k * nc,
                 lambda: check(lib.unetpp_wgrad(C.byref(d), _stream()), "unetpp_wgrad"),
-                4.0 * n * h * w * (k + nc))
+                (2.0 if d.flags & _lib.GEMM_BF16 else 4.0) * n * h * w * (k + nc))
     if n_inner is None:
         n_inner = nc
     check(lib.unetpp_wgrad_finish(_ptr(slabs), split, planes, k, nc, n_inner, _ptr(dw), dw_strides[0], dw_strides[1],
