@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNETPP_ABI_VERSION 4
+#define UNETPP_ABI_VERSION 5
 #define UNETPP_MAX_VIEWS 8
 
 #define UNETPP_OK 0
@@ -251,6 +251,32 @@ int unetpp_create_heatmap(const float* points, int32_t N, int32_t P, int32_t H, 
 /* ---- layout converters at the network edge ------------------------------------------------ */
 int unetpp_nchw_to_nhwc(const float* src, int32_t N, int32_t C, int32_t H, int32_t W, float* dst, void* stream);
 int unetpp_nhwc_to_nchw(const float* src, int32_t N, int32_t C, int32_t H, int32_t W, float* dst, void* stream);
+
+/* ---- bf16-storage companions of the UNETPP_GEMM_BF16 launches (BASELINE configs[3]/[4]) -------------
+ * Same operations as their fp32 namesakes above, on bf16 NHWC activations (void*: 16-byte aligned, C a multiple of
+ * 8; the BatchNorm backward and head kernels want C/8 a power of two); coefficients, partial sums, parameter
+ * gradients and the heads' NCHW probabilities / their gradients stay fp32.  The max-pool winner is the first maximum
+ * in scan order of the STORED (bf16-rounded) activation.  d_pooled / pool_idx may be NULL (no pooled consumer):
+ * otherwise the pooled gradient is routed to the window argmax while d_act is read, in both passes. */
+int unetpp_affine_relu_pool_bf16(const void* y, const float* scale, const float* shift, int32_t relu,
+                                 int32_t N, int32_t H, int32_t W, int32_t C,
+                                 void* act, void* pooled, uint8_t* pool_idx, void* stream);
+int64_t unetpp_bn_bwd_blocks_bf16(int64_t pixels, int32_t C);
+int unetpp_bn_bwd_reduce_bf16(const void* d_act, const void* y, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, const void* d_pooled, const uint8_t* pool_idx,
+                              int32_t N, int32_t H, int32_t W, int32_t C, float* partial, void* stream);
+int unetpp_bn_bwd_apply_bf16(const void* d_act, const void* y, const float* scale, const float* shift,
+                             const float* mean, const float* invstd, const float* gamma, const float* dgamma,
+                             const float* dbeta, const void* d_pooled, const uint8_t* pool_idx,
+                             int32_t N, int32_t H, int32_t W, int32_t C, void* dy, void* stream);
+int unetpp_head_fwd_bf16(const void* x, const float* weight, const float* bias, int32_t N, int32_t H, int32_t W,
+                         int32_t C, int32_t n_cls, float p_drop, uint64_t seed, const uint8_t* mask,
+                         float* out_nchw, void* stream);
+/* partial: unetpp_head_bwd_blocks(N*H*W) rows of [n_cls*C + n_cls], finished by unetpp_sum_partials */
+int unetpp_head_bwd_bf16(const float* d_out_nchw, const float* out_nchw, const void* x, const float* weight,
+                         int32_t N, int32_t H, int32_t W, int32_t C, int32_t n_cls, float p_drop, uint64_t seed,
+                         const uint8_t* mask, void* dx, int32_t accumulate, int32_t gate_x, float* partial,
+                         void* stream);
 
 #ifdef __cplusplus
 }

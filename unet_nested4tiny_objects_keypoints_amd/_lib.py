@@ -15,10 +15,10 @@ _REPO = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.environ.get("UNETPP_LIB", os.path.join(_PKG_DIR, "libunetpp_hip.so"))  # override: kernel A/B runs
 CSRC = os.path.join(_PKG_DIR, "csrc")
 INCLUDE = os.path.join(_REPO, "include")
-SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_wino.hip", "gemm_bf16.hip", "wgrad_bf16.hip", "weight_image.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "wgrad_wino.hip", "first_layer.hip", "pointwise.hip", "caller.hip")
-HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h", "lds_asm.h", "bf16_common.h")
+SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_wino.hip", "gemm_bf16.hip", "wgrad_bf16.hip", "pointwise_bf16.hip", "weight_image.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "wgrad_wino.hip", "first_layer.hip", "pointwise.hip", "caller.hip")
+HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h", "lds_asm.h", "bf16_common.h", "dropout.h")
 MAX_VIEWS = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 # packed-f32 VALU (SLP-vectorised add pairs) costs issue slots beside MFMAs: keep the Winograd transforms scalar
 EXTRA_FLAGS = {"gemm_wino.hip": ("-fno-slp-vectorize",), "wgrad_wino.hip": ("-fno-slp-vectorize",)}
 GEMM_DIRECT = 1  # unetpp_gemm_desc.flags: direct summation only (no Winograd)
@@ -120,6 +120,13 @@ SIGNATURES = {
     "unetpp_bilinear2x_bwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _I32, _P]),
     "unetpp_nchw_to_nhwc": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P]),
     "unetpp_nhwc_to_nchw": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P]),
+    # bf16-storage companions (pointwise_bf16.hip)
+    "unetpp_affine_relu_pool_bf16": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "unetpp_bn_bwd_blocks_bf16": (_I64, [_I64, _I32]),
+    "unetpp_bn_bwd_reduce_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
+    "unetpp_bn_bwd_apply_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
+    "unetpp_head_fwd_bf16": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _P]),
+    "unetpp_head_bwd_bf16": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _I32, _I32, _P, _P]),
 }
 
 _LIB = None

@@ -3,6 +3,7 @@
 // and the NCHW<->NHWC converters used at the network edge.  All NHWC fp32; 16-byte vector
 // accesses whenever the channel count is a multiple of 4, scalar fallback otherwise.
 #include "common.h"
+#include "dropout.h"
 
 namespace unetpp {
 namespace {
@@ -467,24 +468,6 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_pool_kernel(
   }
 }
 
-// ------------------------------------------------------------------ dropout keep mask
-// Counter-based: one splitmix64 hash per group of 4 channels of one pixel gives four 16-bit
-// uniforms; forward and backward regenerate the same mask from (seed, pixel, group).
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-  return z ^ (z >> 31);
-}
-__device__ __forceinline__ uint64_t keep_bits(uint64_t seed, long pixel, int cgroups4, int g4) {
-  return mix64(seed + 0x9E3779B97F4A7C15ULL * (static_cast<uint64_t>(pixel) * cgroups4 + g4 + 1));
-}
-// keep flag of slice channel c of pixel p
-__device__ __forceinline__ bool keep_one(uint64_t bits, int c_in_group, uint32_t thr16) {
-  return ((bits >> (16 * c_in_group)) & 0xFFFFu) < thr16;
-}
-
-constexpr int kHeadMaxC = 128;
-constexpr int kHeadMaxCls = 8;
 
 __global__ __launch_bounds__(kThreads) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ weight,
                                                             const float* __restrict__ bias, long pixels, int HW, int C,
@@ -1234,11 +1217,6 @@ namespace {
 inline bool head_args_ok(int N, int H, int W, int C, int n_cls, float p_drop) {
   return N >= 1 && H >= 1 && W >= 1 && C >= 1 && C <= kHeadMaxC && n_cls >= 1 && n_cls <= kHeadMaxCls &&
          p_drop >= 0.f && p_drop < 1.f;
-}
-inline uint32_t keep_threshold(float p_drop) {
-  const double keep = 1.0 - static_cast<double>(p_drop);
-  uint32_t t = static_cast<uint32_t>(keep * 65536.0 + 0.5);
-  return t > 65536u ? 65536u : t;
 }
 }  // namespace
 

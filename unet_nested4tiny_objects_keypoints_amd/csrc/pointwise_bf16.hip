@@ -1,0 +1,450 @@
+// HBM-bound companions of the bf16 MFMA kernels (BASELINE configs[3]/[4]): every activation tensor is bf16 NHWC in
+// HBM and is touched in 16-byte pieces = 8 channels of one pixel; the arithmetic, the BatchNorm sums and all
+// parameter gradients are fp32.
+//   unetpp_affine_relu_pool_bf16   BatchNorm apply + ReLU (+ 2x2 max-pool with argmax bytes) of a conv output
+//   unetpp_bn_bwd_reduce_bf16      BatchNorm + ReLU backward, pass 1: per-workgroup (sum g, sum g*xhat) partials
+//   unetpp_bn_bwd_apply_bf16       pass 2: dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M)
+//                                  (both passes can route the gradient of the node's max-pooled copy to the window
+//                                  argmax while they read d_act: no scatter pass, no read-modify-write)
+//   unetpp_head_fwd_bf16 / unetpp_head_bwd_bf16   dropout + 1x1 convolution + sigmoid heads: bf16 features in,
+//                                  fp32 NCHW probabilities out (the loss stays fp32), bf16 feature gradient back
+#include "bf16_common.h"
+#include "common.h"
+#include "dropout.h"
+
+namespace unetpp {
+namespace {
+
+#define ST(s) static_cast<hipStream_t>(s)
+
+inline unsigned grid_for8(long items, long cap = 2048 * 8) {
+  long b = (items + kThreads - 1) / kThreads;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return static_cast<unsigned>(b);
+}
+inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+__device__ __forceinline__ void affine8(float (&f)[8], const float* scale, const float* shift, int c, int relu) {
+  if (scale != nullptr) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], scale[c + e], shift[c + e]);
+  }
+  if (relu) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+  }
+}
+
+// thread = (pixel, channel octet)
+__global__ __launch_bounds__(kThreads) void affine_relu_bf16_kernel(const bf16_t* __restrict__ y, const float* scale,
+                                                                    const float* shift, int relu, long items, int CG,
+                                                                    bf16_t* __restrict__ act) {
+  for (long i = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; i < items;
+       i += static_cast<long>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i % CG) * 8;
+    float f[8];
+    unpack8(reinterpret_cast<const u32x4*>(y)[i], f);
+    affine8(f, scale, shift, c, relu);
+    reinterpret_cast<u32x4*>(act)[i] = pack8(f);
+  }
+}
+
+// thread = (2x2 window, channel octet): four 16-byte loads, four optional stores of the activation, one store of the
+// pooled octet and 8 argmax bytes.  The winner is the first maximum in scan order of the ROUNDED (stored) values.
+__global__ __launch_bounds__(kThreads) void affine_relu_pool_bf16_kernel(const bf16_t* __restrict__ y, const float* scale,
+                                                                         const float* shift, int relu, int N, int H, int W,
+                                                                         int CG, bf16_t* __restrict__ act,
+                                                                         bf16_t* __restrict__ pooled,
+                                                                         uint8_t* __restrict__ pool_idx) {
+  const int Hp = H >> 1, Wp = W >> 1;
+  const long items = static_cast<long>(N) * Hp * Wp * CG;
+  for (long i = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; i < items;
+       i += static_cast<long>(gridDim.x) * kThreads) {
+    const int cg = static_cast<int>(i % CG);
+    long r = i / CG;
+    const int xp = static_cast<int>(r % Wp);
+    r /= Wp;
+    const int yp = static_cast<int>(r % Hp);
+    const long n = r / Hp;
+    const long base = ((n * H + 2 * yp) * W + 2 * xp) * CG + cg;  // in octets
+    const long offs[4] = {base, base + CG, base + static_cast<long>(W) * CG, base + static_cast<long>(W) * CG + CG};
+    float best[8];
+    unsigned bi[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float f[8];
+      unpack8(reinterpret_cast<const u32x4*>(y)[offs[q]], f);
+      affine8(f, scale, shift, cg * 8, relu);
+      const u32x4 packed = pack8(f);
+      if (act != nullptr) reinterpret_cast<u32x4*>(act)[offs[q]] = packed;
+      unpack8(packed, f);  // compare what is stored
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (q == 0 || f[e] > best[e]) {
+          best[e] = f[e];
+          bi[e] = q;
+        }
+      }
+    }
+    reinterpret_cast<u32x4*>(pooled)[i] = pack8(best);
+    reinterpret_cast<u32x2*>(pool_idx)[i] = u32x2{bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24),
+                                                  bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24)};
+  }
+}
+
+// gradient of the activation at (pixel i, octet): d_act (+ the pooled gradient when this pixel won its window)
+__device__ __forceinline__ void load_grad8(const bf16_t* d_act, const bf16_t* d_pooled, const uint8_t* pool_idx, long i,
+                                           int CG, int H, int W, float (&g)[8]) {
+  unpack8(reinterpret_cast<const u32x4*>(d_act)[i], g);
+  if (d_pooled != nullptr) {
+    const int cg = static_cast<int>(i % CG);
+    long r = i / CG;
+    const int x = static_cast<int>(r % W);
+    r /= W;
+    const int y = static_cast<int>(r % H);
+    const long n = r / H;
+    const long wi = ((n * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * CG + cg;
+    const unsigned pos = static_cast<unsigned>((y & 1) * 2 + (x & 1));
+    const u32x2 ib = reinterpret_cast<const u32x2*>(pool_idx)[wi];
+    float dp[8];
+    unpack8(reinterpret_cast<const u32x4*>(d_pooled)[wi], dp);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (((ib[e >> 2] >> (8 * (e & 3))) & 0xffu) == pos) g[e] += dp[e];
+  }
+}
+
+// The grid stride is a multiple of CG (a power of two <= 256), so a thread keeps one channel octet.
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_bf16_kernel(const bf16_t* __restrict__ d_act,
+                                                                      const bf16_t* __restrict__ y, const float* scale,
+                                                                      const float* shift, const float* mean,
+                                                                      const float* invstd, const bf16_t* d_pooled,
+                                                                      const uint8_t* pool_idx, long items, int CG, int H,
+                                                                      int W, float* __restrict__ partial) {
+  __shared__ float sm[kThreads][17];
+  const long first = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x;
+  const int c = static_cast<int>(first % CG) * 8;
+  float sc[8], sh[8], mu[8], is[8], s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = scale[c + e];
+    sh[e] = shift[c + e];
+    mu[e] = mean[c + e];
+    is[e] = invstd[c + e];
+    s1[e] = 0.f;
+    s2[e] = 0.f;
+  }
+  for (long i = first; i < items; i += static_cast<long>(gridDim.x) * kThreads) {
+    float g[8], v[8];
+    load_grad8(d_act, d_pooled, pool_idx, i, CG, H, W, g);
+    unpack8(reinterpret_cast<const u32x4*>(y)[i], v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float gg = (fmaf(v[e], sc[e], sh[e]) > 0.f) ? g[e] : 0.f;
+      s1[e] += gg;
+      s2[e] += gg * (v[e] - mu[e]) * is[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sm[threadIdx.x][2 * e] = s1[e];
+    sm[threadIdx.x][2 * e + 1] = s2[e];
+  }
+  __syncthreads();
+  const int C = CG * 8;
+  for (int cc = threadIdx.x; cc < C; cc += kThreads) {  // kThreads % CG == 0: thread t holds octet t % CG
+    const int cg = cc >> 3, e = cc & 7;
+    float a = 0.f, b = 0.f;
+    for (int t = cg; t < kThreads; t += CG) {  // fixed order
+      a += sm[t][2 * e];
+      b += sm[t][2 * e + 1];
+    }
+    partial[(static_cast<long>(blockIdx.x) * C + cc) * 2 + 0] = a;
+    partial[(static_cast<long>(blockIdx.x) * C + cc) * 2 + 1] = b;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_bf16_kernel(const bf16_t* __restrict__ d_act,
+                                                                     const bf16_t* __restrict__ y, const float* scale,
+                                                                     const float* shift, const float* mean,
+                                                                     const float* invstd, const float* gamma,
+                                                                     const float* dgamma, const float* dbeta,
+                                                                     const bf16_t* d_pooled, const uint8_t* pool_idx,
+                                                                     float inv_count, long items, int CG, int H, int W,
+                                                                     bf16_t* __restrict__ dy) {
+  for (long i = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; i < items;
+       i += static_cast<long>(gridDim.x) * kThreads) {
+    const int c = static_cast<int>(i % CG) * 8;
+    float g[8], v[8], out[8];
+    load_grad8(d_act, d_pooled, pool_idx, i, CG, H, W, g);
+    unpack8(reinterpret_cast<const u32x4*>(y)[i], v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float gg = (fmaf(v[e], scale[c + e], shift[c + e]) > 0.f) ? g[e] : 0.f;
+      const float xhat = (v[e] - mean[c + e]) * invstd[c + e];
+      out[e] = gamma[c + e] * invstd[c + e] * (gg - dbeta[c + e] * inv_count - xhat * dgamma[c + e] * inv_count);
+    }
+    reinterpret_cast<u32x4*>(dy)[i] = pack8(out);  // may alias d_act: the item was read by this thread above
+  }
+}
+
+// ---- heads.  Forward: CG = C/8 lanes share a pixel (CG a power of two <= 16): every lane loads one octet, applies the
+// dropout keep mask, multiplies it with the n_cls weight octets and the CG partial sums are folded by wave shuffles.
+__global__ __launch_bounds__(kThreads) void head_fwd_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ weight,
+                                                                 const float* __restrict__ bias, long pixels, int HW,
+                                                                 int C, int CG, int n_cls, float keep_scale, uint32_t thr16,
+                                                                 uint64_t seed, const uint8_t* __restrict__ mask,
+                                                                 int use_drop, float* __restrict__ out) {
+  __shared__ float wsm[kHeadMaxCls * kHeadMaxC];
+  for (int i = threadIdx.x; i < n_cls * C; i += kThreads) wsm[i] = weight[i];
+  __syncthreads();
+  const int ppb = kThreads / CG;  // pixels per workgroup pass
+  const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+  const long passes = (pixels + ppb - 1) / ppb;
+  for (long ps = blockIdx.x; ps < passes; ps += gridDim.x) {  // all lanes stay in the loop: shuffles below
+    const long p = ps * ppb + pl;
+    const bool live = p < pixels;
+    float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      unpack8(reinterpret_cast<const u32x4*>(x)[p * CG + cg], f);
+      if (use_drop) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const uint64_t bits = (mask == nullptr) ? keep_bits(seed, p, C >> 2, 2 * cg + half) : 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int e = 4 * half + q;
+            const bool keep = (mask != nullptr) ? (mask[p * C + cg * 8 + e] != 0) : keep_one(bits, q, thr16);
+            f[e] = keep ? f[e] * keep_scale : 0.f;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kHeadMaxCls; ++k) {
+      if (k < n_cls) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(f[e], wsm[k * C + cg * 8 + e], s);
+        for (int m = 1; m < CG; m <<= 1) s += __shfl_xor(s, m);  // every lane of the pixel holds the logit
+        if (live && (k % CG) == cg) {                            // classes are dealt to the pixel's lanes round robin
+          const long n = p / HW, hw = p - n * HW;
+          out[(n * n_cls + k) * HW + hw] = 1.0f / (1.0f + __expf(-(s + bias[k])));
+        }
+      }
+    }
+  }
+}
+
+// Backward: 64-pixel tiles.  LDS: x*keep*scale fp32 [64][C+1], dlogit [64][8], W [8][C].
+__global__ __launch_bounds__(kThreads) void head_bwd_bf16_kernel(const float* __restrict__ d_out, const float* __restrict__ outp,
+                                                                 const bf16_t* __restrict__ x, const float* __restrict__ weight,
+                                                                 long pixels, int HW, int C, int n_cls, float keep_scale,
+                                                                 uint32_t thr16, uint64_t seed, const uint8_t* __restrict__ mask,
+                                                                 int use_drop, bf16_t* __restrict__ dx, int accumulate,
+                                                                 int gate_x, float* __restrict__ partial) {
+  extern __shared__ float hsm[];
+  const int XS = C + 1, CG = C >> 3;
+  float* xs = hsm;                         // [64][C+1]
+  float* dl = xs + 64 * XS;                // [64][8]
+  float* wsm = dl + 64 * kHeadMaxCls;      // [8][C]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n_cls * C; i += kThreads) wsm[i] = weight[i];
+  float wacc[4] = {0.f, 0.f, 0.f, 0.f};  // dW entries tid, tid+256, ... (n_cls*C <= 1024)
+  float bacc = 0.f;
+  const long n_tiles = (pixels + 63) / 64;
+  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const long p0 = tile * 64;
+    __syncthreads();
+    for (int it = tid; it < 64 * n_cls; it += kThreads) {  // dlogit = d_out * out * (1 - out)
+      const int pl = it & 63, k = it >> 6;
+      const long p = p0 + pl;
+      float v = 0.f;
+      if (p < pixels) {
+        const long n = p / HW, hw = p - n * HW;
+        const long o = (n * n_cls + k) * HW + hw;
+        const float pr = outp[o];
+        v = d_out[o] * pr * (1.f - pr);
+      }
+      dl[pl * kHeadMaxCls + k] = v;
+    }
+    __syncthreads();
+    // one pass over x in octets: keep mask, x*keep*scale -> LDS, dx = keep*scale * (W^T dlogit) (+ old dx, gate)
+    for (int it = tid; it < 64 * CG; it += kThreads) {
+      const int pl = it / CG, cg = it - pl * CG;
+      const long p = p0 + pl;
+      float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ks[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ks[e] = 1.f;
+      if (p < pixels) {
+        float raw[8];
+        unpack8(reinterpret_cast<const u32x4*>(x)[p * CG + cg], raw);
+        if (use_drop) {
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const uint64_t bits = (mask == nullptr) ? keep_bits(seed, p, C >> 2, 2 * cg + half) : 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int e = 4 * half + q;
+              const bool keep = (mask != nullptr) ? (mask[p * C + cg * 8 + e] != 0) : keep_one(bits, q, thr16);
+              ks[e] = keep ? keep_scale : 0.f;
+            }
+          }
+        }
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          f[e] = raw[e] * ks[e];
+          float s = 0.f;
+#pragma unroll
+          for (int k = 0; k < kHeadMaxCls; ++k)
+            if (k < n_cls) s = fmaf(wsm[k * C + cg * 8 + e], dl[pl * kHeadMaxCls + k], s);
+          o[e] = s * ks[e];
+        }
+        if (accumulate) {
+          float old[8];
+          unpack8(reinterpret_cast<const u32x4*>(dx)[p * CG + cg], old);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += old[e];
+        }
+        if (gate_x) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (raw[e] > 0.f) ? o[e] : 0.f;
+        }
+        reinterpret_cast<u32x4*>(dx)[p * CG + cg] = pack8(o);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xs[pl * XS + cg * 8 + e] = f[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // dW[k, c] += sum_p dlogit[p, k] * xs[p, c]
+      const int idx = tid + q * kThreads;
+      if (idx < n_cls * C) {
+        const int k = idx / C, c = idx - k * C;
+        float s = 0.f;
+        for (int pl = 0; pl < 64; ++pl) s = fmaf(dl[pl * kHeadMaxCls + k], xs[pl * XS + c], s);
+        wacc[q] += s;
+      }
+    }
+    if (tid < n_cls) {
+      float s = 0.f;
+      for (int pl = 0; pl < 64; ++pl) s += dl[pl * kHeadMaxCls + tid];
+      bacc += s;
+    }
+  }
+  float* dst = partial + static_cast<long>(blockIdx.x) * (n_cls * C + n_cls);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = tid + q * kThreads;
+    if (idx < n_cls * C) dst[idx] = wacc[q];
+  }
+  if (tid < n_cls) dst[n_cls * C + tid] = bacc;
+}
+
+inline bool octets_ok(int C) {  // C = 8 * CG, CG a power of two <= 256 (a thread keeps its octet across a grid stride)
+  const int cg = C >> 3;
+  return C >= 8 && (C & 7) == 0 && (cg & (cg - 1)) == 0 && cg <= 256;
+}
+
+}  // namespace
+}  // namespace unetpp
+
+using namespace unetpp;
+
+extern "C" int unetpp_affine_relu_pool_bf16(const void* y, const float* scale, const float* shift, int32_t relu, int32_t N,
+                                            int32_t H, int32_t W, int32_t C, void* act, void* pooled, uint8_t* pool_idx,
+                                            void* stream) {
+  if (!y || N < 1 || H < 1 || W < 1 || C < 8 || (C & 7) || !a16(y) || (act && !a16(act))) return UNETPP_EINVAL;
+  if ((scale == nullptr) != (shift == nullptr) || (act == nullptr && pooled == nullptr)) return UNETPP_EINVAL;
+  const int CG = C >> 3;
+  if (pooled == nullptr) {
+    const long items = static_cast<long>(N) * H * W * CG;
+    hipLaunchKernelGGL(affine_relu_bf16_kernel, dim3(grid_for8(items)), dim3(kThreads), 0, ST(stream),
+                       static_cast<const bf16_t*>(y), scale, shift, relu, items, CG, static_cast<bf16_t*>(act));
+    return launch_status();
+  }
+  if ((H & 1) || (W & 1) || !pool_idx || !a16(pooled) || (reinterpret_cast<uintptr_t>(pool_idx) & 7)) return UNETPP_EINVAL;
+  const long items = static_cast<long>(N) * (H / 2) * (W / 2) * CG;
+  hipLaunchKernelGGL(affine_relu_pool_bf16_kernel, dim3(grid_for8(items)), dim3(kThreads), 0, ST(stream),
+                     static_cast<const bf16_t*>(y), scale, shift, relu, N, H, W, CG, static_cast<bf16_t*>(act),
+                     static_cast<bf16_t*>(pooled), pool_idx);
+  return launch_status();
+}
+
+extern "C" int64_t unetpp_bn_bwd_blocks_bf16(int64_t pixels, int32_t C) {
+  if (pixels < 1 || !octets_ok(C)) return 0;
+  const long items = pixels * (C >> 3);
+  long b = (items + 4L * kThreads - 1) / (4L * kThreads);  // >= 4 items per thread
+  if (b > 2048) b = 2048;
+  return b < 1 ? 1 : b;
+}
+
+extern "C" int unetpp_bn_bwd_reduce_bf16(const void* d_act, const void* y, const float* scale, const float* shift,
+                                         const float* mean, const float* invstd, const void* d_pooled,
+                                         const uint8_t* pool_idx, int32_t N, int32_t H, int32_t W, int32_t C, float* partial,
+                                         void* stream) {
+  if (!d_act || !y || !scale || !shift || !mean || !invstd || !partial || N < 1 || H < 1 || W < 1 || !octets_ok(C))
+    return UNETPP_EINVAL;
+  if ((d_pooled == nullptr) != (pool_idx == nullptr) || (d_pooled != nullptr && ((H | W) & 1))) return UNETPP_EINVAL;
+  const long pixels = static_cast<long>(N) * H * W;
+  hipLaunchKernelGGL(bn_bwd_reduce_bf16_kernel, dim3(static_cast<unsigned>(unetpp_bn_bwd_blocks_bf16(pixels, C))),
+                     dim3(kThreads), 0, ST(stream), static_cast<const bf16_t*>(d_act), static_cast<const bf16_t*>(y), scale,
+                     shift, mean, invstd, static_cast<const bf16_t*>(d_pooled), pool_idx, pixels * (C >> 3), C >> 3, H, W,
+                     partial);
+  return launch_status();
+}
+
+extern "C" int unetpp_bn_bwd_apply_bf16(const void* d_act, const void* y, const float* scale, const float* shift,
+                                        const float* mean, const float* invstd, const float* gamma, const float* dgamma,
+                                        const float* dbeta, const void* d_pooled, const uint8_t* pool_idx, int32_t N,
+                                        int32_t H, int32_t W, int32_t C, void* dy, void* stream) {
+  if (!d_act || !y || !scale || !shift || !mean || !invstd || !gamma || !dgamma || !dbeta || !dy || N < 1 || H < 1 ||
+      W < 1 || !octets_ok(C))
+    return UNETPP_EINVAL;
+  if ((d_pooled == nullptr) != (pool_idx == nullptr) || (d_pooled != nullptr && ((H | W) & 1))) return UNETPP_EINVAL;
+  const long pixels = static_cast<long>(N) * H * W;
+  const long items = pixels * (C >> 3);
+  hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel, dim3(grid_for8(items)), dim3(kThreads), 0, ST(stream),
+                     static_cast<const bf16_t*>(d_act), static_cast<const bf16_t*>(y), scale, shift, mean, invstd, gamma,
+                     dgamma, dbeta, static_cast<const bf16_t*>(d_pooled), pool_idx, 1.0f / static_cast<float>(pixels), items,
+                     C >> 3, H, W, static_cast<bf16_t*>(dy));
+  return launch_status();
+}
+
+static bool head_bf16_ok(int N, int H, int W, int C, int n_cls, float p_drop) {
+  const int cg = C >> 3;
+  return N >= 1 && H >= 1 && W >= 1 && C >= 8 && (C & 7) == 0 && C <= kHeadMaxC && (cg & (cg - 1)) == 0 && n_cls >= 1 &&
+         n_cls <= kHeadMaxCls && p_drop >= 0.f && p_drop < 1.f;
+}
+
+extern "C" int unetpp_head_fwd_bf16(const void* x, const float* weight, const float* bias, int32_t N, int32_t H, int32_t W,
+                                    int32_t C, int32_t n_cls, float p_drop, uint64_t seed, const uint8_t* mask,
+                                    float* out_nchw, void* stream) {
+  if (!x || !weight || !bias || !out_nchw || !a16(x) || !head_bf16_ok(N, H, W, C, n_cls, p_drop)) return UNETPP_EINVAL;
+  const long pixels = static_cast<long>(N) * H * W;
+  const int CG = C >> 3;
+  const long passes = (pixels + kThreads / CG - 1) / (kThreads / CG);
+  hipLaunchKernelGGL(head_fwd_bf16_kernel, dim3(static_cast<unsigned>(passes < 256 * 16 ? passes : 256 * 16)), dim3(kThreads),
+                     0, ST(stream), static_cast<const bf16_t*>(x), weight, bias, pixels, H * W, C, CG, n_cls,
+                     1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, p_drop > 0.f ? 1 : 0, out_nchw);
+  return launch_status();
+}
+
+extern "C" int unetpp_head_bwd_bf16(const float* d_out_nchw, const float* out_nchw, const void* x, const float* weight,
+                                    int32_t N, int32_t H, int32_t W, int32_t C, int32_t n_cls, float p_drop, uint64_t seed,
+                                    const uint8_t* mask, void* dx, int32_t accumulate, int32_t gate_x, float* partial,
+                                    void* stream) {
+  if (!d_out_nchw || !out_nchw || !x || !weight || !dx || !partial || !a16(x) || !a16(dx) ||
+      !head_bf16_ok(N, H, W, C, n_cls, p_drop))
+    return UNETPP_EINVAL;
+  const long pixels = static_cast<long>(N) * H * W;
+  const long tiles = (pixels + 63) / 64;
+  const size_t lds = (64 * (C + 1) + 64 * kHeadMaxCls + kHeadMaxCls * C) * sizeof(float);
+  hipLaunchKernelGGL(head_bwd_bf16_kernel, dim3(static_cast<unsigned>(tiles < 4096 ? tiles : 4096)), dim3(kThreads), lds,
+                     ST(stream), d_out_nchw, out_nchw, static_cast<const bf16_t*>(x), weight, pixels, H * W, C, n_cls,
+                     1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, p_drop > 0.f ? 1 : 0,
+                     static_cast<bf16_t*>(dx), accumulate, gate_x, partial);
+  return launch_status();
+}

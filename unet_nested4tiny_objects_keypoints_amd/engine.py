@@ -116,16 +116,17 @@ def _conv_bn_fwd(ins, conv, bn, y, b, h, w, training):
     return (None, None, scale, shift)
 
 
-def _pair_fwd(blk, ins: List[V], b, h, w, training, pool) -> _PairRec:
-    """models/unet.py:150-156: two [conv3x3 (+BN) + ReLU] stages; optional fused 2x2 max-pool of the result."""
+def _pair_fwd(blk, ins: List[V], b, h, w, training, pool, adt=torch.float32) -> _PairRec:
+    """models/unet.py:150-156: two [conv3x3 (+BN) + ReLU] stages; optional fused 2x2 max-pool of the result.
+    adt = storage type of the activations written (fp32, or bf16 for the UNETPP_GEMM_BF16 kernels)."""
     conv1, conv2 = getattr(blk.conv1, "0"), getattr(blk.conv2, "0")
     co = conv1.out_channels
     like = ins[0].t
-    new = lambda: torch.empty((b, h, w, co), dtype=torch.float32, device=like.device)  # noqa: E731
+    new = lambda: torch.empty((b, h, w, co), dtype=adt, device=like.device)  # noqa: E731
     r = _PairRec()
     r.ins, r.h, r.w = ins, h, w
     if pool:
-        r.pooled = torch.empty((b, h // 2, w // 2, co), dtype=torch.float32, device=like.device)
+        r.pooled = torch.empty((b, h // 2, w // 2, co), dtype=adt, device=like.device)
         r.pool_idx = torch.empty((b, h // 2, w // 2, co), dtype=torch.uint8, device=like.device)
     if blk.is_batchnorm:
         bn1, bn2 = getattr(blk.conv1, "1"), getattr(blk.conv2, "1")
@@ -148,13 +149,13 @@ def _pair_fwd(blk, ins: List[V], b, h, w, training, pool) -> _PairRec:
     return r
 
 
-def _up_fwd(upmod, is_deconv, src, b, hs, ws) -> _UpRec:
+def _up_fwd(upmod, is_deconv, src, b, hs, ws, adt=torch.float32) -> _UpRec:
     """models/unet.py:186-191,199: ConvTranspose2d(2,2) or bilinear x2 (align_corners) + conv1x1; src is [b,hs,ws,ci]."""
     u = _UpRec()
     u.src, u.h, u.w = src, hs, ws
     if is_deconv:
         co = upmod.out_channels
-        u.up = torch.empty((b, 2 * hs, 2 * ws, co), dtype=torch.float32, device=src.device)
+        u.up = torch.empty((b, 2 * hs, 2 * ws, co), dtype=adt, device=src.device)
         ops.gemm_fwd(b, hs, ws, 1, [V(src)], _phase_views(u.up), pack_deconv_fwd(upmod.weight.detach()),
                      tile_bias4(upmod.bias.detach()))
     else:
@@ -183,6 +184,18 @@ def _check_input(model, x):
         raise ValueError("H and W must be divisible by %d, got %dx%d" % (m, x.shape[2], x.shape[3]))
     if next(model.parameters()).device != x.device:
         raise RuntimeError("model and input are on different devices")
+
+
+def _activation_dtype(model):
+    """fp32, or bf16 storage (UNet_Nested.set_activation_dtype): BASELINE configs[3]/[4].  The bf16 kernels cover the
+    reference's default structure (transposed-convolution up path, BatchNorm encoder, channel counts 8 * 2^k)."""
+    adt = getattr(model, "activation_dtype", torch.float32)
+    if adt == torch.bfloat16:
+        if not (model.is_deconv and model.is_batchnorm):
+            raise NotImplementedError("bf16 storage supports is_deconv=True, is_batchnorm=True only")
+        if any(f % 8 or (f // 8) & (f // 8 - 1) for f in model.filters):
+            raise NotImplementedError("bf16 storage needs channel counts 8 * 2^k, got %s" % (model.filters,))
+    return adt
 
 
 def _dropout_config(model, training):
@@ -221,6 +234,7 @@ def _plan_of(model) -> "ops.PackPlan":
 def _forward_impl(model, x, training: bool, save: bool):
     b, _, h0, w0 = x.shape
     d = model.depth
+    adt = _activation_dtype(model)
     x_nhwc = ops.nchw_to_nhwc(x.detach().contiguous())
     X: Dict[Tuple[int, int], torch.Tensor] = {}
     pairs: Dict[Tuple[int, int], _PairRec] = {}
@@ -228,7 +242,7 @@ def _forward_impl(model, x, training: bool, save: bool):
     inp, h, w = x_nhwc, h0, w0
     for i in range(d):  # encoder column (:257-265)
         with ops.region("X%d0.fwd" % i):
-            r = _pair_fwd(getattr(model, "conv%d0" % i), [V(inp)], b, h, w, training, pool=(i < d - 1))
+            r = _pair_fwd(getattr(model, "conv%d0" % i), [V(inp)], b, h, w, training, pool=(i < d - 1), adt=adt)
         pairs[(i, 0)], X[(i, 0)] = r, r.out
         if i < d - 1:
             inp, h, w = r.pooled, h // 2, w // 2
@@ -236,9 +250,9 @@ def _forward_impl(model, x, training: bool, save: bool):
         for i in range(d - j):
             mod = getattr(model, "up_concat%d%d" % (i, j))
             hi, wi = h0 >> i, w0 >> i
-            u = _up_fwd(mod.up, model.is_deconv, X[(i + 1, j - 1)], b, hi // 2, wi // 2)
+            u = _up_fwd(mod.up, model.is_deconv, X[(i + 1, j - 1)], b, hi // 2, wi // 2, adt)
             ins = [V(u.up)] + [V(X[(i, jj)]) for jj in range(j)]  # up first, then X_i0.. (:198-202)
-            r = _pair_fwd(mod.conv, ins, b, hi, wi, training, pool=False)
+            r = _pair_fwd(mod.conv, ins, b, hi, wi, training, pool=False, adt=adt)
             ups[(i, j)], pairs[(i, j)], X[(i, j)] = u, r, r.out
     p_drop, seeds, masks = _dropout_config(model, training)
     outs = []
@@ -447,6 +461,8 @@ def _backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=No
                 t.zero_()
             pool_grad = (d_pooled, s.pairs[(i - 1, 0)].pool_idx)
         elif want_input_grad:
+            if s.X[(0, 0)].dtype != torch.float32:
+                raise NotImplementedError("the input gradient is not available with bf16 activation storage")
             dx_in = torch.empty_like(s.x_nhwc)
             _pair_bwd(blk, r, d_out, [V(dx_in)], b, grads, pre_gated, pool_grad=mine)
         else:

@@ -410,16 +410,46 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps):
     return scale, shift
 
 
+def _is_bf16(t):
+    return t.dtype == torch.bfloat16
+
+
 def affine_relu_pool(y, scale, shift, relu, act, pooled, pool_idx):
     n, h, w, c = y.shape
+    if _is_bf16(y):
+        check(_lib.lib().unetpp_affine_relu_pool_bf16(_ptr(y), _ptr(scale), _ptr(shift), int(relu), n, h, w, c, _ptr(act),
+                                                      _ptr(pooled), _ptr(pool_idx), _stream()),
+              "unetpp_affine_relu_pool_bf16")
+        return
     check(_lib.lib().unetpp_affine_relu_pool(_ptr(y), _ptr(scale), _ptr(shift), int(relu), n, h, w, c, _ptr(act),
                                              _ptr(pooled), _ptr(pool_idx), _stream()), "unetpp_affine_relu_pool")
 
 
 def maxpool_bwd(d_pooled, pool_idx, d_act):
     n, h, w, c = d_act.shape
+    if _is_bf16(d_act):
+        raise NotImplementedError("bf16 storage: the pool gradient is only routed inside BatchNorm backward "
+                                  "(is_batchnorm=False is an fp32-only configuration)")
     check(_lib.lib().unetpp_maxpool_bwd(_ptr(d_pooled), _ptr(pool_idx), n, h, w, c, _ptr(d_act), _stream()),
           "unetpp_maxpool_bwd")
+
+
+def _bn_backward_bf16(d_act, y, scale, shift, mean, invstd, gamma, dy_out, dgamma, dbeta, pool):
+    lib = _lib.lib()
+    n, h, w, c = y.shape
+    blocks = int(lib.unetpp_bn_bwd_blocks_bf16(n * h * w, c))
+    if blocks < 1:
+        raise ValueError("bf16 BatchNorm backward needs C = 8 * 2^k channels, got %d" % c)
+    partial = torch.empty(blocks * c * 2, dtype=torch.float32, device=y.device)
+    dp, pi = (None, None) if pool is None else (_need(pool[0], "d_pooled", torch.bfloat16), _need(pool[1], "pool_idx", torch.uint8))
+    st = _stream()
+    check(lib.unetpp_bn_bwd_reduce_bf16(_ptr(d_act), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _ptr(dp),
+                                        _ptr(pi), n, h, w, c, _ptr(partial), st), "unetpp_bn_bwd_reduce_bf16")
+    check(lib.unetpp_bn_bwd_finalize(_ptr(partial), blocks, c, _ptr(dgamma), _ptr(dbeta), st), "unetpp_bn_bwd_finalize")
+    check(lib.unetpp_bn_bwd_apply_bf16(_ptr(d_act), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                       _ptr(dgamma), _ptr(dbeta), _ptr(dp), _ptr(pi), n, h, w, c, _ptr(dy_out), st),
+          "unetpp_bn_bwd_apply_bf16")
+    return dgamma, dbeta
 
 
 def bn_backward(d_act, y, scale, shift, mean, invstd, gamma, dy_out, dgamma=None, dbeta=None, pool=None):
@@ -429,15 +459,17 @@ def bn_backward(d_act, y, scale, shift, mean, invstd, gamma, dy_out, dgamma=None
     lib = _lib.lib()
     n, h, w, c = y.shape
     pixels = n * h * w
+    if dgamma is None:
+        dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
+    if dbeta is None:
+        dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
+    if _is_bf16(y):
+        return _bn_backward_bf16(d_act, y, scale, shift, mean, invstd, gamma, dy_out, dgamma, dbeta, pool)
     if pool is not None and not lib.unetpp_bn_bwd_pool_ok(n, h, w, c):
         maxpool_bwd(pool[0], pool[1], d_act)
         pool = None
     blocks = int(lib.unetpp_bn_bwd_blocks(pixels, c))
     partial = torch.empty(blocks * c * 2, dtype=torch.float32, device=y.device)
-    if dgamma is None:
-        dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
-    if dbeta is None:
-        dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
     st = _stream()
     if pool is None:
         check(lib.unetpp_bn_bwd_reduce(_ptr(d_act), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), pixels,
@@ -462,8 +494,9 @@ def bn_backward(d_act, y, scale, shift, mean, invstd, gamma, dy_out, dgamma=None
 def head_fwd(x, weight, bias, p_drop, seed, mask, out_nchw):
     n, h, w, c = x.shape
     n_cls = weight.shape[0]
-    check(_lib.lib().unetpp_head_fwd(_ptr(x), _ptr(weight), _ptr(bias), n, h, w, c, n_cls, float(p_drop),
-                                     C.c_uint64(seed), _ptr(mask), _ptr(out_nchw), _stream()), "unetpp_head_fwd")
+    fn = _lib.lib().unetpp_head_fwd_bf16 if _is_bf16(x) else _lib.lib().unetpp_head_fwd
+    check(fn(_ptr(x), _ptr(weight), _ptr(bias), n, h, w, c, n_cls, float(p_drop), C.c_uint64(seed), _ptr(mask),
+             _ptr(out_nchw), _stream()), "unetpp_head_fwd")
 
 
 def head_bwd(d_out, out, x, weight, p_drop, seed, mask, dx, accumulate, gate_x=False):
@@ -476,14 +509,16 @@ def head_bwd(d_out, out, x, weight, p_drop, seed, mask, dx, accumulate, gate_x=F
     partial = torch.empty(blocks * ln, dtype=torch.float32, device=x.device)
     sums = torch.empty(ln, dtype=torch.float32, device=x.device)
     st = _stream()
-    check(lib.unetpp_head_bwd(_ptr(d_out), _ptr(out), _ptr(x), _ptr(weight), n, h, w, c, n_cls, float(p_drop),
-                              C.c_uint64(seed), _ptr(mask), _ptr(dx), int(accumulate), int(gate_x), _ptr(partial), st),
-          "unetpp_head_bwd")
+    fn = lib.unetpp_head_bwd_bf16 if _is_bf16(x) else lib.unetpp_head_bwd
+    check(fn(_ptr(d_out), _ptr(out), _ptr(x), _ptr(weight), n, h, w, c, n_cls, float(p_drop), C.c_uint64(seed), _ptr(mask),
+             _ptr(dx), int(accumulate), int(gate_x), _ptr(partial), st), "unetpp_head_bwd")
     check(lib.unetpp_sum_partials(_ptr(partial), blocks, ln, _ptr(sums), st), "unetpp_sum_partials")
     return sums[:n_cls * c].view(n_cls, c, 1, 1), sums[n_cls * c:]
 
 
 def bilinear2x_fwd(x, y):
+    if _is_bf16(x):
+        raise NotImplementedError("bf16 storage covers the default transposed-convolution up path only (is_deconv=True)")
     n, h, w, c = x.shape
     check(_lib.lib().unetpp_bilinear2x_fwd(_ptr(x), n, h, w, c, _ptr(y), _stream()), "unetpp_bilinear2x_fwd")
 

@@ -142,6 +142,15 @@ class UNet_Nested(nn.Module):
         self.drop_out = nn.Dropout(p=0.4)  # :254
         # Test hook: list of uint8 NHWC keep-masks (one per head) used instead of the in-kernel generator.
         self.dropout_masks = None
+        # storage type of the activations and their gradients in HBM: fp32 (reference numerics), or bf16 with fp32
+        # accumulation / statistics / parameter gradients (BASELINE configs[3]/[4]); parameters stay fp32 either way
+        self.activation_dtype = torch.float32
+
+    def set_activation_dtype(self, dtype):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("activation storage is float32 or bfloat16")
+        self.activation_dtype = dtype
+        return self
 
     def forward(self, inputs):
         return engine.run(self, inputs)
