@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--depth", type=int, default=4, help="resolution levels (reference: 4; configs[4]: 5)")
     ap.add_argument("--in-channels", type=int, default=1)
     ap.add_argument("--n-classes", type=int, default=4)
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="activation storage: f32 (configs[1], reference numerics) or bf16 with fp32 accumulation (configs[3]/[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps (BASELINE.md section 4: >= 3)")
     ap.add_argument("--prewarm", type=int, default=10, help="untimed steps before the W warm-up steps (see main)")
@@ -221,6 +223,8 @@ def main():
     fs = int(args.feature_scale) if float(args.feature_scale).is_integer() else args.feature_scale
     torch.manual_seed(0)
     model = UNet_Nested(in_channels=args.in_channels, n_classes=n_cls, feature_scale=fs, depth=args.depth).to(dev).train()
+    if args.dtype == "bf16":
+        model.set_activation_dtype(torch.bfloat16)
     averager = None
     if distributed:
         averager = dp.make_data_parallel(model)
@@ -300,13 +304,14 @@ def main():
     if timer is not None:
         launches, regions = timer.summary()
         kernels = {k: {"launches_per_step": v["launches"] / sampled_steps, "ms_per_step": round(v["ms"] / sampled_steps, 3),
-                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in launches.items()}
+                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                       "algorithmic_gb_per_s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} for k, v in launches.items()}
         dom = max(launches.items(), key=lambda kv: kv[1]["ms"])
         alg = dom[1]["flops"] / (dom[1]["ms"] * 1e-3) / 1e12
         # what the matrix pipe executes: Winograd F(2x2,3x3) runs 16 multiply-adds per 36 algorithmic ones
         wino = dom[0].startswith("gemm_wino") or dom[0].startswith("wgrad_wino")
         executed = alg / 2.25 if wino else alg
-        c2 = args.size == 256 and fs == 1 and args.batch == 32 and args.depth == 4
+        c2 = args.size == 256 and fs == 1 and args.batch == 32 and args.depth == 4 and args.dtype == "f32"
         from unet_nested4tiny_objects_keypoints_amd import _lib as _l
         traffic = pmc_traffic(dom[0], _l.source_hash()) if c2 else None
         traffic_alg = dom[1]["bytes"] / dom[1]["launches"]
@@ -326,7 +331,26 @@ def main():
                     "timed_steps_with_launch_events": sampled_steps,
                     "avg_launch_ms": round(dom[1]["ms"] / dom[1]["launches"], 4),
                     "flop_per_launch_avg": dom[1]["flops"] / dom[1]["launches"]}
-        if "X00.fwd" in regions and args.size == 256 and fs == 1 and args.in_channels == 1:
+        if args.dtype == "bf16":
+            # bf16 storage: the dense bf16 MFMA ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B) lies above most layers of this
+            # network, so the kernel is priced against BOTH limits and `bound` names the one that governs its launches
+            peak_bf = 2500.0
+            t_mfma = dom[1]["flops"] / (peak_bf * 1e12)
+            t_hbm = dom[1]["bytes"] / (PEAK_HBM_TBS * 1e12)
+            gbs = dom[1]["bytes"] / (dom[1]["ms"] * 1e-3) / 1e9
+            hbm_bound = t_hbm >= t_mfma
+            roofline.update({
+                "bound": "hbm" if hbm_bound else "mfma",
+                "achieved": round(gbs, 1) if hbm_bound else round(alg, 2),
+                "peak": PEAK_HBM_TBS * 1e3 if hbm_bound else peak_bf,
+                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": round(max(t_hbm, t_mfma) / (dom[1]["ms"] * 1e-3), 4),
+                "achieved_note": "algorithmic bytes (2 B x (Cin + Cout) x pixels) or FLOPs of the launches / their HIP-event "
+                                 "time; frac = max(HBM floor, bf16 MFMA floor) / measured time",
+                "achieved_algorithmic": round(alg, 2), "algorithmic_gb_per_s": round(gbs, 1),
+                "algorithm": "direct implicit GEMM, v_mfma_f32_32x32x16_bf16, bf16 storage, fp32 accumulation",
+                "floor_hbm_ms": round(1e3 * t_hbm / sampled_steps, 3), "floor_mfma_ms": round(1e3 * t_mfma / sampled_steps, 3)})
+        if "X00.fwd" in regions and args.size == 256 and fs == 1 and args.in_channels == 1 and args.dtype == "f32":
             t_img_us = 1e3 * regions["X00.fwd"]["ms"] / regions["X00.fwd"]["count"] / args.batch
             floor_c = X00_GFLOP_PER_IMG * 1e9 / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e6
             floor_h = X00_MB_PER_IMG * 1e6 / (PEAK_HBM_TBS * 1e12) * 1e6
@@ -349,12 +373,13 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": args.dtype,
         "data": "synthetic",
         "config": {"workload": "UNet_Nested(in=%d,n_classes=%d,base=%d,depth=%d) %dx%d train step, batch %d/GPU, "
-                               "FocalLoss_BCE_2d on %d heads, Adam, dropout p=0.4 active"
+                               "FocalLoss_BCE_2d on %d heads, Adam, dropout p=0.4 active, %s"
                                % (args.in_channels, n_cls, int(32 / args.feature_scale), args.depth, args.size, args.size,
-                                  args.batch, args.depth - 1),
+                                  args.batch, args.depth - 1,
+                                  "fp32" if args.dtype == "f32" else "bf16 activation storage / fp32 accumulation and parameters"),
                    "global_batch": world * args.batch, "per_gpu_batch": args.batch,
                    "parallelism": "dp%d" % world if distributed else "single",
                    "world_size": dist.get_world_size() if distributed else 1,

@@ -27,8 +27,14 @@ constexpr int BKC = 32;        // channels per K chunk
 constexpr int BPIX = 80;       // LDS bytes per staged pixel (64 + 16 pad)
 constexpr int BSTEP = 1024;    // bytes of one (tap, g) weight step: 32 columns x 16 k x 2 B
 
-template <int TAPS, int LOG2TW, int NT>
-__global__ __launch_bounds__(kThreads, 3) void gemm_bf16_kernel(const FastArgs a) {
+// STATS: the launch takes BatchNorm partial sums (per-column sums over pixels).  Those launches keep the pixel on the
+// MFMA row (accumulator register = pixel, lane = column: a column's sum is lane-local) and transpose the tile through
+// LDS for 16-byte stores.  All other launches SWAP the MFMA operands (A = weights, B = pixels): the accumulator tile
+// comes out as D[column][pixel], i.e. a lane holds 16 channels of ONE pixel in groups of four; one
+// v_permlane32_swap per register pair pairs the groups of lanes (j, 0) and (j, 1) into 8 consecutive channels, and
+// the tile leaves as two 16-byte stores per lane straight from registers -- no LDS round trip, no wave barriers.
+template <int TAPS, int LOG2TW, int NT, bool STATS>
+__global__ __launch_bounds__(kThreads, TAPS == 1 ? 4 : (NT == 2 ? 2 : 3)) void gemm_bf16_kernel(const FastArgs a) {
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
   constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;
   constexpr int HWp = TW + 2 * HALO, HHp = TH + 2 * HALO;
@@ -42,6 +48,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_bf16_kernel(const FastArgs a
   __shared__ __attribute__((aligned(16))) unsigned char smem[IN_BYTES + NT * IMG];
   unsigned char* in_tile = smem;
   unsigned char* w_tile = smem + IN_BYTES;
+  __shared__ float stat_lds[4 * 32 * 2];  // the four waves' BatchNorm partial sums of a column tile
 
   const unetpp_gemm_desc& d = a.d;
   const int tid = threadIdx.x;
@@ -77,6 +84,10 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_bf16_kernel(const FastArgs a
   int p_n = 0, p_ty0 = 0, p_tx0 = 0;
   const unsigned char* p_wimg = nullptr;
   const unsigned char* wimg_base = reinterpret_cast<const unsigned char*>(d.weight_image);
+  // the image a chunk needs is (column group, chunk): with ONE chunk per unit and ONE column group every unit of the
+  // launch uses the same image, which then stays in LDS (short-K layers: K <= 32 into <= 32*NT columns)
+  const bool w_resident = a.n_chunks == 1 && a.n_groups == 1;
+  bool w_loaded = false;
 
   auto prefetch_unit = [&](long k) {
     const UnitGeom g = decode_unit<LOG2TW>(a, first_unit + k * unit_step);
@@ -113,12 +124,14 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_bf16_kernel(const FastArgs a
       const unsigned off = voff[q] + static_cast<unsigned>(p_c0 + (cc < pf_cnt ? cc : 0));
       reg_in[q] = *reinterpret_cast<const u32x4*>(vp + off);
     }
-    const unsigned char* wp = p_wimg + static_cast<long>(p_chunk) * IMG;
+    if (!(w_resident && w_loaded)) {  // uniform branch
+      const unsigned char* wp = p_wimg + static_cast<long>(p_chunk) * IMG;
 #pragma unroll
-    for (int q = 0; q < W_ITEMS; ++q) {
-      const unsigned it = min(tid + q * kThreads, NT * IMG / 16 - 1);
-      const unsigned t = it / (IMG / 16), r = it - t * (IMG / 16);
-      reg_w[q] = *reinterpret_cast<const u32x4*>(wp + static_cast<long>(t) * a.n_chunks * IMG + r * 16u);
+      for (int q = 0; q < W_ITEMS; ++q) {
+        const unsigned it = min(tid + q * kThreads, NT * IMG / 16 - 1);
+        const unsigned t = it / (IMG / 16), r = it - t * (IMG / 16);
+        reg_w[q] = *reinterpret_cast<const u32x4*>(wp + static_cast<long>(t) * a.n_chunks * IMG + r * 16u);
+      }
     }
   };
   auto store_chunk = [&]() {
@@ -157,10 +170,13 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_bf16_kernel(const FastArgs a
       for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0u;  // zero padding AFTER the transform
       if (it < NPIX * 4) *reinterpret_cast<u32x4*>(&in_tile[hp * BPIX + (q4 << 4)]) = v;
     }
+    if (!(w_resident && w_loaded)) {
 #pragma unroll
-    for (int q = 0; q < W_ITEMS; ++q) {
-      const int it = tid + q * kThreads;
-      if (it < NT * IMG / 16) *reinterpret_cast<u32x4*>(&w_tile[it * 16]) = reg_w[q];
+      for (int q = 0; q < W_ITEMS; ++q) {
+        const int it = tid + q * kThreads;
+        if (it < NT * IMG / 16) *reinterpret_cast<u32x4*>(&w_tile[it * 16]) = reg_w[q];
+      }
+      w_loaded = true;
     }
   };
   struct Frag {
@@ -178,7 +194,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_bf16_kernel(const FastArgs a
   };
 
   // Accumulator register r of lane (j, h): pixel 64*wave + 32*mt + 4h + c(r), c(r) = (r&3) + 8*(r>>2), column j.
-  auto epilogue = [&](long k) {
+  auto epilogue_stats = [&](long k) {
     const UnitGeom g = decode_unit<LOG2TW>(a, first_unit + k * unit_step);
     const bool interior = (g.ty0 + TH <= d.H) && (g.tx0 + TW <= d.W);
 #pragma unroll
@@ -247,7 +263,7 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_bf16_kernel(const FastArgs a
       if (d.stats_partial != nullptr) {
         s1 += __shfl_xor(s1, 32);
         s2sum += __shfl_xor(s2sum, 32);
-        float* wsc = reinterpret_cast<float*>(w_tile);  // weight tile as scratch (the input tile is transpose scratch)
+        float* wsc = stat_lds;
         if (h == 0) {
           wsc[(wave * 32 + j) * 2 + 0] = s1;
           wsc[(wave * 32 + j) * 2 + 1] = s2sum;
@@ -265,6 +281,84 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_bf16_kernel(const FastArgs a
           dst[1] = t2;
         }
         __syncthreads();
+      }
+    }
+  };
+
+  // ---- register-direct epilogue (swapped operands).  Register r of acc[t][mt] of lane (j, h): output column
+  // (r & 3) + 8 * (r >> 2) + 4 * h of pixel 64 * wave + 32 * mt + j. ----
+  auto epilogue_direct = [&](long k) {
+    const UnitGeom g = decode_unit<LOG2TW>(a, first_unit + k * unit_step);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const TileCols tc = decode_tile(a, g.group * NT + t);
+      const unetpp_view& O = d.out[tc.ov];
+      bf16_t* optr = reinterpret_cast<bf16_t*>(O.ptr);
+      const bf16_t* gptr = reinterpret_cast<const bf16_t*>(O.gate);
+      const long row_stride = static_cast<long>(O.sy) * O.Ws * O.C, col_stride = static_cast<long>(O.sx) * O.C;
+      const long tile_base = view_pixel_offset(O, g.n, g.ty0, g.tx0) + tc.nt * 32;
+      f32x4 b4[4];  // bias of this lane's four channel groups 8q + 4h .. + 3
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        b4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (d.bias != nullptr && 8 * q + 4 * h < tc.n_cnt) b4[q] = *reinterpret_cast<const f32x4*>(d.bias + tc.n0 + 8 * q + 4 * h);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int p = 64 * wave + 32 * mt + j;
+        const int py = p >> LOG2TW, px = p & (TW - 1);
+        const bool pix_ok = (g.ty0 + py < d.H) && (g.tx0 + px < d.W);
+        const long pbase = tile_base + py * row_stride + px * col_stride;
+        unsigned pk[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[t][mt][4 * q + e] + b4[q][e];
+            if (O.relu) v[e] = fmaxf(v[e], 0.f);
+            acc[t][mt][4 * q + e] = 0.f;
+          }
+          pk[q][0] = pack_bf2(v[0], v[1]);
+          pk[q][1] = pack_bf2(v[2], v[3]);
+        }
+        // groups (1, 0) and (3, 2): afterwards lane (j, 0) holds columns 8..15 / 24..31, lane (j, 1) columns 0..7 / 16..23
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          u32x4 out;
+#pragma unroll
+          for (int w2 = 0; w2 < 2; ++w2) {
+            const auto r = __builtin_amdgcn_permlane32_swap(pk[2 * half + 1][w2], pk[2 * half][w2], false, false);
+            out[w2] = r[0];
+            out[2 + w2] = r[1];
+          }
+          const int c0 = 16 * half + 8 * (1 - h);  // first column of this lane's 8
+          if (pix_ok && c0 < tc.n_cnt) {
+            const long off = pbase + c0;
+            if (gptr != nullptr || O.accumulate) {
+              float v[8];
+              unpack8(out, v);
+              float gt[8];
+              if (gptr != nullptr) unpack8(*reinterpret_cast<const u32x4*>(gptr + off), gt);
+              if (gptr != nullptr && !O.gate_sum) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (gt[e] > 0.f) ? v[e] : 0.f;
+              }
+              if (O.accumulate) {
+                float old[8];
+                unpack8(*reinterpret_cast<const u32x4*>(optr + off), old);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += old[e];
+              }
+              if (gptr != nullptr && O.gate_sum) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (gt[e] > 0.f) ? v[e] : 0.f;
+              }
+              out = pack8(v);
+            }
+            *reinterpret_cast<u32x4*>(optr + off) = out;
+          }
+        }
       }
     }
   };
@@ -305,23 +399,53 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_bf16_kernel(const FastArgs a
     }
     load_chunk();  // unconditional (the cursor stays on the last chunk)
     Frag cur = read_frag(0);
+#ifdef UNETPP_BF16_EXP_NO_MFMA
+    if (cur.a0[0] == 0x12345678u) acc[0][0][0] = 1.f;
+#else
 #pragma unroll
     for (int step = 0; step < TAPS * 2; ++step) {
       Frag nxt = cur;
       if (step + 1 < TAPS * 2) nxt = read_frag(step + 1);
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) {
-        acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.a0),
-                                                             __builtin_bit_cast(bf16x8, cur.b[ct]), acc[ct][0], 0, 0, 0);
-        acc[ct][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.a1),
-                                                             __builtin_bit_cast(bf16x8, cur.b[ct]), acc[ct][1], 0, 0, 0);
+        if constexpr (STATS) {
+          acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.a0),
+                                                               __builtin_bit_cast(bf16x8, cur.b[ct]), acc[ct][0], 0, 0, 0);
+          acc[ct][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.a1),
+                                                               __builtin_bit_cast(bf16x8, cur.b[ct]), acc[ct][1], 0, 0, 0);
+        } else {  // swapped roles: rows = output columns, columns = pixels (same fragments: see the lane maps)
+          acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.b[ct]),
+                                                               __builtin_bit_cast(bf16x8, cur.a0), acc[ct][0], 0, 0, 0);
+          acc[ct][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.b[ct]),
+                                                               __builtin_bit_cast(bf16x8, cur.a1), acc[ct][1], 0, 0, 0);
+        }
       }
       cur = nxt;
     }
+#endif
     __syncthreads();
     if (c_chunk + 1 == a.n_chunks) {
-      epilogue(c_unit);
-      __syncthreads();
+      // Collect the prefetched chunk BEFORE the epilogue issues its stores: vmcnt counts in order, so the wait hipcc puts
+      // in front of the next staging store would otherwise also wait for this unit's output to reach memory.
+#pragma unroll
+      for (int q = 0; q < IN_ITEMS; ++q) asm volatile("" : "+v"(reg_in[q]));
+#pragma unroll
+      for (int q = 0; q < W_ITEMS; ++q) asm volatile("" : "+v"(reg_w[q]));
+#ifndef UNETPP_BF16_EXP_NO_EPILOGUE  // experiment builds only (tools/README.md): where does a unit's time go
+      if constexpr (STATS) epilogue_stats(c_unit);
+      else epilogue_direct(c_unit);
+#else
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (acc[t][mt][r] == 123.456f) d.out[0].ptr[r] = 1.f;
+            acc[t][mt][r] = 0.f;
+          }
+#endif
+      if constexpr (STATS) __syncthreads();  // the transposing epilogue used the input tile as scratch
       ++c_unit;
       c_chunk = 0;
     } else {
@@ -338,6 +462,13 @@ __global__ __launch_bounds__(kThreads, 3) void gemm_bf16_kernel(const FastArgs a
 bool bf16_gemm_args(const unetpp_gemm_desc* d, FastArgs& a) {
   if (d == nullptr || (d->flags & UNETPP_GEMM_BF16) == 0) return false;
   if (!fast_args(d, a, BKC, 32)) return false;
+  // 3x3 launches without a statistics epilogue feed TWO column tiles from one staged input patch when they can
+  // (input gradients into several views, layers with >= 64 output channels)
+  if (d->taps == 9 && d->stats_partial == nullptr && a.n_tiles % 2 == 0) {
+    a.nt_unit = 2;
+    a.n_groups = a.n_tiles / 2;
+    a.total_blocks /= 2;
+  }
   for (int i = 0; i < d->n_in; ++i)
     if (!bf16_view_aligned(d->in[i])) return false;
   for (int i = 0; i < d->n_out; ++i)
@@ -353,18 +484,22 @@ int launch_gemm_bf16(const unetpp_gemm_desc* d, hipStream_t st) {
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     return UNETPP_ELAUNCH;
-  long workers = (3L * cus) & ~7L;
+  long workers = ((d->taps == 1 ? 4L : (a.nt_unit == 2 ? 2L : 3L)) * cus) & ~7L;  // = the kernels' launch bounds
   if (workers < 8) workers = 8;
   const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(kThreads);
-#define UNETPP_LAUNCH_BF16(T, NTU)                                                                      \
-  do {                                                                                                  \
-    if (a.log2tw == 5) hipLaunchKernelGGL((gemm_bf16_kernel<T, 5, NTU>), grid, block, 0, st, a);        \
-    else if (a.log2tw == 4) hipLaunchKernelGGL((gemm_bf16_kernel<T, 4, NTU>), grid, block, 0, st, a);   \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<T, 3, NTU>), grid, block, 0, st, a);                      \
+#define UNETPP_LAUNCH_BF16(T, NTU, ST)                                                                    \
+  do {                                                                                                    \
+    if (a.log2tw == 5) hipLaunchKernelGGL((gemm_bf16_kernel<T, 5, NTU, ST>), grid, block, 0, st, a);      \
+    else if (a.log2tw == 4) hipLaunchKernelGGL((gemm_bf16_kernel<T, 4, NTU, ST>), grid, block, 0, st, a); \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<T, 3, NTU, ST>), grid, block, 0, st, a);                    \
   } while (0)
-  if (d->taps == 9) UNETPP_LAUNCH_BF16(9, 1);
-  else if (a.nt_unit == 2) UNETPP_LAUNCH_BF16(1, 2);
-  else UNETPP_LAUNCH_BF16(1, 1);
+  const bool stats = d->stats_partial != nullptr;
+  if (d->taps == 9) {
+    if (stats) UNETPP_LAUNCH_BF16(9, 1, true);
+    else if (a.nt_unit == 2) UNETPP_LAUNCH_BF16(9, 2, false);
+    else UNETPP_LAUNCH_BF16(9, 1, false);
+  } else if (a.nt_unit == 2) UNETPP_LAUNCH_BF16(1, 2, false);
+  else UNETPP_LAUNCH_BF16(1, 1, false);
 #undef UNETPP_LAUNCH_BF16
   note_kernel(d->taps == 9 ? "gemm_bf16_kernel<9>" : "gemm_bf16_kernel<1>");
   return launch_status();
