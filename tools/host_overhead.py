@@ -7,8 +7,10 @@ from unet_nested4tiny_objects_keypoints_amd import UNet_Nested, FocalLoss_BCE_2d
 B = int(os.environ.get("B", "32")); S = int(os.environ.get("S", "256"))
 torch.manual_seed(0)
 m = UNet_Nested(1, 4, feature_scale=1).cuda().train()
+if os.environ.get("DTYPE") == "bf16":
+    m.set_activation_dtype(torch.bfloat16)
 x = torch.randn(B, 1, S, S, device="cuda"); t = torch.rand(B, 4, S, S, device="cuda")
-opt = torch.optim.Adam(m.parameters(), lr=1e-3); crit = FocalLoss_BCE_2d(3, size_average=False)
+opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=True); crit = FocalLoss_BCE_2d(3, size_average=False)
 for _ in range(3): train_step(m, opt, crit, x, t)
 torch.cuda.synchronize()
 host = []

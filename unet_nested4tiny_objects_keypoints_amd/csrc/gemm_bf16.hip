@@ -34,7 +34,7 @@ constexpr int BSTEP = 1024;    // bytes of one (tap, g) weight step: 32 columns 
 // v_permlane32_swap per register pair pairs the groups of lanes (j, 0) and (j, 1) into 8 consecutive channels, and
 // the tile leaves as two 16-byte stores per lane straight from registers -- no LDS round trip, no wave barriers.
 template <int TAPS, int LOG2TW, int NT, bool STATS>
-__global__ __launch_bounds__(kThreads, TAPS == 1 ? 4 : (NT == 2 ? 2 : 3)) void gemm_bf16_kernel(const FastArgs a) {
+__global__ __launch_bounds__(kThreads, (NT == 2 && TAPS == 9) ? 2 : 3) void gemm_bf16_kernel(const FastArgs a) {
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
   constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;
   constexpr int HWp = TW + 2 * HALO, HHp = TH + 2 * HALO;
@@ -484,7 +484,8 @@ int launch_gemm_bf16(const unetpp_gemm_desc* d, hipStream_t st) {
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     return UNETPP_ELAUNCH;
-  long workers = ((d->taps == 1 ? 4L : (a.nt_unit == 2 ? 2L : 3L)) * cus) & ~7L;  // = the kernels' launch bounds
+  // = the kernels' launch bounds (four workgroups per CU for the pointwise GEMMs: 128 VGPRs, spills, 2x slower)
+  long workers = ((d->taps == 9 && a.nt_unit == 2 ? 2L : 3L) * cus) & ~7L;
   if (workers < 8) workers = 8;
   const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(kThreads);
 #define UNETPP_LAUNCH_BF16(T, NTU, ST)                                                                    \
