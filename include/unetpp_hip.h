@@ -278,6 +278,27 @@ int unetpp_head_bwd_bf16(const float* d_out_nchw, const float* out_nchw, const v
                          const uint8_t* mask, void* dx, int32_t accumulate, int32_t gate_x, float* partial,
                          void* stream);
 
+/* ---- heat-map side of validation (tools/misc/heatmap.py; SURVEY 8 row f3 -- parity unpinned: the reference needs
+ * OpenCV, absent from the build image) ------------------------------------------------------------------------------
+ * unetpp_heatmap_pattern: Heatmap.create_heatmap (heatmap.py:203-230).  points [N, P, 2] as (x, y); map m draws the
+ * key points map_points[map_begin[m] .. map_begin[m+1]) (device int32 arrays, n_maps + 1 begins); out [N, n_maps, H, W]:
+ * float32 sum of exp(-0.5 * distance / radius) in pattern order, divided by the map's maximum. */
+int64_t unetpp_heatmap_pattern_workspace_bytes(int32_t N, int32_t n_maps, int32_t H, int32_t W);
+int unetpp_heatmap_pattern(const float* points, int32_t N, int32_t P, const int32_t* map_points,
+                           const int32_t* map_begin, int32_t n_maps, int32_t H, int32_t W, float radius,
+                           float* out_nchw, void* workspace, void* stream);
+/* unetpp_keypoints_extract: Heatmap.extract_points_ (heatmap.py:148-200) with 8-connected components of the region
+ * mask in place of the OpenCV watershed (heatmap.py:100-144).  heat [maps, H, W]; thr [maps] (device).  Three stages on
+ * one workspace: 0 = mask (values < thr zeroed, 3x3 median > 0) and label initialisation; 1 = `sweeps` rounds of label
+ * merging, *changed (device int32, zeroed by the caller) is set while labels still move: repeat until it stays 0;
+ * 2 = per-region maximum and selection: points [maps, num, 2] = (x, y) of the first pixel in raster order attaining the
+ * maximum of the num brightest regions (ties: raster order of the regions' first pixels), -1 where there are fewer;
+ * counts [maps] = regions found (results are only complete when counts <= max_regions). */
+int64_t unetpp_keypoints_workspace_bytes(int32_t maps, int32_t H, int32_t W, int32_t max_regions);
+int unetpp_keypoints_extract(int32_t stage, const float* heat, int32_t maps, int32_t H, int32_t W,
+                             const float* thr_per_map, int32_t num, int32_t max_regions, int32_t sweeps,
+                             void* workspace, int32_t* changed, float* points, int32_t* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

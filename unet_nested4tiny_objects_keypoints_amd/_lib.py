@@ -15,7 +15,7 @@ _REPO = os.path.dirname(_PKG_DIR)
 LIB_PATH = os.environ.get("UNETPP_LIB", os.path.join(_PKG_DIR, "libunetpp_hip.so"))  # override: kernel A/B runs
 CSRC = os.path.join(_PKG_DIR, "csrc")
 INCLUDE = os.path.join(_REPO, "include")
-SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_wino.hip", "gemm_bf16.hip", "wgrad_bf16.hip", "pointwise_bf16.hip", "weight_image.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "wgrad_wino.hip", "first_layer.hip", "pointwise.hip", "caller.hip")
+SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_wino.hip", "gemm_bf16.hip", "wgrad_bf16.hip", "pointwise_bf16.hip", "keypoints.hip", "weight_image.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "wgrad_wino.hip", "first_layer.hip", "pointwise.hip", "caller.hip")
 HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h", "lds_asm.h", "bf16_common.h", "dropout.h")
 MAX_VIEWS = 8
 ABI_VERSION = 5
@@ -126,6 +126,11 @@ SIGNATURES = {
     "unetpp_bn_bwd_reduce_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "unetpp_bn_bwd_apply_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "unetpp_head_fwd_bf16": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _P]),
+    # heat-map side of validation (keypoints.hip)
+    "unetpp_heatmap_pattern_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32]),
+    "unetpp_heatmap_pattern": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _I32, _I32, _F, _P, _P, _P]),
+    "unetpp_keypoints_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32]),
+    "unetpp_keypoints_extract": (C.c_int, [_I32, _P, _I32, _I32, _I32, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
     "unetpp_head_bwd_bf16": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _I32, _I32, _P, _P]),
 }
 

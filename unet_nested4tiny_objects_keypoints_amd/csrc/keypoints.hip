@@ -1,0 +1,263 @@
+// Heat-map side of validation on the device (/root/reference/tools/misc/heatmap.py):
+//   unetpp_heatmap_pattern     pattern-driven target maps (heatmap.py:203-230): per map the Gaussians
+//                              exp(-0.5 * distance / radius) of its key points summed in float32 (one rounding per
+//                              addition, in pattern order), divided by the map's maximum
+//   unetpp_keypoints_extract   heat map -> up to `num` (x, y) peaks per map (heatmap.py:148-200): values below the
+//                              threshold zeroed, 3x3 median > 0 as the region mask, one region per 8-connected component
+//                              of the mask, regions ordered by their maximum (descending, ties in raster order of the
+//                              region's first pixel), each reported at the first pixel in raster order that attains it.
+// The reference finds its regions with OpenCV (distance transform cores + watershed, heatmap.py:100-144), which also
+// splits blobs that touch; connected components give the same regions and peaks for separated blobs.  OpenCV is
+// absent from the build image, so this row is "parity unpinned": checked against oracle/keypoints_oracle.py only.
+//
+// All kernels are HBM/latency trivial (a 512x512 map is 1 MB); what matters is that the whole extraction stays on the
+// device: the reference moves every head output to the CPU and runs OpenCV per map (trainer/trainer.py:213-221).
+// Labels: label[p] = smallest raster index of p's component, by min-propagation over the 8 neighbours followed by
+// pointer jumping, iterated until a sweep changes nothing (device flag read by the host every few sweeps).  The only
+// atomics are atomicMin/atomicMax on integers (order independent: results are bitwise reproducible).
+#include "common.h"
+
+namespace unetpp {
+namespace {
+
+constexpr int kKpThreads = 256;
+
+// ---- pattern maps: thread = pixel, blockIdx.y = (image, map) ----
+__global__ __launch_bounds__(kKpThreads) void pattern_map_kernel(const float* __restrict__ points, int P,
+                                                                 const int* __restrict__ map_points,
+                                                                 const int* __restrict__ map_begin, int n_maps, int H,
+                                                                 int W, double radius, float* __restrict__ out,
+                                                                 float* __restrict__ blockmax) {
+  __shared__ float red[kKpThreads / 64];
+  const int n = blockIdx.y / n_maps, m = blockIdx.y % n_maps;
+  const long hw = static_cast<long>(H) * W;
+  const long i = blockIdx.x * static_cast<long>(kKpThreads) + threadIdx.x;
+  const float* pts = points + static_cast<long>(n) * P * 2;
+  float acc = 0.f;
+  if (i < hw) {
+    const double y = static_cast<double>(i / W), x = static_cast<double>(i % W);
+    for (int k = map_begin[m]; k < map_begin[m + 1]; ++k) {
+      const int p = map_points[k];
+      const double dx = x - static_cast<double>(pts[2 * p]), dy = y - static_cast<double>(pts[2 * p + 1]);
+      acc = static_cast<float>(static_cast<double>(acc) + exp(-0.5 * sqrt(dx * dx + dy * dy) / radius));
+    }
+    out[static_cast<long>(blockIdx.y) * hw + i] = acc;
+  }
+  float mx = acc;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    blockmax[static_cast<long>(blockIdx.y) * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(kKpThreads) void pattern_norm_kernel(int H, int W, float* __restrict__ out,
+                                                                  const float* __restrict__ blockmax) {
+  __shared__ float red[kKpThreads];
+  const long hw = static_cast<long>(H) * W;
+  float mx = 0.f;
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += kKpThreads)
+    mx = fmaxf(mx, blockmax[static_cast<long>(blockIdx.y) * gridDim.x + b]);
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = kKpThreads / 2; s >= 1; s >>= 1) {
+    if (static_cast<int>(threadIdx.x) < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  const long i = blockIdx.x * static_cast<long>(kKpThreads) + threadIdx.x;
+  if (i < hw) out[static_cast<long>(blockIdx.y) * hw + i] /= red[0];  // float32 / float32, as the reference's arrays
+}
+
+// ---- extraction.  Work buffers per map: label int32 [H*W], best uint64 [H*W]. ----
+__device__ __forceinline__ float thresholded(const float* heat, int H, int W, int y, int x, float thr) {
+  y = min(max(y, 0), H - 1);  // replicated border (cv2.medianBlur's BORDER_REPLICATE)
+  x = min(max(x, 0), W - 1);
+  const float v = heat[static_cast<long>(y) * W + x];
+  return v < thr ? 0.f : v;
+}
+
+// mask = (3x3 median of the thresholded map) > 0  <=>  at least 5 of the 9 window values are > 0; label = own index
+__global__ __launch_bounds__(kKpThreads) void kp_mask_kernel(const float* __restrict__ heat, int H, int W,
+                                                             const float* __restrict__ thr_per_map,
+                                                             int* __restrict__ label, unsigned long long* __restrict__ best) {
+  const long hw = static_cast<long>(H) * W;
+  const long i = blockIdx.x * static_cast<long>(kKpThreads) + threadIdx.x;
+  if (i >= hw) return;
+  const float* hm = heat + static_cast<long>(blockIdx.y) * hw;
+  const float thr = thr_per_map[blockIdx.y];
+  const int y = static_cast<int>(i / W), x = static_cast<int>(i % W);
+  int positive = 0;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) positive += thresholded(hm, H, W, y + dy, x + dx, thr) > 0.f ? 1 : 0;
+  label[static_cast<long>(blockIdx.y) * hw + i] = positive >= 5 ? static_cast<int>(i) : -1;
+  best[static_cast<long>(blockIdx.y) * hw + i] = 0ull;
+}
+
+// one sweep: every masked pixel pulls the smallest label of its 8 neighbours into its component's root
+__global__ __launch_bounds__(kKpThreads) void kp_merge_kernel(int H, int W, int* __restrict__ label, int* __restrict__ changed) {
+  const long hw = static_cast<long>(H) * W;
+  const long i = blockIdx.x * static_cast<long>(kKpThreads) + threadIdx.x;
+  if (i >= hw) return;
+  int* lab = label + static_cast<long>(blockIdx.y) * hw;
+  const int mine = lab[i];
+  if (mine < 0) return;
+  const int y = static_cast<int>(i / W), x = static_cast<int>(i % W);
+  int m = mine;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int yy = y + dy, xx = x + dx;
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+      const int l = lab[static_cast<long>(yy) * W + xx];
+      if (l >= 0 && l < m) m = l;
+    }
+  if (m < mine) {
+    atomicMin(&lab[mine], m);  // hook the old root under the smaller label
+    atomicMin(&lab[i], m);
+    *changed = 1;
+  }
+}
+
+// pointer jumping: every pixel points at its root
+__global__ __launch_bounds__(kKpThreads) void kp_flatten_kernel(int H, int W, int* __restrict__ label) {
+  const long hw = static_cast<long>(H) * W;
+  const long i = blockIdx.x * static_cast<long>(kKpThreads) + threadIdx.x;
+  if (i >= hw) return;
+  int* lab = label + static_cast<long>(blockIdx.y) * hw;
+  int l = lab[i];
+  if (l < 0) return;
+  while (lab[l] != l) l = lab[l];
+  lab[i] = l;
+}
+
+// per region: (maximum of the thresholded map, first raster index attaining it), packed so that a 64-bit max does both
+__global__ __launch_bounds__(kKpThreads) void kp_peak_kernel(const float* __restrict__ heat, int H, int W,
+                                                             const float* __restrict__ thr_per_map,
+                                                             const int* __restrict__ label, unsigned long long* __restrict__ best) {
+  const long hw = static_cast<long>(H) * W;
+  const long i = blockIdx.x * static_cast<long>(kKpThreads) + threadIdx.x;
+  if (i >= hw) return;
+  const int l = label[static_cast<long>(blockIdx.y) * hw + i];
+  if (l < 0) return;
+  float v = heat[static_cast<long>(blockIdx.y) * hw + i];
+  if (v < thr_per_map[blockIdx.y]) v = 0.f;  // the median mask may cover zeroed pixels
+  const unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(v)) << 32) |
+                                 static_cast<unsigned long long>(0xFFFFFFFFu - static_cast<unsigned>(i));
+  atomicMax(&best[static_cast<long>(blockIdx.y) * hw + l], key);
+}
+
+// one workgroup per map: gather the roots, rank them by (peak descending, root index ascending), write the first `num`
+__global__ __launch_bounds__(1024) void kp_select_kernel(int H, int W, const int* __restrict__ label,
+                                                         const unsigned long long* __restrict__ best, int num,
+                                                         int max_regions, unsigned long long* __restrict__ cand,
+                                                         float* __restrict__ points, int* __restrict__ counts) {
+  __shared__ int n_cand;
+  const long hw = static_cast<long>(H) * W;
+  const int* lab = label + static_cast<long>(blockIdx.x) * hw;
+  const unsigned long long* bst = best + static_cast<long>(blockIdx.x) * hw;
+  unsigned long long* cd = cand + static_cast<long>(blockIdx.x) * max_regions * 2;  // (peak key, root)
+  if (threadIdx.x == 0) n_cand = 0;
+  __syncthreads();
+  for (long i = threadIdx.x; i < hw; i += blockDim.x) {
+    if (lab[i] == static_cast<int>(i)) {
+      const int slot = atomicAdd(&n_cand, 1);
+      if (slot < max_regions) {
+        cd[2 * slot] = bst[i];
+        cd[2 * slot + 1] = static_cast<unsigned long long>(i);
+      }
+    }
+  }
+  __syncthreads();
+  const int total = n_cand;
+  const int n = min(total, max_regions);
+  float* out = points + static_cast<long>(blockIdx.x) * num * 2;
+  for (int k = threadIdx.x; k < num * 2; k += blockDim.x) out[k] = -1.f;
+  __syncthreads();
+  for (int c = threadIdx.x; c < n; c += blockDim.x) {
+    const unsigned peak = static_cast<unsigned>(cd[2 * c] >> 32);
+    const unsigned long long root = cd[2 * c + 1];
+    int rank = 0;
+    for (int o = 0; o < n; ++o) {
+      const unsigned po = static_cast<unsigned>(cd[2 * o] >> 32);
+      if (po > peak || (po == peak && cd[2 * o + 1] < root)) ++rank;
+    }
+    if (rank < num) {
+      // (a region whose thresholded values are all zero: the reference's np.where(map == 0) then finds the first zero
+      // of the WHOLE map, pixel 0 -- heatmap.py:168-170)
+      const unsigned idx = peak == 0u ? 0u : 0xFFFFFFFFu - static_cast<unsigned>(cd[2 * c] & 0xFFFFFFFFull);
+      out[2 * rank] = static_cast<float>(idx % static_cast<unsigned>(W));      // x
+      out[2 * rank + 1] = static_cast<float>(idx / static_cast<unsigned>(W));  // y
+    }
+  }
+  if (threadIdx.x == 0) counts[blockIdx.x] = total;  // regions found (may exceed max_regions: the caller checks)
+}
+
+}  // namespace
+}  // namespace unetpp
+
+using namespace unetpp;
+
+extern "C" int64_t unetpp_heatmap_pattern_workspace_bytes(int32_t N, int32_t n_maps, int32_t H, int32_t W) {
+  if (N < 1 || n_maps < 1 || H < 1 || W < 1) return 0;
+  const int64_t blocks = (static_cast<int64_t>(H) * W + kKpThreads - 1) / kKpThreads;
+  return static_cast<int64_t>(N) * n_maps * blocks * 4;
+}
+
+extern "C" int unetpp_heatmap_pattern(const float* points, int32_t N, int32_t P, const int32_t* map_points,
+                                      const int32_t* map_begin, int32_t n_maps, int32_t H, int32_t W, float radius,
+                                      float* out_nchw, void* workspace, void* stream) {
+  if (!points || !map_points || !map_begin || !out_nchw || !workspace) return UNETPP_EINVAL;
+  if (N < 1 || P < 1 || n_maps < 1 || H < 1 || W < 1 || !(radius > 0.f) || static_cast<long>(N) * n_maps > 65535)
+    return UNETPP_EINVAL;
+  const unsigned blocks = static_cast<unsigned>((static_cast<long>(H) * W + kKpThreads - 1) / kKpThreads);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* blockmax = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(pattern_map_kernel, dim3(blocks, N * n_maps), dim3(kKpThreads), 0, st, points, P, map_points, map_begin,
+                     n_maps, H, W, static_cast<double>(radius), out_nchw, blockmax);
+  hipLaunchKernelGGL(pattern_norm_kernel, dim3(blocks, N * n_maps), dim3(kKpThreads), 0, st, H, W, out_nchw, blockmax);
+  return launch_status();
+}
+
+extern "C" int64_t unetpp_keypoints_workspace_bytes(int32_t maps, int32_t H, int32_t W, int32_t max_regions) {
+  if (maps < 1 || H < 1 || W < 1 || max_regions < 1) return 0;
+  const int64_t hw = static_cast<int64_t>(H) * W;
+  return static_cast<int64_t>(maps) * (hw * 4 + hw * 8 + static_cast<int64_t>(max_regions) * 16) + 64;
+}
+
+// stage 0: mask + labels initialised; stage 1: `sweeps` merge + flatten sweeps (sets *changed when a sweep moved a
+// label: the caller repeats stage 1 until it stays 0); stage 2: peaks + selection.  heat [maps, H, W]; thr [maps];
+// points [maps, num, 2] as (x, y), -1 where there is no region; counts [maps] = regions found.
+extern "C" int unetpp_keypoints_extract(int32_t stage, const float* heat, int32_t maps, int32_t H, int32_t W,
+                                        const float* thr_per_map, int32_t num, int32_t max_regions, int32_t sweeps,
+                                        void* workspace, int32_t* changed, float* points, int32_t* counts, void* stream) {
+  if (!heat || !thr_per_map || !workspace || maps < 1 || maps > 65535 || H < 1 || W < 1 || num < 1 || max_regions < num ||
+      static_cast<long>(H) * W >= 0x7fffffffL)
+    return UNETPP_EINVAL;
+  const long hw = static_cast<long>(H) * W;
+  unsigned long long* best = static_cast<unsigned long long*>(workspace);  // 8-byte aligned first
+  unsigned long long* cand = best + static_cast<long>(maps) * hw;
+  int* label = reinterpret_cast<int*>(cand + static_cast<long>(maps) * max_regions * 2);
+  const dim3 grid(static_cast<unsigned>((hw + kKpThreads - 1) / kKpThreads), static_cast<unsigned>(maps));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (stage == 0) {
+    hipLaunchKernelGGL(kp_mask_kernel, grid, dim3(kKpThreads), 0, st, heat, H, W, thr_per_map, label, best);
+  } else if (stage == 1) {
+    if (!changed || sweeps < 1) return UNETPP_EINVAL;
+    for (int s = 0; s < sweeps; ++s) {
+      hipLaunchKernelGGL(kp_merge_kernel, grid, dim3(kKpThreads), 0, st, H, W, label, changed);
+      hipLaunchKernelGGL(kp_flatten_kernel, grid, dim3(kKpThreads), 0, st, H, W, label);
+    }
+  } else if (stage == 2) {
+    if (!points || !counts) return UNETPP_EINVAL;
+    hipLaunchKernelGGL(kp_peak_kernel, grid, dim3(kKpThreads), 0, st, heat, H, W, thr_per_map, label, best);
+    hipLaunchKernelGGL(kp_select_kernel, dim3(static_cast<unsigned>(maps)), dim3(1024), 0, st, H, W, label, best, num,
+                       max_regions, cand, points, counts);
+  } else {
+    return UNETPP_EINVAL;
+  }
+  return launch_status();
+}

@@ -577,3 +577,72 @@ def create_heatmap(points: torch.Tensor, height: int, width: int, radius: float 
     check(lib.unetpp_create_heatmap(_ptr(points), n, p, height, width, float(radius), _ptr(out), _ptr(ws), _stream()),
           "unetpp_create_heatmap")
     return out
+
+
+def heatmap_pattern(points: torch.Tensor, pattern, height: int, width: int, radius: float = 3.0) -> torch.Tensor:
+    """points [N, P, 2] (x, y) fp32 on the GPU, pattern = list of lists of key-point indices -> [N, len(pattern), H, W]
+    (tools/misc/heatmap.py:203-230)."""
+    lib = _lib.lib()
+    _need(points, "points")
+    if points.dim() != 3 or points.shape[2] != 2:
+        raise ValueError("points must be [N, P, 2]")
+    n, p = points.shape[0], points.shape[1]
+    flat = [i for hmap in pattern for i in hmap]
+    if not flat or min(flat) < 0 or max(flat) >= p or any(len(h) == 0 for h in pattern):
+        raise ValueError("pattern indexes key points 0..%d, every map needs at least one" % (p - 1))
+    begins = [0]
+    for hmap in pattern:
+        begins.append(begins[-1] + len(hmap))
+    mp = torch.tensor(flat, dtype=torch.int32, device=points.device)
+    mb = torch.tensor(begins, dtype=torch.int32, device=points.device)
+    out = torch.empty(n, len(pattern), height, width, dtype=torch.float32, device=points.device)
+    ws = torch.empty(int(lib.unetpp_heatmap_pattern_workspace_bytes(n, len(pattern), height, width)), dtype=torch.uint8,
+                     device=points.device)
+    check(lib.unetpp_heatmap_pattern(_ptr(points), n, p, _ptr(mp), _ptr(mb), len(pattern), height, width, float(radius),
+                                     _ptr(out), _ptr(ws), _stream()), "unetpp_heatmap_pattern")
+    return out
+
+
+def keypoints_extract(heat: torch.Tensor, num: int, threshold: float = 0.5, max_regions: int = 4096):
+    """heat [maps, H, W] fp32 on the GPU -> (points [maps, num, 2] as (x, y), -1 padded; counts [maps] regions found).
+    tools/misc/heatmap.py:148-200 with connected components as the region step; a map without any region is retried
+    once at 0.9 * threshold (heatmap.py:176-198)."""
+    lib = _lib.lib()
+    _need(heat, "heat")
+    if heat.dim() != 3:
+        raise ValueError("heat must be [maps, H, W]")
+    maps, h, w = heat.shape
+    dev = heat.device
+    ws = torch.empty(int(lib.unetpp_keypoints_workspace_bytes(maps, h, w, max_regions)), dtype=torch.uint8, device=dev)
+    changed = torch.zeros(1, dtype=torch.int32, device=dev)
+    points = torch.empty(maps, num, 2, dtype=torch.float32, device=dev)
+    counts = torch.empty(maps, dtype=torch.int32, device=dev)
+    thr = torch.full((maps,), float(threshold), dtype=torch.float32, device=dev)
+
+    def run():
+        st = _stream()
+        args = (_ptr(heat), maps, h, w, _ptr(thr), num, max_regions)
+        check(lib.unetpp_keypoints_extract(0, *args, 1, _ptr(ws), _ptr(changed), _ptr(points), _ptr(counts), st), "keypoints mask")
+        for _ in range(4 * (h + w)):  # a sweep moves a label at least one pixel: bounded, and normally 2-3 batches
+            changed.zero_()
+            check(lib.unetpp_keypoints_extract(1, *args, 4, _ptr(ws), _ptr(changed), _ptr(points), _ptr(counts), st),
+                  "keypoints merge")
+            if int(changed.item()) == 0:
+                break
+        else:
+            raise RuntimeError("keypoints_extract: label propagation did not converge")
+        check(lib.unetpp_keypoints_extract(2, *args, 1, _ptr(ws), _ptr(changed), _ptr(points), _ptr(counts), st), "keypoints select")
+
+    run()
+    host_counts = counts.cpu()
+    if int((host_counts == 0).sum()) > 0:  # retry the empty maps at 0.9 * threshold; the others keep their result
+        keep_points, keep_counts = points.clone(), counts.clone()
+        empty = (counts == 0)
+        thr = torch.where(empty, thr * 0.9, thr)
+        run()
+        points = torch.where(empty.view(-1, 1, 1), points, keep_points)
+        counts = torch.where(empty, counts, keep_counts)
+        host_counts = counts.cpu()
+    if int(host_counts.max()) > max_regions:
+        raise RuntimeError("keypoints_extract: more than max_regions=%d regions in a map" % max_regions)
+    return points, counts
