@@ -23,6 +23,22 @@
 namespace unetpp {
 namespace {
 
+// In-kernel phase stamps (profiling builds only: -DUNETPP_BF16_STAMPS, tools/gbf_stamps.py): wave 0 of every workgroup adds
+// the cycles it spent in each phase of its (unit, chunk) stream to a global table.
+#ifdef UNETPP_BF16_STAMPS
+__device__ unsigned long long g_gbf_stamps[16];
+#define GBF_STAMP(i)                           \
+  do {                                         \
+    const unsigned long long now_ = clock64(); \
+    st_acc[i] += now_ - st_last;               \
+    st_last = now_;                            \
+  } while (0)
+#else
+#define GBF_STAMP(i) \
+  do {               \
+  } while (0)
+#endif
+
 constexpr int BKC = 32;        // channels per K chunk
 constexpr int BPIX = 80;       // LDS bytes per staged pixel (64 + 16 pad)
 constexpr int BSTEP = 1024;    // bytes of one (tap, g) weight step: 32 columns x 16 k x 2 B
@@ -54,9 +70,41 @@ __global__ __launch_bounds__(kThreads, (NT == 2 && TAPS == 9) ? 2 : 3) void gemm
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
 
-  const UnitRange ur = my_unit_range(a.total_blocks);
-  const long first_unit = ur.first, unit_step = ur.step, my_units = ur.count;
+  // A workgroup walks a CONTIGUOUS run of units (column group fastest, then the patch along x, y, image): both cursors
+  // (prefetch side, compute side) are decoded once and then stepped with scalar adds and compares -- at bf16 MFMA speed
+  // the divisions and 64-bit multiplies of a per-unit decode (150 integer multiplies per unit, quarter rate) cost
+  // more issue time than the unit's 36 MFMAs.
+  // (The pointwise GEMMs of the transposed convolutions keep the round-robin order inside an XCD: their units are
+  // short and write four strided phase views; contiguous runs made them 1.3x slower.)
+  constexpr bool CONTIG = TAPS == 9;
+  const UnitRange ur = CONTIG ? my_contiguous_unit_range(a.total_blocks) : my_unit_range(a.total_blocks);
+  const long my_units = ur.count;
   if (my_units == 0) return;
+  long p_index = ur.first, c_index = ur.first;  // round-robin mode: the cursors' unit indices
+  auto step_unit = [&](UnitGeom& u, long& index) {
+    if constexpr (!CONTIG) {
+      index += ur.step;
+      u = decode_unit<LOG2TW>(a, index);
+      return;
+    }
+    if (++u.group < a.n_groups) return;
+    u.group = 0;
+    ++u.patch;
+    u.tx0 += TW;
+    if (u.tx0 < a.tiles_x * TW) return;
+    u.tx0 = 0;
+    u.ty0 += TH;
+    if (u.ty0 < a.tiles_y * TH) return;
+    u.ty0 = 0;
+    ++u.n;
+  };
+  UnitGeom p_ug = decode_unit<LOG2TW>(a, ur.first);
+  p_ug.n = __builtin_amdgcn_readfirstlane(p_ug.n);
+  p_ug.ty0 = __builtin_amdgcn_readfirstlane(p_ug.ty0);
+  p_ug.tx0 = __builtin_amdgcn_readfirstlane(p_ug.tx0);
+  p_ug.group = __builtin_amdgcn_readfirstlane(p_ug.group);
+  p_ug.patch = __builtin_amdgcn_readfirstlane(static_cast<int>(p_ug.patch));  // < 2^31 (fast_args)
+  UnitGeom c_ug = p_ug;
 
   int apix[2];
 #pragma unroll
@@ -89,28 +137,50 @@ __global__ __launch_bounds__(kThreads, (NT == 2 && TAPS == 9) ? 2 : 3) void gemm
   const bool w_resident = a.n_chunks == 1 && a.n_groups == 1;
   bool w_loaded = false;
 
-  auto prefetch_unit = [&](long k) {
-    const UnitGeom g = decode_unit<LOG2TW>(a, first_unit + k * unit_step);
+  // Per-thread constants of the staging items: halo coordinates and validity (the patch shape is a template parameter).
+  // Interior patches (all but the image border) need no clamping and no bounds mask: an item's offset is the patch
+  // origin (wave uniform) plus (hy * row stride + hx * column stride) of the view -- a unit's MFMAs take 0.5 us per wave,
+  // so the ~250 instructions of per-item clamping and index arithmetic per unit were a third of its instruction stream.
+  int item_hy[IN_ITEMS], item_hx[IN_ITEMS];
+  unsigned item_valid = 0;
+#pragma unroll
+  for (int q = 0; q < IN_ITEMS; ++q) {
+    const int it = tid + q * kThreads;
+    const int hp = min(it >> 2, NPIX - 1);
+    item_hy[q] = hp / HWp;
+    item_hx[q] = hp - item_hy[q] * HWp;
+    if (it < NPIX * 4) item_valid |= 1u << q;
+  }
+  bool p_interior = false;
+  auto prefetch_unit = [&]() {  // geometry of the unit under the prefetch cursor
+    const UnitGeom& g = p_ug;
     p_n = g.n;
     p_ty0 = g.ty0;
     p_tx0 = g.tx0;
     p_wimg = wimg_base + static_cast<long>(g.group) * NT * a.n_chunks * IMG;
+    p_interior = p_ty0 >= HALO && p_tx0 >= HALO && p_ty0 + TH + HALO <= d.H && p_tx0 + TW + HALO <= d.W;  // uniform
+    if (p_interior) {
+      in_mask = item_valid;
+      return;
+    }
     in_mask = 0;
 #pragma unroll
     for (int q = 0; q < IN_ITEMS; ++q) {
-      const int it = tid + q * kThreads;
-      const int hp = it >> 2;
-      const int hy = hp / HWp, hx = hp - hy * HWp;
-      const int y = p_ty0 + hy - HALO, x = p_tx0 + hx - HALO;
-      if ((it < NPIX * 4) && y >= 0 && y < d.H && x >= 0 && x < d.W) in_mask |= 1u << q;
+      const int y = p_ty0 + item_hy[q] - HALO, x = p_tx0 + item_hx[q] - HALO;
+      if (((item_valid >> q) & 1u) && y >= 0 && y < d.H && x >= 0 && x < d.W) in_mask |= 1u << q;
     }
   };
-  auto view_offsets = [&](const unetpp_view& V) {  // clamped: every item loads from a valid address
+  auto view_offsets = [&](const unetpp_view& V) {  // every item loads from a valid address (clamped on border patches)
+    if (p_interior) {
+      const unsigned origin = view_pixel_offset32(V, p_n, p_ty0 - HALO, p_tx0 - HALO);
+      const unsigned rs = static_cast<unsigned>(V.sy) * V.Ws * V.C, cs = static_cast<unsigned>(V.sx) * V.C;
+#pragma unroll
+      for (int q = 0; q < IN_ITEMS; ++q) voff[q] = origin + static_cast<unsigned>(item_hy[q]) * rs + static_cast<unsigned>(item_hx[q]) * cs;
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < IN_ITEMS; ++q) {
-      const int hp = min((tid + q * kThreads) >> 2, NPIX - 1);
-      const int hy = hp / HWp, hx = hp - hy * HWp;
-      const int yy = min(max(p_ty0 + hy - HALO, 0), d.H - 1), xx = min(max(p_tx0 + hx - HALO, 0), d.W - 1);
+      const int yy = min(max(p_ty0 + item_hy[q] - HALO, 0), d.H - 1), xx = min(max(p_tx0 + item_hx[q] - HALO, 0), d.W - 1);
       voff[q] = static_cast<unsigned>(view_pixel_offset(V, p_n, yy, xx));
     }
   };
@@ -194,8 +264,8 @@ __global__ __launch_bounds__(kThreads, (NT == 2 && TAPS == 9) ? 2 : 3) void gemm
   };
 
   // Accumulator register r of lane (j, h): pixel 64*wave + 32*mt + 4h + c(r), c(r) = (r&3) + 8*(r>>2), column j.
-  auto epilogue_stats = [&](long k) {
-    const UnitGeom g = decode_unit<LOG2TW>(a, first_unit + k * unit_step);
+  auto epilogue_stats = [&]() {
+    const UnitGeom& g = c_ug;
     const bool interior = (g.ty0 + TH <= d.H) && (g.tx0 + TW <= d.W);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -285,18 +355,27 @@ __global__ __launch_bounds__(kThreads, (NT == 2 && TAPS == 9) ? 2 : 3) void gemm
     }
   };
 
+  int epi_py[2], epi_px[2];  // patch coordinates of this lane's pixel in the two MFMA pixel tiles (swapped epilogue)
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int p = 64 * wave + 32 * mt + j;
+    epi_py[mt] = p >> LOG2TW;
+    epi_px[mt] = p & (TW - 1);
+  }
   // ---- register-direct epilogue (swapped operands).  Register r of acc[t][mt] of lane (j, h): output column
   // (r & 3) + 8 * (r >> 2) + 4 * h of pixel 64 * wave + 32 * mt + j. ----
-  auto epilogue_direct = [&](long k) {
-    const UnitGeom g = decode_unit<LOG2TW>(a, first_unit + k * unit_step);
+  auto epilogue_direct = [&]() {
+    const UnitGeom& g = c_ug;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const TileCols tc = decode_tile(a, g.group * NT + t);
       const unetpp_view& O = d.out[tc.ov];
       bf16_t* optr = reinterpret_cast<bf16_t*>(O.ptr);
       const bf16_t* gptr = reinterpret_cast<const bf16_t*>(O.gate);
-      const long row_stride = static_cast<long>(O.sy) * O.Ws * O.C, col_stride = static_cast<long>(O.sx) * O.C;
-      const long tile_base = view_pixel_offset(O, g.n, g.ty0, g.tx0) + tc.nt * 32;
+      // 32-bit element offsets (fast_args: every tensor < 2^31 elements); the lane's pixel coordinates are constants
+      const unsigned row_stride = static_cast<unsigned>(O.sy) * O.Ws * O.C, col_stride = static_cast<unsigned>(O.sx) * O.C;
+      const unsigned tile_base = view_pixel_offset32(O, g.n, g.ty0, g.tx0) + tc.nt * 32;
+      const bool rmw = gptr != nullptr || O.accumulate;  // uniform
       f32x4 b4[4];  // bias of this lane's four channel groups 8q + 4h .. + 3
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -305,10 +384,9 @@ __global__ __launch_bounds__(kThreads, (NT == 2 && TAPS == 9) ? 2 : 3) void gemm
       }
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        const int p = 64 * wave + 32 * mt + j;
-        const int py = p >> LOG2TW, px = p & (TW - 1);
+        const int py = epi_py[mt], px = epi_px[mt];
         const bool pix_ok = (g.ty0 + py < d.H) && (g.tx0 + px < d.W);
-        const long pbase = tile_base + py * row_stride + px * col_stride;
+        const unsigned pbase = tile_base + static_cast<unsigned>(py) * row_stride + static_cast<unsigned>(px) * col_stride;
         unsigned pk[4][2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -333,8 +411,11 @@ __global__ __launch_bounds__(kThreads, (NT == 2 && TAPS == 9) ? 2 : 3) void gemm
             out[2 + w2] = r[1];
           }
           const int c0 = 16 * half + 8 * (1 - h);  // first column of this lane's 8
-          if (pix_ok && c0 < tc.n_cnt) {
-            const long off = pbase + c0;
+          if (!rmw) {  // plain store: a path of its own, without loads -- hipcc puts a vmcnt(0) in front of a store whose
+                       // value MAY come from a load, and with in-order vmcnt that waits for the previous store to land
+            if (pix_ok && c0 < tc.n_cnt) *reinterpret_cast<u32x4*>(optr + pbase + c0) = out;
+          } else if (pix_ok && c0 < tc.n_cnt) {
+            const unsigned off = pbase + c0;
             if (gptr != nullptr || O.accumulate) {
               float v[8];
               unpack8(out, v);
@@ -363,7 +444,7 @@ __global__ __launch_bounds__(kThreads, (NT == 2 && TAPS == 9) ? 2 : 3) void gemm
     }
   };
 
-  prefetch_unit(0);
+  prefetch_unit();
   view_offsets(d.in[0]);
   load_chunk();
   store_chunk();
@@ -371,7 +452,13 @@ __global__ __launch_bounds__(kThreads, (NT == 2 && TAPS == 9) ? 2 : 3) void gemm
 
   long c_unit = 0;
   int c_chunk = 0;
+#ifdef UNETPP_BF16_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = clock64();
+  unsigned long long n_chunks_done = 0;
+#endif
   while (true) {
+    GBF_STAMP(0);  // 0: loop bookkeeping / prologue
     bool more = true;
     {
       int s2 = p_s, c2 = p_c0 + BKC;
@@ -391,13 +478,15 @@ __global__ __launch_bounds__(kThreads, (NT == 2 && TAPS == 9) ? 2 : 3) void gemm
         p_chunk = 0;
         p_s = 0;
         p_c0 = 0;
-        prefetch_unit(p_unit);
+        step_unit(p_ug, p_index);
+        prefetch_unit();
         view_offsets(d.in[0]);
       } else {
         more = false;
       }
     }
     load_chunk();  // unconditional (the cursor stays on the last chunk)
+    GBF_STAMP(1);  // 1: cursor advance (unit decode, offsets) + load issue
     Frag cur = read_frag(0);
 #ifdef UNETPP_BF16_EXP_NO_MFMA
     if (cur.a0[0] == 0x12345678u) acc[0][0][0] = 1.f;
@@ -423,7 +512,9 @@ __global__ __launch_bounds__(kThreads, (NT == 2 && TAPS == 9) ? 2 : 3) void gemm
       cur = nxt;
     }
 #endif
+    GBF_STAMP(2);  // 2: LDS fragment reads + MFMAs
     __syncthreads();
+    GBF_STAMP(3);  // 3: barrier after the MFMA loop
     if (c_chunk + 1 == a.n_chunks) {
       // Collect the prefetched chunk BEFORE the epilogue issues its stores: vmcnt counts in order, so the wait hipcc puts
       // in front of the next staging store would otherwise also wait for this unit's output to reach memory.
@@ -431,9 +522,10 @@ __global__ __launch_bounds__(kThreads, (NT == 2 && TAPS == 9) ? 2 : 3) void gemm
       for (int q = 0; q < IN_ITEMS; ++q) asm volatile("" : "+v"(reg_in[q]));
 #pragma unroll
       for (int q = 0; q < W_ITEMS; ++q) asm volatile("" : "+v"(reg_w[q]));
+      GBF_STAMP(4);  // 4: wait for the prefetched loads
 #ifndef UNETPP_BF16_EXP_NO_EPILOGUE  // experiment builds only (tools/README.md): where does a unit's time go
-      if constexpr (STATS) epilogue_stats(c_unit);
-      else epilogue_direct(c_unit);
+      if constexpr (STATS) epilogue_stats();
+      else epilogue_direct();
 #else
 #pragma unroll
       for (int t = 0; t < NT; ++t)
@@ -446,18 +538,45 @@ __global__ __launch_bounds__(kThreads, (NT == 2 && TAPS == 9) ? 2 : 3) void gemm
           }
 #endif
       if constexpr (STATS) __syncthreads();  // the transposing epilogue used the input tile as scratch
+      GBF_STAMP(5);  // 5: epilogue
+      step_unit(c_ug, c_index);
       ++c_unit;
       c_chunk = 0;
     } else {
       ++c_chunk;
     }
+#ifdef UNETPP_BF16_STAMPS
+    ++n_chunks_done;
+#endif
     if (!more) break;
     store_chunk();
+    GBF_STAMP(6);  // 6: staging stores (waits for the loads when no epilogue collected them)
     __syncthreads();
+    GBF_STAMP(7);  // 7: barrier after the staging stores
   }
+#ifdef UNETPP_BF16_STAMPS
+  if (tid == 0) {
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_gbf_stamps[i], st_acc[i]);
+    atomicAdd(&g_gbf_stamps[8], n_chunks_done);
+    atomicAdd(&g_gbf_stamps[9], static_cast<unsigned long long>(my_units));
+    atomicAdd(&g_gbf_stamps[10], 1ull);
+  }
+#endif
 }
 
 }  // namespace
+
+#ifdef UNETPP_BF16_STAMPS
+extern "C" int unetpp_debug_gbf_stamps(unsigned long long* out16, int reset) {  // profiling builds only
+  if (out16 != nullptr && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_gbf_stamps), sizeof(g_gbf_stamps)) != hipSuccess)
+    return UNETPP_ELAUNCH;
+  if (reset) {
+    const unsigned long long zero[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_gbf_stamps), zero, sizeof(zero)) != hipSuccess) return UNETPP_ELAUNCH;
+  }
+  return UNETPP_OK;
+}
+#endif
 
 bool bf16_gemm_args(const unetpp_gemm_desc* d, FastArgs& a) {
   if (d == nullptr || (d->flags & UNETPP_GEMM_BF16) == 0) return false;
