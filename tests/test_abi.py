@@ -107,3 +107,20 @@ def test_product_never_imports_the_oracle():
         if fn.endswith(".py"):
             text = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), fn
+
+
+def test_clean_build_from_sources(tmp_path):
+    """`build()` returns early when the in-tree .so is newer than its sources, so the shipped binary is
+    what normally runs.  Force a from-scratch hipcc build of every source into a temporary directory and check that the
+    result is a complete library: same ABI version, gfx950, every symbol of the argtypes table."""
+    import ctypes as C
+
+    from unet_nested4tiny_objects_keypoints_amd import _lib
+    out = _lib.build_library(force=True, out_path=str(tmp_path / "libunetpp_clean.so"), obj_dir=str(tmp_path / "obj"))
+    handle = C.CDLL(out)
+    handle.unetpp_abi_version.restype = C.c_int
+    handle.unetpp_build_arch.restype = C.c_char_p
+    assert handle.unetpp_abi_version() == _lib.ABI_VERSION
+    assert handle.unetpp_build_arch() == b"gfx950"
+    for name in _lib.SIGNATURES:
+        getattr(handle, name)  # AttributeError if a source file dropped out of the build

@@ -469,6 +469,47 @@ def test_head_dropout_generator_is_consistent(dev):
     assert not torch.equal(o, o2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_head_dropout_generator_independence(dev, dtype):
+    """one splitmix64 hash per 4 channels gives four 16-bit uniforms.  The keep flags must be
+    Bernoulli(0.6) per channel position of the quad, uncorrelated between the channels of a quad, between neighbouring
+    pixels, and between the seeds the three heads use (engine._dropout_config: base + odd constant * head)."""
+    from unet_nested4tiny_objects_keypoints_amd import ops
+    b, h, w, c, ncls = 2, 96, 96, 32, 4
+    x = torch.ones(b, h, w, c, device=dev, dtype=dtype)
+    wt = torch.zeros(ncls, c, device=dev)
+    bias = torch.zeros(ncls, device=dev)
+    o = torch.zeros(b, ncls, h, w, device=dev)
+
+    def mask_of(seed):  # backward regenerates the mask: dx != 0 exactly where the element was kept (W = 1 for class 0)
+        wt.zero_()
+        wt[0] = 1.0
+        ops.head_fwd(x, wt, bias, 0.4, seed, None, o)
+        dx = torch.empty_like(x)
+        ops.head_bwd(torch.ones_like(o), o, x, wt, 0.4, seed, None, dx, False)
+        return (dx.float() != 0).float().view(-1, c)
+
+    base = 0x1234567
+    seeds = [(base + 0x632BE59BD9B4E019 * (j + 1)) & 0xFFFFFFFFFFFFFFFF for j in range(3)]
+    masks = [mask_of(s) for s in seeds]
+    n = masks[0].shape[0]
+    sigma = (0.6 * 0.4 / n) ** 0.5
+    for m in masks:
+        rate = m.mean(0)                                    # per channel: each of the 4 positions of every quad
+        assert float((rate - 0.6).abs().max()) < 5 * sigma, rate
+        centred = m - 0.6
+        cov = (centred.t() @ centred) / n / 0.24            # correlation matrix of the 32 channels
+        off = cov - torch.diag(torch.diag(cov))
+        assert float(off.abs().max()) < 5 / n ** 0.5, float(off.abs().max())       # incl. channels of one quad
+        img = m.view(b, h, w, c)
+        horiz = ((img[:, :, 1:] - 0.6) * (img[:, :, :-1] - 0.6)).mean() / 0.24      # neighbouring pixels
+        assert abs(float(horiz)) < 5 / (n * c) ** 0.5
+    for i in range(3):
+        for j in range(i + 1, 3):                           # the three heads draw independent masks
+            corr = ((masks[i] - 0.6) * (masks[j] - 0.6)).mean() / 0.24
+            assert abs(float(corr)) < 5 / (n * c) ** 0.5, (i, j, float(corr))
+
+
 @pytest.mark.parametrize("shape", [(2, 8, 8, 6), (1, 5, 7, 4), (1, 1, 1, 3)])
 def test_bilinear2x_align_corners(dev, shape):
     from unet_nested4tiny_objects_keypoints_amd import ops

@@ -148,15 +148,17 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 into the in-tree shared object (cross-compiles without a GPU)."""
+def build_library(force: bool = False, verbose: bool = False, out_path: str = None, obj_dir: str = None) -> str:
+    """Compile the HIP sources for gfx950 into the in-tree shared object (cross-compiles without a GPU).
+    out_path / obj_dir: build somewhere else (tests/test_abi.py forces a from-scratch build into a temporary directory)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "unetpp_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    lib_path = out_path or LIB_PATH
+    if not force and os.path.exists(lib_path) and all(os.path.getmtime(lib_path) >= os.path.getmtime(d) for d in deps):
+        return lib_path
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC]
-    obj_dir = os.path.join(_REPO, "build", "obj")
+    obj_dir = obj_dir or os.path.join(_REPO, "build", "obj")
     os.makedirs(obj_dir, exist_ok=True)
     jobs = []
     for src in SOURCES:  # one object per source, compiled concurrently; EXTRA_FLAGS are per kernel file
@@ -168,13 +170,14 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     for obj, cmd, proc in jobs:
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + [j[0] for j in jobs]
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + [j[0] for j in jobs]
     if verbose:
         print(" ".join(link))
     subprocess.run(link, check=True)
-    global _LIB
-    _LIB = None
-    return LIB_PATH
+    if out_path is None:
+        global _LIB
+        _LIB = None
+    return lib_path
 
 
 def lib():

@@ -61,12 +61,13 @@ __global__ __launch_bounds__(kThreads) void affine_relu_pool_bf16_kernel(const b
   const long items = static_cast<long>(N) * Hp * Wp * CG;
   for (long i = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; i < items;
        i += static_cast<long>(gridDim.x) * kThreads) {
-    const int cg = static_cast<int>(i % CG);
-    long r = i / CG;
-    const int xp = static_cast<int>(r % Wp);
-    r /= Wp;
-    const int yp = static_cast<int>(r % Hp);
-    const long n = r / Hp;
+    const unsigned iu = static_cast<unsigned>(i);  // items < 2^31 (launcher)
+    const int cg = static_cast<int>(iu % static_cast<unsigned>(CG));
+    unsigned r = iu / static_cast<unsigned>(CG);
+    const int xp = static_cast<int>(r % static_cast<unsigned>(Wp));
+    r /= static_cast<unsigned>(Wp);
+    const int yp = static_cast<int>(r % static_cast<unsigned>(Hp));
+    const long n = r / static_cast<unsigned>(Hp);
     const long base = ((n * H + 2 * yp) * W + 2 * xp) * CG + cg;  // in octets
     const long offs[4] = {base, base + CG, base + static_cast<long>(W) * CG, base + static_cast<long>(W) * CG + CG};
     float best[8];
@@ -97,15 +98,16 @@ __global__ __launch_bounds__(kThreads) void affine_relu_pool_bf16_kernel(const b
 __device__ __forceinline__ void load_grad8(const bf16_t* d_act, const bf16_t* d_pooled, const uint8_t* pool_idx, long i,
                                            int CG, int H, int W, float (&g)[8]) {
   unpack8(reinterpret_cast<const u32x4*>(d_act)[i], g);
-  if (d_pooled != nullptr) {
-    const int cg = static_cast<int>(i % CG);
-    long r = i / CG;
-    const int x = static_cast<int>(r % W);
-    r /= W;
-    const int y = static_cast<int>(r % H);
-    const long n = r / H;
-    const long wi = ((n * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)) * CG + cg;
-    const unsigned pos = static_cast<unsigned>((y & 1) * 2 + (x & 1));
+  if (d_pooled != nullptr) {  // 32-bit index arithmetic: items < 2^31 (launchers); CG is a power of two
+    const unsigned iu = static_cast<unsigned>(i), ucg = static_cast<unsigned>(CG);
+    const unsigned cg = iu & (ucg - 1u);
+    unsigned r = iu / ucg;
+    const unsigned x = r % static_cast<unsigned>(W);
+    r /= static_cast<unsigned>(W);
+    const unsigned y = r % static_cast<unsigned>(H);
+    const unsigned n = r / static_cast<unsigned>(H);
+    const unsigned wi = ((n * (static_cast<unsigned>(H) >> 1) + (y >> 1)) * (static_cast<unsigned>(W) >> 1) + (x >> 1)) * ucg + cg;
+    const unsigned pos = (y & 1u) * 2u + (x & 1u);
     const u32x2 ib = reinterpret_cast<const u32x2*>(pool_idx)[wi];
     float dp[8];
     unpack8(reinterpret_cast<const u32x4*>(d_pooled)[wi], dp);
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_bf16_kernel(const bf16_
                                                                      bf16_t* __restrict__ dy) {
   for (long i = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; i < items;
        i += static_cast<long>(gridDim.x) * kThreads) {
-    const int c = static_cast<int>(i % CG) * 8;
+    const int c = static_cast<int>(static_cast<unsigned>(i) & static_cast<unsigned>(CG - 1)) * 8;  // CG is a power of two
     float g[8], v[8], out[8];
     load_grad8(d_act, d_pooled, pool_idx, i, CG, H, W, g);
     unpack8(reinterpret_cast<const u32x4*>(y)[i], v);
@@ -196,18 +198,19 @@ __global__ __launch_bounds__(kThreads) void head_fwd_bf16_kernel(const bf16_t* _
                                                                  int C, int CG, int n_cls, float keep_scale, uint32_t thr16,
                                                                  uint64_t seed, const uint8_t* __restrict__ mask,
                                                                  int use_drop, float* __restrict__ out) {
-  __shared__ float wsm[kHeadMaxCls * kHeadMaxC];
+  __shared__ float wsm[kHeadMaxCls * kHeadMaxC];  // (the class weights in registers, 64 VGPRs, ran 1.27x slower)
   for (int i = threadIdx.x; i < n_cls * C; i += kThreads) wsm[i] = weight[i];
   __syncthreads();
   const int ppb = kThreads / CG;  // pixels per workgroup pass
   const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
-  const long passes = (pixels + ppb - 1) / ppb;
-  for (long ps = blockIdx.x; ps < passes; ps += gridDim.x) {  // all lanes stay in the loop: shuffles below
-    const long p = ps * ppb + pl;
-    const bool live = p < pixels;
+  const unsigned npix = static_cast<unsigned>(pixels), uhw = static_cast<unsigned>(HW);  // < 2^31 (launcher)
+  const unsigned passes = (npix + ppb - 1) / ppb;
+  for (unsigned ps = blockIdx.x; ps < passes; ps += gridDim.x) {  // all lanes stay in the loop: shuffles below
+    const unsigned p = ps * ppb + pl;
+    const bool live = p < npix;
     float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (live) {
-      unpack8(reinterpret_cast<const u32x4*>(x)[p * CG + cg], f);
+      unpack8(reinterpret_cast<const u32x4*>(x)[static_cast<long>(p) * CG + cg], f);
       if (use_drop) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -215,12 +218,14 @@ __global__ __launch_bounds__(kThreads) void head_fwd_bf16_kernel(const bf16_t* _
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int e = 4 * half + q;
-            const bool keep = (mask != nullptr) ? (mask[p * C + cg * 8 + e] != 0) : keep_one(bits, q, thr16);
+            const bool keep = (mask != nullptr) ? (mask[static_cast<long>(p) * C + cg * 8 + e] != 0) : keep_one(bits, q, thr16);
             f[e] = keep ? f[e] * keep_scale : 0.f;
           }
         }
       }
     }
+    const unsigned n = p / uhw, hw = p - n * uhw;  // one 32-bit division per pixel
+    float* obase = out + static_cast<long>(n) * n_cls * uhw + hw;
 #pragma unroll
     for (int k = 0; k < kHeadMaxCls; ++k) {
       if (k < n_cls) {
@@ -228,10 +233,8 @@ __global__ __launch_bounds__(kThreads) void head_fwd_bf16_kernel(const bf16_t* _
 #pragma unroll
         for (int e = 0; e < 8; ++e) s = fmaf(f[e], wsm[k * C + cg * 8 + e], s);
         for (int m = 1; m < CG; m <<= 1) s += __shfl_xor(s, m);  // every lane of the pixel holds the logit
-        if (live && (k % CG) == cg) {                            // classes are dealt to the pixel's lanes round robin
-          const long n = p / HW, hw = p - n * HW;
-          out[(n * n_cls + k) * HW + hw] = 1.0f / (1.0f + __expf(-(s + bias[k])));
-        }
+        if (live && (k % CG) == cg)                              // classes are dealt to the pixel's lanes round robin
+          obase[static_cast<long>(k) * uhw] = 1.0f / (1.0f + __expf(-(s + bias[k])));
       }
     }
   }
@@ -367,6 +370,7 @@ extern "C" int unetpp_affine_relu_pool_bf16(const void* y, const float* scale, c
   }
   if ((H & 1) || (W & 1) || !pool_idx || !a16(pooled) || (reinterpret_cast<uintptr_t>(pool_idx) & 7)) return UNETPP_EINVAL;
   const long items = static_cast<long>(N) * (H / 2) * (W / 2) * CG;
+  if (items >= 0x7fffffffL) return UNETPP_EINVAL;
   hipLaunchKernelGGL(affine_relu_pool_bf16_kernel, dim3(grid_for8(items)), dim3(kThreads), 0, ST(stream),
                      static_cast<const bf16_t*>(y), scale, shift, relu, N, H, W, CG, static_cast<bf16_t*>(act),
                      static_cast<bf16_t*>(pooled), pool_idx);
@@ -389,6 +393,7 @@ extern "C" int unetpp_bn_bwd_reduce_bf16(const void* d_act, const void* y, const
     return UNETPP_EINVAL;
   if ((d_pooled == nullptr) != (pool_idx == nullptr) || (d_pooled != nullptr && ((H | W) & 1))) return UNETPP_EINVAL;
   const long pixels = static_cast<long>(N) * H * W;
+  if (pixels * (C >> 3) >= 0x7fffffffL) return UNETPP_EINVAL;
   hipLaunchKernelGGL(bn_bwd_reduce_bf16_kernel, dim3(static_cast<unsigned>(unetpp_bn_bwd_blocks_bf16(pixels, C))),
                      dim3(kThreads), 0, ST(stream), static_cast<const bf16_t*>(d_act), static_cast<const bf16_t*>(y), scale,
                      shift, mean, invstd, static_cast<const bf16_t*>(d_pooled), pool_idx, pixels * (C >> 3), C >> 3, H, W,
@@ -406,6 +411,7 @@ extern "C" int unetpp_bn_bwd_apply_bf16(const void* d_act, const void* y, const 
   if ((d_pooled == nullptr) != (pool_idx == nullptr) || (d_pooled != nullptr && ((H | W) & 1))) return UNETPP_EINVAL;
   const long pixels = static_cast<long>(N) * H * W;
   const long items = pixels * (C >> 3);
+  if (items >= 0x7fffffffL) return UNETPP_EINVAL;
   hipLaunchKernelGGL(bn_bwd_apply_bf16_kernel, dim3(grid_for8(items)), dim3(kThreads), 0, ST(stream),
                      static_cast<const bf16_t*>(d_act), static_cast<const bf16_t*>(y), scale, shift, mean, invstd, gamma,
                      dgamma, dbeta, static_cast<const bf16_t*>(d_pooled), pool_idx, 1.0f / static_cast<float>(pixels), items,
@@ -424,6 +430,7 @@ extern "C" int unetpp_head_fwd_bf16(const void* x, const float* weight, const fl
                                     float* out_nchw, void* stream) {
   if (!x || !weight || !bias || !out_nchw || !a16(x) || !head_bf16_ok(N, H, W, C, n_cls, p_drop)) return UNETPP_EINVAL;
   const long pixels = static_cast<long>(N) * H * W;
+  if (pixels >= 0x7fffffffL) return UNETPP_EINVAL;
   const int CG = C >> 3;
   const long passes = (pixels + kThreads / CG - 1) / (kThreads / CG);
   hipLaunchKernelGGL(head_fwd_bf16_kernel, dim3(static_cast<unsigned>(passes < 256 * 16 ? passes : 256 * 16)), dim3(kThreads),
