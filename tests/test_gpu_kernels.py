@@ -481,9 +481,9 @@ def test_head_dropout_generator_independence(dev, dtype):
     bias = torch.zeros(ncls, device=dev)
     o = torch.zeros(b, ncls, h, w, device=dev)
 
-    def mask_of(seed):  # backward regenerates the mask: dx != 0 exactly where the element was kept (W = 1 for class 0)
+    def mask_of(seed):  # backward regenerates the mask: dx != 0 exactly where the element was kept (logit of class 0 ~ 1)
         wt.zero_()
-        wt[0] = 1.0
+        wt[0] = 1.0 / c
         ops.head_fwd(x, wt, bias, 0.4, seed, None, o)
         dx = torch.empty_like(x)
         ops.head_bwd(torch.ones_like(o), o, x, wt, 0.4, seed, None, dx, False)
