@@ -18,3 +18,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bf16_c5 -o p -- 
 cd $R
 find $O -name "*kernel_trace.csv" -delete   # per-dispatch traces are large; the stats files are what is kept
 ls -R $O | head -40
+# HBM traffic of the fp32 headline configuration: two separate --pmc passes (MI355X_MICROARCH.md), summarised with the
+# build's source hash so that bench.py accepts the file for roofline.traffic
+cd /tmp
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- python3 $R/bench.py --steps 2 --warmup 1 --prewarm 0 --no-cpu-baseline --no-launch-timing > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- python3 $R/bench.py --steps 2 --warmup 1 --prewarm 0 --no-cpu-baseline --no-launch-timing > $O/pmc_write.log 2>&1
+cd $R
+python tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_hbm_traffic_r2.json > $O/pmc_hbm_traffic_r2.txt 2>&1
+rm -rf $O/pmc_fetch $O/pmc_write
+tail -12 $O/pmc_hbm_traffic_r2.txt

@@ -39,6 +39,9 @@ __device__ unsigned long long g_gbf_stamps[16];
   } while (0)
 #endif
 
+#ifndef UNETPP_BF16_WGS
+#define UNETPP_BF16_WGS(TAPS, NT) (((NT) == 2 && (TAPS) == 9) ? 2 : 3)
+#endif
 constexpr int BKC = 32;        // channels per K chunk
 constexpr int BPIX = 80;       // LDS bytes per staged pixel (64 + 16 pad)
 constexpr int BSTEP = 1024;    // bytes of one (tap, g) weight step: 32 columns x 16 k x 2 B
@@ -50,7 +53,7 @@ constexpr int BSTEP = 1024;    // bytes of one (tap, g) weight step: 32 columns 
 // v_permlane32_swap per register pair pairs the groups of lanes (j, 0) and (j, 1) into 8 consecutive channels, and
 // the tile leaves as two 16-byte stores per lane straight from registers -- no LDS round trip, no wave barriers.
 template <int TAPS, int LOG2TW, int NT, bool STATS>
-__global__ __launch_bounds__(kThreads, (NT == 2 && TAPS == 9) ? 2 : 3) void gemm_bf16_kernel(const FastArgs a) {
+__global__ __launch_bounds__(kThreads, UNETPP_BF16_WGS(TAPS, NT)) void gemm_bf16_kernel(const FastArgs a) {
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
   constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;
   constexpr int HWp = TW + 2 * HALO, HHp = TH + 2 * HALO;
