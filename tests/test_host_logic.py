@@ -71,3 +71,23 @@ def test_invalid_arguments():
     m.dropout_masks = [None]
     with pytest.raises(RuntimeError):   # CPU tensor: no fallback
         m(torch.randn(1, 1, 16, 16))
+
+
+def test_bench_spawns_its_ranks_and_propagates_failure():
+    """`python bench.py --gpus 2` without a launcher starts two rank processes itself (it used to run one GPU
+    silently).  Without a GPU every rank refuses to run, and the parent must report that with a non-zero exit code --
+    which exercises the spawn path, the environment it hands to the ranks and the failure propagation on CPU."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-only check (on a GPU box the ranks would run the benchmark)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "rank exit codes" in r.stderr and "bench.py needs a GPU" in r.stderr
+    assert r.stderr.count("bench.py needs a GPU") == 2   # both ranks were started
