@@ -368,29 +368,43 @@ __global__ __launch_bounds__(kWThreads, 1) void wgrad_bf16_kernel(const WBfArgs 
     }
 #endif
   } else {
-  if (n_my > 0) {
-    set_tile(t0);
-#pragma unroll
-    for (int qi = 0; qi < N_ITEMS; ++qi) store_item(qi, smem, load_item(qi));
-  }
-  __syncthreads();
-  for (long i = 0; i < n_my; ++i) {
-    const unsigned cur = static_cast<unsigned>(i & 1) * BUF;
-    unsigned char* nxt = smem + ((i + 1) & 1) * BUF;
-    const bool more = i + 1 < n_my;
+    // Register path, prefetch distance two with ONE register stage and two LDS buffers: at the top of iteration i the
+    // registers hold tile i+1 (requested a whole iteration ago); they go into the buffer tile i-1 was read from, tile
+    // i+2 is requested, then tile i's MFMAs run.  One barrier per tile.
     u32x4 stage[N_ITEMS];
-    if (more) {
-      set_tile(t0 + (i + 1) * stride);
+    int s_ty0 = 0, s_tx0 = 0;  // geometry of the tile held in `stage` (store_item reads ty0 / tx0)
+    if (n_my > 0) {
+      set_tile(t0);
+#pragma unroll
+      for (int qi = 0; qi < N_ITEMS; ++qi) store_item(qi, smem, load_item(qi));
+    }
+    if (n_my > 1) {
+      set_tile(t0 + stride);
+      s_ty0 = ty0;
+      s_tx0 = tx0;
 #pragma unroll
       for (int qi = 0; qi < N_ITEMS; ++qi) stage[qi] = load_item(qi);
     }
-    compute(cur);
-    if (more) {
-#pragma unroll
-      for (int qi = 0; qi < N_ITEMS; ++qi) store_item(qi, nxt, stage[qi]);
-    }
     __syncthreads();
-  }
+    for (long i = 0; i < n_my; ++i) {
+      const unsigned cur = static_cast<unsigned>(i & 1) * BUF;
+      if (i + 1 < n_my) {
+        ty0 = s_ty0;
+        tx0 = s_tx0;
+        unsigned char* nxt = smem + ((i + 1) & 1) * BUF;  // last read by tile i-1, a barrier ago
+#pragma unroll
+        for (int qi = 0; qi < N_ITEMS; ++qi) store_item(qi, nxt, stage[qi]);
+      }
+      if (i + 2 < n_my) {
+        set_tile(t0 + (i + 2) * stride);
+        s_ty0 = ty0;
+        s_tx0 = tx0;
+#pragma unroll
+        for (int qi = 0; qi < N_ITEMS; ++qi) stage[qi] = load_item(qi);
+      }
+      compute(cur);
+      __syncthreads();
+    }
   }
 
   // ---- fixed-order tree sum of the 8 waves through LDS, then one slab per workgroup ----
@@ -475,6 +489,9 @@ int launch_wgrad_bf16(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_til
   const dim3 grid(static_cast<unsigned>(d->n_split), static_cast<unsigned>(static_cast<long>(k_tiles) * n_tiles_cols));
   bool dma = true;  // plain views only
   for (int i = 0; i < d->n_x; ++i) dma = dma && d->x[i].scale == nullptr && !d->x[i].relu;
+#ifdef UNETPP_WBF_EXP_REGISTER_PATH  // experiment builds: the register path for every launch
+  dma = false;
+#endif
 #define UNETPP_WBF(T, L)                                                   \
   return dma ? launch_one<T, L, true>(a, grid, st) : launch_one<T, L, false>(a, grid, st)
   if (d->taps == 9) {
