@@ -378,6 +378,8 @@ def wgrad(n: int, h: int, w: int, taps: int, xs: Sequence[V], dys: Sequence[V], 
     pairs = sum((v.c_len + 31) // 32 for v in d.x[:len(xs)]) * sum((v.c_len + 31) // 32 for v in d.dy[:len(dys)])
     if len(xs) == 1 and xs[0].t.shape[3] <= 4:
         target_blocks = 2048  # the 1..4-channel first layer runs an HBM-bound VALU kernel: many small workgroups
+    if dys[0].t.dtype == torch.bfloat16 and target_blocks == 256:
+        target_blocks = 512  # the bf16 kernel runs two 4-wave workgroups per CU
     split = max(1, min(int(lib.unetpp_wgrad_max_split(n, h, w)), target_blocks // max(1, pairs)))
     d.n_split = split
     d.flags = (_lib.GEMM_DIRECT if (direct or not USE_WINOGRAD) else 0) | _storage_flag(dys, xs)
