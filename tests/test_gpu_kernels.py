@@ -203,6 +203,63 @@ def test_deconv2x2_fwd_dgrad_wgrad(dev, shape):
     assert rel_err(db.cpu(), bias.grad.float()) < TOL
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 16, [8], 16), (1, 32, 64, [32, 16], 64), (2, 24, 40, [8], 12),
+                                   (1, 37, 21, [20, 4], 36), (1, 3, 5, [4], 6), (2, 64, 64, [64], 32)])
+@pytest.mark.parametrize("mode", ["plain", "relu", "gate", "gate_sum", "accumulate", "sliced", "stats"])
+def test_pointwise_fast_and_generic_agree(dev, shape, mode):
+    """Pointwise (1x1) GEMM: the swapped-operand register-direct epilogue of the fast kernel against the generic
+    kernel, bitwise, for every store mode (ReLU, gate before/after the sum, accumulate, channel-sliced output in a
+    wider tensor, unaligned column counts -> scalar stores, statistics launches -> pixel-major epilogue) and against
+    the fp64 statement."""
+    from unet_nested4tiny_objects_keypoints_amd import engine, ops
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    b, h, w, cins, co = shape
+    g = torch.Generator().manual_seed(21)
+    srcs = [torch.randn(b, c, h, w, generator=g) for c in cins]
+    wt = torch.randn(co, sum(cins), 1, 1, generator=g) * 0.3
+    bias = torch.randn(co, generator=g)
+    gate = torch.randn(b, co, h, w, generator=g)
+    prev = torch.randn(b, co, h, w, generator=g)
+    ref = F.conv2d(torch.cat(srcs, 1).double(), wt.double(), bias.double())
+    if mode == "relu":
+        ref = F.relu(ref)
+    elif mode == "gate":
+        ref = prev.double() + ref * (gate > 0)
+    elif mode == "gate_sum":
+        ref = (prev.double() + ref) * (gate > 0)
+    elif mode == "accumulate":
+        ref = prev.double() + ref
+    wp = engine.pack_conv_fwd(wt.cuda())
+    res = []
+    for fast in (True, False):
+        ops.USE_FAST_GEMM = fast
+        try:
+            part = None
+            if mode == "sliced":
+                wide = torch.full((b, h, w, co + 12), 7.0, device=dev)
+                outs = [V(wide, c_off=8, c_len=co)]
+            else:
+                wide = nhwc(prev)
+                kw = {"relu": {"relu": True}, "gate": {"gate": nhwc(gate), "accumulate": True},
+                      "gate_sum": {"gate": nhwc(gate), "accumulate": True, "gate_sum": True},
+                      "accumulate": {"accumulate": True}}.get(mode, {})
+                outs = [V(wide, **kw)]
+                if mode == "stats":
+                    part = torch.empty(ops.gemm_pixel_blocks(b, h, w) * co * 2, device=dev)
+            ops.gemm_fwd(b, h, w, 1, [V(nhwc(s)) for s in srcs], outs, wp, bias.cuda(), part)
+        finally:
+            ops.USE_FAST_GEMM = True
+        res.append((wide, part))
+    assert torch.equal(res[0][0], res[1][0])
+    if mode == "stats":
+        assert torch.equal(res[0][1], res[1][1])
+    got = res[0][0]
+    if mode == "sliced":
+        assert bool((got[..., :8] == 7.0).all()) and bool((got[..., 8 + co:] == 7.0).all())
+        got = got[..., 8:8 + co]
+    assert rel_err(nchw(got), ref.float()) < TOL
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, [8], 8), (1, 32, 32, [32, 32, 32], 32), (2, 24, 40, [3], 4),
                                    (1, 8, 8, [40, 5], 33), (3, 64, 64, [16], 16), (2, 32, 64, [1], 32),
                                    (1, 24, 40, [3], 8)])
