@@ -26,6 +26,11 @@
 //   * the LDS operand reads of the MFMA phase are placed by hand (inline asm, one group of 8 MFMAs ahead, one
 //     s_waitcnt per group, scheduling fences around each group): hipcc sinks every ds_read to just in front of its
 //     first use, which leaves a lone wave's matrix pipe idle for an LDS round trip 13 times per 32 MFMAs.
+//   * LEAN instantiation (every input view a plain fp32 tensor of the launch geometry, no transform on load, channel
+//     slices in multiples of 8, at most 2 GB): the inputs come in through buffer loads whose hardware range check
+//     returns zeros for out-of-image halo pixels (their offset is simply out of range), so the staging of a chunk is
+//     three loads and three LDS stores per thread -- no clamping, no masks, no selects; the general instantiation keeps
+//     the BatchNorm fold / ReLU on load and the per-element padding select.
 #include <cstdlib>
 #include <utility>
 
@@ -37,6 +42,8 @@ namespace unetpp {
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4v __attribute__((vector_size(16)));  // the buffer-load builtin's own return type
+constexpr unsigned kOutOfRange = 0x80000000u;  // buffer offset no LEAN view reaches (views are at most 2 GB)
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -89,7 +96,7 @@ __device__ unsigned long long g_wino_stamps[16];
 
 // NH = 16-column halves of the tile that are computed: 2, or 1 when no output view is wider than 16 channels (narrow
 // networks, e.g. the reference's default base width 16) -- the second half would multiply zero weights.
-template <int LOG2TW, int NH>
+template <int LOG2TW, int NH, bool LEAN>
 __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a) {
   constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;
   constexpr int HWp = TW + 2, HHp = TH + 2;
@@ -99,6 +106,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   constexpr int IN_ITEMS = (NPIX * 2 + kThreads - 1) / kThreads;  // 16-byte items, 2 per pixel (<= 3)
   constexpr int W_ITEMS = WIMG / 4 / kThreads;                    // 4
   static_assert(kMaxHaloPixels * WP <= IN_FLOATS, "input patch does not fit");
+  static_assert(((IN_ITEMS * kThreads - 1) >> 1) * WP + 8 <= IN_FLOATS, "staging items past the patch must stay inside the buffer");
   // Two (input patch, weight image) buffers: the next chunk is written into the other buffer at the top of the
   // current chunk (its loads were issued a whole chunk earlier), so a chunk costs one barrier.
   constexpr int BUF = IN_FLOATS + WIMG;
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 
   const unetpp_gemm_desc& d = a.d;
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, t16 = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, t16 = lane & 15, g = lane >> 4;
 
   const UnitRange ur = my_contiguous_unit_range(a.total_blocks);
   if (ur.count == 0) return;
@@ -144,13 +152,24 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   const float* v_shift = nullptr;
   int v_clen = 0;
   bool v_relu = false;
+  // LEAN: the view as a buffer resource (range-checked loads), its pixel pitch and slice origin in bytes, and the
+  // linear index of every staging item's pixel in the (plain, launch-sized) input tensors, -1 outside the image
+  int v_bytes = 0, v_pitch = 0, v_origin = 0;
+  int pix[IN_ITEMS];
   auto cache_view = [&]() {
     const unetpp_view& V = d.in[p_s];
-    v_ptr = V.ptr;
-    v_scale = V.scale;
-    v_shift = V.shift;
     v_clen = V.c_len;
-    v_relu = V.relu != 0;
+    if constexpr (LEAN) {
+      v_ptr = V.ptr;
+      v_bytes = d.N * V.Hs * V.Ws * V.C * 4;  // <= 2 GB (launcher)
+      v_pitch = V.C * 4;
+      v_origin = V.c_off * 4;
+    } else {
+      v_ptr = V.ptr;
+      v_scale = V.scale;
+      v_shift = V.shift;
+      v_relu = V.relu != 0;
+    }
   };
 
   // The unit run is contiguous, so both cursors (prefetch side, compute side) are decoded once and then stepped:
@@ -184,6 +203,23 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     p_n = ug.n;
     p_ty0 = ug.ty0;
     p_tx0 = ug.tx0;
+    if constexpr (LEAN) {
+      const int row0 = p_n * d.H;
+#pragma unroll
+      for (int q = 0; q < IN_ITEMS; ++q) {
+        const int it = tid + q * kThreads;
+        const int hp = it >> 1;
+        const int hy = hp / HWp, hx = hp - hy * HWp;
+        const int y = p_ty0 + hy - 1, x = p_tx0 + hx - 1;
+        // bitwise, and the index computed on both sides: a short-circuit here becomes a divergent branch that the
+        // optimiser threads into the cursor code below, after which the whole cursor lives in vector registers
+        const bool inside = (it < NPIX * 2) & (static_cast<unsigned>(y) < static_cast<unsigned>(d.H)) &
+                            (static_cast<unsigned>(x) < static_cast<unsigned>(d.W));
+        const int linear = (row0 + y) * d.W + x;
+        pix[q] = inside ? linear : -1;
+      }
+      return false;
+    }
     in_mask = 0;
 #pragma unroll
     for (int q = 0; q < IN_ITEMS; ++q) {
@@ -196,6 +232,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     return false;
   };
   auto view_offsets = [&](const unetpp_view& V) {  // clamped: every item loads from a valid address
+    if constexpr (LEAN) {  // byte offsets; padding pixels and the dummy items of the last pass are out of range = zeros
+#pragma unroll
+      for (int q = 0; q < IN_ITEMS; ++q)
+        voff[q] = static_cast<unsigned>(pix[q] * v_pitch + v_origin + cc * 4) |
+                  (static_cast<unsigned>(pix[q] >> 31) & kOutOfRange);  // arithmetic on purpose: see prefetch_unit
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < IN_ITEMS; ++q) {
       const int hp = min((tid + q * kThreads) >> 1, NPIX - 1);
@@ -230,6 +273,18 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     }
   };
   auto load_inputs = [&]() {
+    if constexpr (LEAN) {  // slices are multiples of 8 channels: every chunk is full
+      // (the resource is put together here, three scalar instructions: carried through the loop as a 128-bit value it
+      // pulled the whole cursor into vector registers)
+      const __amdgpu_buffer_rsrc_t v_rsrc =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(v_ptr), 0, v_bytes, 0x00020000);
+#pragma unroll
+      for (int q = 0; q < IN_ITEMS; ++q) {
+        const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, static_cast<int>(voff[q]), p_c0 * 4, 0);
+        reg_in[q] = __builtin_bit_cast(f32x4, v);
+      }
+      return;
+    }
     pf_cnt = min(WKC, v_clen - p_c0);
 #pragma unroll
     for (int q = 0; q < IN_ITEMS; ++q) {
@@ -247,6 +302,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
                                        (lptr_t)(w_dst + (q * kThreads + wave * 64) * 4), 16, 0, 0);
   };
   auto store_chunk = [&](float* in_dst) {
+    if constexpr (LEAN) {  // the dummy items of the last pass land behind the patch, inside the buffer (767 / 2 * WP < IN_FLOATS)
+#pragma unroll
+      for (int q = 0; q < IN_ITEMS; ++q) {
+        const int it = tid + q * kThreads;
+        *reinterpret_cast<f32x2*>(&in_dst[(it >> 1) * WP + cc]) = f32x2{reg_in[q][0], reg_in[q][1]};
+        *reinterpret_cast<f32x2*>(&in_dst[(it >> 1) * WP + cc + 2]) = f32x2{reg_in[q][2], reg_in[q][3]};
+      }
+      return;
+    }
     const bool affine = v_scale != nullptr;  // BatchNorm apply + ReLU folded into the operand load
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (affine) {
@@ -577,10 +641,20 @@ int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
   const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(kThreads);
   bool narrow = true;  // no output view wider than 16 channels: the second column half is never used
   for (int i = 0; i < d->n_out; ++i) narrow = narrow && d->out[i].c_len <= 16;
+  // lean staging: plain launch-sized fp32 tensors, no transform on load, whole 8-channel chunks, 2 GB at most
+  bool lean = getenv("UNETPP_WINO_NO_LEAN") == nullptr;
+  for (int i = 0; i < d->n_in; ++i) {
+    const unetpp_view& v = d->in[i];
+    lean = lean && v.scale == nullptr && v.relu == 0 && (v.c_len & 7) == 0 && v.Hs == d->H && v.Ws == d->W &&
+           v.sy == 1 && v.sx == 1 && v.oy == 0 && v.ox == 0 &&
+           static_cast<long>(d->N) * v.Hs * v.Ws * v.C * 4 <= 0x7fffffffL;
+  }
 #define UNETPP_LAUNCH_WINO(L)                                                                          \
   do {                                                                                                 \
-    if (narrow) hipLaunchKernelGGL((gemm_wino_kernel<L, 1>), grid, block, 0, st, a);                   \
-    else hipLaunchKernelGGL((gemm_wino_kernel<L, 2>), grid, block, 0, st, a);                          \
+    if (narrow && lean) hipLaunchKernelGGL((gemm_wino_kernel<L, 1, true>), grid, block, 0, st, a);     \
+    else if (narrow) hipLaunchKernelGGL((gemm_wino_kernel<L, 1, false>), grid, block, 0, st, a);       \
+    else if (lean) hipLaunchKernelGGL((gemm_wino_kernel<L, 2, true>), grid, block, 0, st, a);          \
+    else hipLaunchKernelGGL((gemm_wino_kernel<L, 2, false>), grid, block, 0, st, a);                   \
   } while (0)
   if (a.log2tw == 5) UNETPP_LAUNCH_WINO(5);
   else if (a.log2tw == 4) UNETPP_LAUNCH_WINO(4);
