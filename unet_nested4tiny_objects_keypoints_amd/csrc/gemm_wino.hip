@@ -105,6 +105,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   constexpr int IN_FLOATS = 4096;    // >= kMaxHaloPixels * WP (3400); also the 4 x 4 KB transpose scratch of the epilogue
   constexpr int IN_ITEMS = (NPIX * 2 + kThreads - 1) / kThreads;  // 16-byte items, 2 per pixel (<= 3)
   constexpr int W_ITEMS = WIMG / 4 / kThreads;                    // 4
+  static_assert(IN_ITEMS == 3 && W_ITEMS == 4, "the staging lambdas' default ranges");
   static_assert(kMaxHaloPixels * WP <= IN_FLOATS, "input patch does not fit");
   static_assert(((IN_ITEMS * kThreads - 1) >> 1) * WP + 8 <= IN_FLOATS, "staging items past the patch must stay inside the buffer");
   // Two (input patch, weight image) buffers: the next chunk is written into the other buffer at the top of the
@@ -294,17 +295,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   };
   // The weight image of the cursor's chunk goes L2 -> LDS directly (LDS-DMA, 1 KB per wave and instruction, lane
   // linear like the image itself): no staging registers.
-  auto dma_weights = [&](float* w_dst) {
+  auto dma_weights = [&](float* w_dst, int q0 = 0, int q1 = 4) {  // W_ITEMS
     const float* wp = p_wimg + static_cast<long>(p_chunk) * WIMG;
 #pragma unroll
-    for (int q = 0; q < W_ITEMS; ++q)
+    for (int q = q0; q < q1; ++q)
       __builtin_amdgcn_global_load_lds((gptr_t)(wp + (tid + q * kThreads) * 4),
                                        (lptr_t)(w_dst + (q * kThreads + wave * 64) * 4), 16, 0, 0);
   };
-  auto store_chunk = [&](float* in_dst) {
+  auto store_chunk = [&](float* in_dst, int q0 = 0, int q1 = 3) {  // IN_ITEMS
     if constexpr (LEAN) {  // the dummy items of the last pass land behind the patch, inside the buffer (767 / 2 * WP < IN_FLOATS)
 #pragma unroll
-      for (int q = 0; q < IN_ITEMS; ++q) {
+      for (int q = q0; q < q1; ++q) {
         const int it = tid + q * kThreads;
         *reinterpret_cast<f32x2*>(&in_dst[(it >> 1) * WP + cc]) = f32x2{reg_in[q][0], reg_in[q][1]};
         *reinterpret_cast<f32x2*>(&in_dst[(it >> 1) * WP + cc + 2]) = f32x2{reg_in[q][2], reg_in[q][3]};
@@ -526,14 +527,28 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     lds_read2st64_b64<2, 3>(us[0][1], w_b);
 
     float* other = smem + (cur ^ 1) * BUF;
-    // The staging code is a few hundred sequential instructions; at the highest priority it gets through the issue
-    // slots the co-resident wave's MFMA stream leaves and this wave is back at its own MFMAs sooner (+2 %).
-    __builtin_amdgcn_s_setprio(3);
-    store_chunk(other);
-    dma_weights(other + IN_FLOATS);
-    advance();
-    load_inputs();
+    if constexpr (!LEAN) {
+      // The staging code is a few hundred sequential instructions; at the highest priority it gets through the issue
+      // slots the co-resident wave's MFMA stream leaves and this wave is back at its own MFMAs sooner (+2 %).
+      __builtin_amdgcn_s_setprio(3);
+      store_chunk(other);
+      dma_weights(other + IN_FLOATS);
+      advance();
+      load_inputs();
+    }
     WINO_STAMP(1);  // 1: staging store, cursor, load issue
+    // LEAN: the staging of the next chunk is a hundred instructions; they are spread over the first MFMA groups below,
+    // where they issue in the shadow of this wave's own MFMAs.  Order: the LDS stores of the inputs requested most of a
+    // chunk ago, then the weight DMA (hipcc makes any LDS store that follows a DMA wait for vmcnt(0)), the cursor, and
+    // the requests for the chunk after next -- the DMA has three quarters of the phase to land, the loads a whole one.
+    auto staging_piece = [&](auto gc) {
+      constexpr int g = decltype(gc)::v;
+      if constexpr (!LEAN) return;
+      if constexpr (g == 0) store_chunk(other);
+      if constexpr (g == 1) dma_weights(other + IN_FLOATS);
+      if constexpr (g == 2) advance();
+      if constexpr (g == 3) load_inputs();
+    };
 
     // ---- per channel s the 4x4 window -> B^T d B in registers -> 32 MFMAs; every accumulator is touched once per
     // channel (no back-to-back dependence).  Raised wave priority for the MFMA phase: the co-resident workgroup's wave
@@ -565,6 +580,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
         if (NH == 2)
           acc[xi][NH - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi], up[(q & 1) * 2 + 1], acc[xi][NH - 1], 0, 0, 0);
       }
+      staging_piece(gc);
       WINO_FENCE();
       if constexpr (g == 0) lds_wait16(ddn);
       if constexpr (g + 1 < 8) lds_wait(us[ns][0], us[ns][1]);
