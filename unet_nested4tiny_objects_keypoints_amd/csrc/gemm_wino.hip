@@ -236,8 +236,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     if constexpr (LEAN) {  // byte offsets; padding pixels and the dummy items of the last pass are out of range = zeros
 #pragma unroll
       for (int q = 0; q < IN_ITEMS; ++q)
+#ifdef UNETPP_WINO_EXP_SAME_LINE  // experiment: every load of the launch hits the same few cache lines
+        voff[q] = static_cast<unsigned>(cc * 4 + (pix[q] & 1) * 32);
+#else
         voff[q] = static_cast<unsigned>(pix[q] * v_pitch + v_origin + cc * 4) |
                   (static_cast<unsigned>(pix[q] >> 31) & kOutOfRange);  // arithmetic on purpose: see prefetch_unit
+#endif
       return;
     }
 #pragma unroll
@@ -295,8 +299,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   };
   // The weight image of the cursor's chunk goes L2 -> LDS directly (LDS-DMA, 1 KB per wave and instruction, lane
   // linear like the image itself): no staging registers.
-  auto dma_weights = [&](float* w_dst, int q0 = 0, int q1 = 4) {  // W_ITEMS
-    const float* wp = p_wimg + static_cast<long>(p_chunk) * WIMG;
+  auto dma_source = [&]() { return p_wimg + static_cast<long>(p_chunk) * WIMG; };  // the cursor's chunk image
+  auto dma_weights = [&](float* w_dst, const float* wp, int q0 = 0, int q1 = 4) {    // W_ITEMS
 #pragma unroll
     for (int q = q0; q < q1; ++q)
       __builtin_amdgcn_global_load_lds((gptr_t)(wp + (tid + q * kThreads) * 4),
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   prefetch_unit();
   view_offsets(d.in[0]);
   load_inputs();
-  dma_weights(w_tile);
+  dma_weights(w_tile, dma_source());
   store_chunk(in_tile);
   advance();
   load_inputs();
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       // slots the co-resident wave's MFMA stream leaves and this wave is back at its own MFMAs sooner (+2 %).
       __builtin_amdgcn_s_setprio(3);
       store_chunk(other);
-      dma_weights(other + IN_FLOATS);
+      dma_weights(other + IN_FLOATS, dma_source());
       advance();
       load_inputs();
     }
@@ -540,14 +544,25 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     // LEAN: the staging of the next chunk is a hundred instructions; they are spread over the first MFMA groups below,
     // where they issue in the shadow of this wave's own MFMAs.  Order: the LDS stores of the inputs requested most of a
     // chunk ago, then the weight DMA (hipcc makes any LDS store that follows a DMA wait for vmcnt(0)), the cursor, and
-    // the requests for the chunk after next -- the DMA has three quarters of the phase to land, the loads a whole one.
+    // the requests for the chunk after next, which must stay the YOUNGEST vector-memory operations: the barrier waits
+    // with vmcnt(IN_ITEMS), i.e. for the DMA but not for them.
     auto staging_piece = [&](auto gc) {
       constexpr int g = decltype(gc)::v;
       if constexpr (!LEAN) return;
-      if constexpr (g == 0) store_chunk(other);
-      if constexpr (g == 1) dma_weights(other + IN_FLOATS);
+#ifdef UNETPP_WINO_EXP_NO_STAGING
       if constexpr (g == 2) advance();
+#else
+#ifndef UNETPP_WINO_EXP_NO_STORE
+      if constexpr (g == 0) store_chunk(other);
+#endif
+#ifndef UNETPP_WINO_EXP_NO_DMA
+      if constexpr (g == 1) dma_weights(other + IN_FLOATS, dma_source());
+#endif
+      if constexpr (g == 2) advance();
+#ifndef UNETPP_WINO_EXP_NO_LOADS
       if constexpr (g == 3) load_inputs();
+#endif
+#endif
     };
 
     // ---- per channel s the 4x4 window -> B^T d B in registers -> 32 MFMAs; every accumulator is touched once per
@@ -591,8 +606,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     });
     __builtin_amdgcn_s_setprio(0);
     WINO_STAMP(4);  // 4: second half of the MFMA phase
+#ifndef UNETPP_WINO_EXP_NO_BARRIER
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_ITEMS) : "memory");  // this wave's share of the next weight image is in
     __syncthreads();  // all waves: done reading the current buffers, next buffers written
+#endif
     WINO_STAMP(5);  // 5: barrier
     if (c_chunk + 1 == a.n_chunks) {
       // Collect the prefetched inputs BEFORE the epilogue issues its stores: vmcnt counts in order, so a wait for
@@ -600,7 +617,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       // for the unit's stores to reach memory.  The loads are a whole MFMA phase old here.
 #pragma unroll
       for (int q = 0; q < IN_ITEMS; ++q) asm volatile("" : "+v"(reg_in[q]));
+#ifdef UNETPP_WINO_EXP_NO_EPILOGUE  // experiment builds only (tools/README.md): where does a unit's time go
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int nh = 0; nh < NH; ++nh) {
+          asm volatile("" : "+v"(acc[xi][nh]));
+          acc[xi][nh] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#else
       epilogue();  // the current buffers are its scratch; stores drain while the next unit computes
+#endif
       WINO_STAMP(6);  // 6: epilogue
       __syncthreads();   // before the next chunk's staging overwrites that scratch
       flush_stats();
@@ -650,7 +677,7 @@ int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
     return UNETPP_ELAUNCH;
   long workers = (2L * cus) & ~7L;  // persistent grid: two workgroups per CU (= the kernel's launch bounds)
-#ifdef UNETPP_WINO_STAMPS
+#if defined(UNETPP_WINO_STAMPS) || defined(UNETPP_WINO_EXP)
   if (const char* e = getenv("UNETPP_WINO_ONE_PER_CU"); e != nullptr && e[0] == '1') workers = cus & ~7L;  // waves alone on their SIMD
 #endif
   if (workers < 8) workers = 8;
