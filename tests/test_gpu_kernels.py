@@ -74,22 +74,23 @@ def test_conv3x3_fwd_multiview(dev, shape, conv_algo):
     assert rel_err(sums[:, 1], (ref.double() ** 2).sum((0, 2, 3))) < TOL
 
 
-def test_conv3x3_load_transform_and_slices(dev, conv_algo):
+@pytest.mark.parametrize("ck", [12, 16])  # 12: partial 8-channel chunk (general kernel); 16: the lean fold kernel
+def test_conv3x3_load_transform_and_slices(dev, conv_algo, ck):
     """affine + ReLU applied on load (zero padding AFTER the transform), channel-sliced views, store gate/accumulate."""
     from unet_nested4tiny_objects_keypoints_amd import engine, ops
     from unet_nested4tiny_objects_keypoints_amd.ops import V
     b, h, w = 2, 16, 16
     g = torch.Generator().manual_seed(2)
-    big = torch.randn(b, 24, h, w, generator=g)          # use channels 8..20
-    scale, shift = torch.randn(12, generator=g), torch.randn(12, generator=g)
-    wt = torch.randn(16, 12, 3, 3, generator=g) * 0.2
-    xin = F.relu(big[:, 8:20] * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    big = torch.randn(b, 28, h, w, generator=g)          # use channels 8..8+ck
+    scale, shift = torch.randn(ck, generator=g), torch.randn(ck, generator=g)
+    wt = torch.randn(16, ck, 3, 3, generator=g) * 0.2
+    xin = F.relu(big[:, 8:8 + ck] * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
     ref = F.conv2d(xin.double(), wt.double(), None, padding=1).float()
     gate = torch.randn(b, 16, h, w, generator=g)
     prev = torch.randn(b, 16, h, w, generator=g)
     expect = prev + ref * (gate > 0)
     out = nhwc(prev)
-    ops.gemm_fwd(b, h, w, 9, [V(nhwc(big), c_off=8, c_len=12, scale=scale.cuda(), shift=shift.cuda(), relu=True)],
+    ops.gemm_fwd(b, h, w, 9, [V(nhwc(big), c_off=8, c_len=ck, scale=scale.cuda(), shift=shift.cuda(), relu=True)],
                  [V(out, gate=nhwc(gate), accumulate=True)], engine.pack_conv_fwd(wt.cuda()))
     assert rel_err(nchw(out), expect) < TOL
     # gate_sum: the ReLU mask is applied to the accumulated sum (the "last contributor" form); plain input
@@ -104,6 +105,29 @@ def test_conv3x3_load_transform_and_slices(dev, conv_algo):
         finally:
             ops.USE_FAST_GEMM = True
         assert rel_err(nchw(out), (prev + ref) * (gate > 0)) < TOL
+
+
+@pytest.mark.parametrize("hw", [(24, 40), (64, 64), (5, 7)])
+def test_conv3x3_mixed_folded_views(dev, hw, conv_algo):
+    """Virtual concat of a plain view, a view with affine + ReLU on load and a view with the affine alone (whole
+    8-channel chunks: the lean kernel with the fold), ragged patches: the padding must be zero AFTER the transform."""
+    from unet_nested4tiny_objects_keypoints_amd import engine, ops
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    b, (h, w) = 2, hw
+    g = torch.Generator().manual_seed(12)
+    xs = [torch.randn(b, c, h, w, generator=g) for c in (8, 16, 8)]
+    sc1, sh1 = torch.randn(16, generator=g), torch.randn(16, generator=g) + 0.5
+    sc2, sh2 = torch.randn(8, generator=g), torch.randn(8, generator=g) - 0.5
+    wt = torch.randn(24, 32, 3, 3, generator=g) * 0.2
+    bias = torch.randn(24, generator=g)
+    x1 = F.relu(xs[1] * sc1.view(1, -1, 1, 1) + sh1.view(1, -1, 1, 1))
+    x2 = xs[2] * sc2.view(1, -1, 1, 1) + sh2.view(1, -1, 1, 1)
+    ref = F.conv2d(torch.cat([xs[0], x1, x2], 1).double(), wt.double(), bias.double(), padding=1).float()
+    out = torch.full((b, h, w, 24), float("nan"), device=dev)
+    ops.gemm_fwd(b, h, w, 9, [V(nhwc(xs[0])), V(nhwc(xs[1]), scale=sc1.cuda(), shift=sh1.cuda(), relu=True),
+                              V(nhwc(xs[2]), scale=sc2.cuda(), shift=sh2.cuda())],
+                 [V(out)], engine.pack_conv_fwd(wt.cuda()), bias.cuda())
+    assert rel_err(nchw(out), ref) < TOL
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 32, [32], 32), (1, 64, 64, [32, 32, 32, 32], 32), (2, 8, 8, [16, 8, 8], 40),

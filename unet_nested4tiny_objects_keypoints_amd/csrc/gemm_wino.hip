@@ -26,11 +26,13 @@
 //   * the LDS operand reads of the MFMA phase are placed by hand (inline asm, one group of 8 MFMAs ahead, one
 //     s_waitcnt per group, scheduling fences around each group): hipcc sinks every ds_read to just in front of its
 //     first use, which leaves a lone wave's matrix pipe idle for an LDS round trip 13 times per 32 MFMAs.
-//   * LEAN instantiation (every input view a plain fp32 tensor of the launch geometry, no transform on load, channel
-//     slices in multiples of 8, at most 2 GB): the inputs come in through buffer loads whose hardware range check
-//     returns zeros for out-of-image halo pixels (their offset is simply out of range), so the staging of a chunk is
-//     three loads and three LDS stores per thread -- no clamping, no masks, no selects; the general instantiation keeps
-//     the BatchNorm fold / ReLU on load and the per-element padding select.
+//   * LEAN instantiations (MODE 1, 2: every input view an fp32 tensor of the launch geometry, channel slices in
+//     multiples of 8, at most 2 GB): the inputs come in through buffer loads whose hardware range check returns zeros
+//     for out-of-image halo pixels (their offset is simply out of range), so the staging of a chunk is three loads and
+//     three LDS stores per thread -- no clamping, no selects -- issued inside the first MFMA groups of the chunk
+//     before.  MODE 2 adds the BatchNorm fold / ReLU on load: the chunk's coefficients are requested with the cursor,
+//     a chunk ahead, and the padding is restored by a bitwise AND with the in-image mask.  MODE 0 is the general
+//     kernel (any view geometry, partial chunks, per-element padding select).
 #include <cstdlib>
 #include <utility>
 
@@ -96,8 +98,9 @@ __device__ unsigned long long g_wino_stamps[16];
 
 // NH = 16-column halves of the tile that are computed: 2, or 1 when no output view is wider than 16 channels (narrow
 // networks, e.g. the reference's default base width 16) -- the second half would multiply zero weights.
-template <int LOG2TW, int NH, bool LEAN>
+template <int LOG2TW, int NH, int MODE>
 __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a) {
+  constexpr bool LEAN = MODE != 0, FOLD = MODE == 2;
   constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;
   constexpr int HWp = TW + 2, HHp = TH + 2;
   constexpr int NPIX = HWp * HHp;
@@ -165,6 +168,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       v_bytes = d.N * V.Hs * V.Ws * V.C * 4;  // <= 2 GB (launcher)
       v_pitch = V.C * 4;
       v_origin = V.c_off * 4;
+      if constexpr (FOLD) {
+        v_scale = V.scale;
+        v_shift = V.shift;
+        v_relu = V.relu != 0;
+      }
     } else {
       v_ptr = V.ptr;
       v_scale = V.scale;
@@ -277,6 +285,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       if (!prefetch_unit() || !same_view) view_offsets(d.in[0]);  // same patch and view: offsets still valid
     }
   };
+  // FOLD: scale / shift of this thread's channel quad in the cursor's chunk, requested right after the cursor moves
+  // and used a chunk later, when that chunk's inputs go to LDS
+  f32x4 co_sc = {1.f, 1.f, 1.f, 1.f}, co_sh = {0.f, 0.f, 0.f, 0.f};
+  float co_floor = 0.f;
+  auto load_coeffs = [&]() {
+    if constexpr (!FOLD) return;
+    co_floor = v_relu ? 0.f : -__builtin_inff();
+    if (v_scale != nullptr) {  // uniform
+      co_sc = *reinterpret_cast<const f32x4*>(v_scale + p_c0 + cc);
+      co_sh = *reinterpret_cast<const f32x4*>(v_shift + p_c0 + cc);
+    } else {
+      co_sc = f32x4{1.f, 1.f, 1.f, 1.f};
+      co_sh = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
   auto load_inputs = [&]() {
     if constexpr (LEAN) {  // slices are multiples of 8 channels: every chunk is full
       // (the resource is put together here, three scalar instructions: carried through the loop as a 128-bit value it
@@ -311,8 +334,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 #pragma unroll
       for (int q = q0; q < q1; ++q) {
         const int it = tid + q * kThreads;
-        *reinterpret_cast<f32x2*>(&in_dst[(it >> 1) * WP + cc]) = f32x2{reg_in[q][0], reg_in[q][1]};
-        *reinterpret_cast<f32x2*>(&in_dst[(it >> 1) * WP + cc + 2]) = f32x2{reg_in[q][2], reg_in[q][3]};
+        f32x4 v = reg_in[q];
+        if constexpr (FOLD) {  // affine, ReLU, and the zero padding back (pix < 0: outside the image)
+          const unsigned inside = ~static_cast<unsigned>(pix[q] >> 31);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, fmaxf(fmaf(v[e], co_sc[e], co_sh[e]), co_floor)) & inside);
+        }
+        *reinterpret_cast<f32x2*>(&in_dst[(it >> 1) * WP + cc]) = f32x2{v[0], v[1]};
+        *reinterpret_cast<f32x2*>(&in_dst[(it >> 1) * WP + cc + 2]) = f32x2{v[2], v[3]};
       }
       return;
     }
@@ -507,10 +537,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   cache_view();
   prefetch_unit();
   view_offsets(d.in[0]);
+  load_coeffs();
   load_inputs();
   dma_weights(w_tile, dma_source());
   store_chunk(in_tile);
   advance();
+  load_coeffs();
   load_inputs();
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_ITEMS) : "memory");  // the weight DMA has landed (the loads are younger)
   __syncthreads();
@@ -558,7 +590,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 #ifndef UNETPP_WINO_EXP_NO_DMA
       if constexpr (g == 1) dma_weights(other + IN_FLOATS, dma_source());
 #endif
-      if constexpr (g == 2) advance();
+      if constexpr (g == 2) {
+        advance();
+        load_coeffs();
+      }
 #ifndef UNETPP_WINO_EXP_NO_LOADS
       if constexpr (g == 3) load_inputs();
 #endif
@@ -684,25 +719,31 @@ int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
   const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(kThreads);
   bool narrow = true;  // no output view wider than 16 channels: the second column half is never used
   for (int i = 0; i < d->n_out; ++i) narrow = narrow && d->out[i].c_len <= 16;
-  // lean staging: plain launch-sized fp32 tensors, no transform on load, whole 8-channel chunks, 2 GB at most
-  bool lean = getenv("UNETPP_WINO_NO_LEAN") == nullptr;
+  // lean staging: launch-sized fp32 tensors, whole 8-channel chunks, 2 GB at most; mode 1 = no transform on load
+  bool lean = getenv("UNETPP_WINO_NO_LEAN") == nullptr, fold = false;
   for (int i = 0; i < d->n_in; ++i) {
     const unetpp_view& v = d->in[i];
-    lean = lean && v.scale == nullptr && v.relu == 0 && (v.c_len & 7) == 0 && v.Hs == d->H && v.Ws == d->W &&
-           v.sy == 1 && v.sx == 1 && v.oy == 0 && v.ox == 0 &&
-           static_cast<long>(d->N) * v.Hs * v.Ws * v.C * 4 <= 0x7fffffffL;
+    lean = lean && (v.c_len & 7) == 0 && v.Hs == d->H && v.Ws == d->W && v.sy == 1 && v.sx == 1 && v.oy == 0 &&
+           v.ox == 0 && static_cast<long>(d->N) * v.Hs * v.Ws * v.C * 4 <= 0x7fffffffL;
+    fold = fold || v.scale != nullptr || v.relu != 0;
   }
-#define UNETPP_LAUNCH_WINO(L)                                                                          \
-  do {                                                                                                 \
-    if (narrow && lean) hipLaunchKernelGGL((gemm_wino_kernel<L, 1, true>), grid, block, 0, st, a);     \
-    else if (narrow) hipLaunchKernelGGL((gemm_wino_kernel<L, 1, false>), grid, block, 0, st, a);       \
-    else if (lean) hipLaunchKernelGGL((gemm_wino_kernel<L, 2, true>), grid, block, 0, st, a);          \
-    else hipLaunchKernelGGL((gemm_wino_kernel<L, 2, false>), grid, block, 0, st, a);                   \
+  const int mode = !lean ? 0 : (fold ? 2 : 1);
+#define UNETPP_LAUNCH_WINO_M(L, NHV)                                                                    \
+  do {                                                                                                  \
+    if (mode == 0) hipLaunchKernelGGL((gemm_wino_kernel<L, NHV, 0>), grid, block, 0, st, a);            \
+    else if (mode == 1) hipLaunchKernelGGL((gemm_wino_kernel<L, NHV, 1>), grid, block, 0, st, a);       \
+    else hipLaunchKernelGGL((gemm_wino_kernel<L, NHV, 2>), grid, block, 0, st, a);                      \
+  } while (0)
+#define UNETPP_LAUNCH_WINO(L)                 \
+  do {                                        \
+    if (narrow) UNETPP_LAUNCH_WINO_M(L, 1);   \
+    else UNETPP_LAUNCH_WINO_M(L, 2);          \
   } while (0)
   if (a.log2tw == 5) UNETPP_LAUNCH_WINO(5);
   else if (a.log2tw == 4) UNETPP_LAUNCH_WINO(4);
   else UNETPP_LAUNCH_WINO(3);
 #undef UNETPP_LAUNCH_WINO
+#undef UNETPP_LAUNCH_WINO_M
   note_kernel("gemm_wino_kernel");
   return launch_status();
 }
