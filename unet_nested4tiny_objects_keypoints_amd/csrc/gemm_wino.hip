@@ -168,6 +168,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       v_bytes = d.N * V.Hs * V.Ws * V.C * 4;  // <= 2 GB (launcher)
       v_pitch = V.C * 4;
       v_origin = V.c_off * 4;
+#ifdef UNETPP_WINO_EXP_DENSE  // experiment: 32-byte pixel pitch = every fetched cache line is used completely (wrong data)
+      v_pitch = 32;
+      v_origin = 0;
+#endif
       if constexpr (FOLD) {
         v_scale = V.scale;
         v_shift = V.shift;
