@@ -215,30 +215,56 @@ __global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : 3) : 3)) void
           acc[t][mt][r] = 0.f;
         }
         __builtin_amdgcn_wave_barrier();
+        // The four 16-byte pieces of this lane: offsets and validity first, then (read-modify-write launches only) all
+        // gate / previous-value reads in one batch, then the stores.  vmcnt counts in order: a read issued between two
+        // stores waits for the store before it, and hipcc guards every store that shares a path with a load by a
+        // counted wait -- plain launches therefore take a path of their own with nothing but LDS reads and stores.
+        const int q4 = (lane & 7) << 2;  // first column of the piece
+        unsigned offs[4];  // elements: the fast kernels only take tensors below 2^31 elements (fast_args)
+        bool live[4];
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
-          const int pi = (lane >> 3) + 8 * pass, q4 = (lane & 7) << 2;  // pixel inside the MFMA tile, first column
+          const int pi = (lane >> 3) + 8 * pass;  // pixel inside the MFMA tile
           const int p = 64 * wave + 32 * mt + pi;
           const int py = p >> LOG2TW, px = p & (TW - 1);
-          f32x4 v = *reinterpret_cast<const f32x4*>(&scratch[pi * 32 + q4]);
-          if (q4 < tc.n_cnt && (interior || ((g.ty0 + py < d.H) && (g.tx0 + px < d.W)))) {
-            const long off = tile_base4 + py * row_stride + px * col_stride + q4;
-            f32x4 gt = {1.f, 1.f, 1.f, 1.f};
-            if (O.gate != nullptr) gt = *reinterpret_cast<const f32x4*>(O.gate + off);
-            if (O.gate != nullptr && !O.gate_sum) {
+          live[pass] = q4 < tc.n_cnt && (interior || ((g.ty0 + py < d.H) && (g.tx0 + px < d.W)));
+          offs[pass] = static_cast<unsigned>(tile_base4 + py * row_stride + px * col_stride + q4);
+        }
+        const bool has_gate = O.gate != nullptr, acc_out = O.accumulate != 0;  // uniform
+        if (!has_gate && !acc_out) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = (gt[e] > 0.f) ? v[e] : 0.f;
-            }
-            if (O.accumulate) {
-              const f32x4 old = *reinterpret_cast<const f32x4*>(O.ptr + off);
+          for (int pass = 0; pass < 4; ++pass) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&scratch[((lane >> 3) + 8 * pass) * 32 + q4]);
+            if (live[pass]) *reinterpret_cast<f32x4*>(O.ptr + offs[pass]) = v;
+          }
+        } else {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += old[e];
-            }
-            if (O.gate != nullptr && O.gate_sum) {
+          for (int half = 0; half < 2; ++half) {  // two pieces per batch: four would spill under the 168-register bound
+            f32x4 gt[2], old[2];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = (gt[e] > 0.f) ? v[e] : 0.f;
+            for (int u = 0; u < 2; ++u) {  // dead pieces read the tile's first (always valid) address
+              const unsigned lo = live[2 * half + u] ? offs[2 * half + u] : static_cast<unsigned>(tile_base4);
+              if (has_gate) gt[u] = *reinterpret_cast<const f32x4*>(O.gate + lo);
+              if (acc_out) old[u] = *reinterpret_cast<const f32x4*>(O.ptr + lo);
             }
-            *reinterpret_cast<f32x4*>(O.ptr + off) = v;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int pass = 2 * half + u;
+              f32x4 v = *reinterpret_cast<const f32x4*>(&scratch[((lane >> 3) + 8 * pass) * 32 + q4]);
+              if (has_gate && !O.gate_sum) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (gt[u][e] > 0.f) ? v[e] : 0.f;
+              }
+              if (acc_out) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += old[u][e];
+              }
+              if (has_gate && O.gate_sum) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (gt[u][e] > 0.f) ? v[e] : 0.f;
+              }
+              if (live[pass]) *reinterpret_cast<f32x4*>(O.ptr + offs[pass]) = v;
+            }
           }
         }
         __builtin_amdgcn_wave_barrier();

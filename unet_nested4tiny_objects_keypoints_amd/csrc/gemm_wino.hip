@@ -408,8 +408,31 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       // store hit 64 distinct banks. ----
       float* scratch = in_tile + wave * 1024;  // in_tile is free between the barriers
       const int sw_lane = g * 32 + (t16 ^ ((g >> 1) << 4));
+      const bool has_gate = gbase != nullptr, acc_out = O.accumulate != 0;  // uniform
 #pragma unroll
       for (int ap = 0; ap < 2; ++ap) {  // output row inside the 2x2 tile
+        // The gate / previous-value reads of the four store passes are requested HERE, in front of the output transform:
+        // vmcnt counts in order, so a read issued between two stores would wait for the store before it (a memory round
+        // trip per pass, eight per unit: the input-gradient launches ran 10 % behind the forward ones for this).
+        const int q4 = (lane & 7) << 2;  // first column of this lane's 16-byte piece
+        unsigned off[4];
+        f32x4 gt[4], old[4];
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int ps = (lane >> 3) + 8 * pass;  // pixel slot (rr, bp, g)
+          const int tile = 16 * wave + 4 * (ps & 3) + (ps >> 3);
+          const unsigned py = 2 * (tile / TXN) + ap, px = 2 * (tile % TXN) + ((ps >> 2) & 1);
+          off[pass] = py * rs + px * cs + q4;
+          if (NH == 1 && q4 >= 16) off[pass] = 0;  // NH = 1: these lanes store nothing; any valid address will do
+        }
+        if (has_gate) {
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) gt[pass] = *reinterpret_cast<const f32x4*>(gbase + off[pass]);
+        }
+        if (acc_out) {
+#pragma unroll
+          for (int pass = 0; pass < 4; ++pass) old[pass] = *reinterpret_cast<const f32x4*>(obase + off[pass]);
+        }
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
 #pragma unroll
@@ -429,36 +452,35 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
           }
         }
         __builtin_amdgcn_wave_barrier();
+        if (!has_gate && !acc_out) {  // plain stores on a path of their own: no load in it, so hipcc puts no vmcnt wait
+#pragma unroll                        // between the stores (on the shared path every store waits for all but three)
+          for (int pass = 0; pass < 4; ++pass) {
+            const int ps = (lane >> 3) + 8 * pass;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&scratch[ps * 32 + (q4 ^ (((ps & 3) >> 1) << 4))]);
+            if (q4 < 16 * NH) *reinterpret_cast<f32x4*>(obase + off[pass]) = v;
+          }
+          __builtin_amdgcn_wave_barrier();
+          continue;
+        }
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
-          const int ps = (lane >> 3) + 8 * pass, q4 = (lane & 7) << 2;  // pixel slot (rr, bp, g), first column
+          const int ps = (lane >> 3) + 8 * pass;
           const int gg = ps & 3;
-          const int tile = 16 * wave + 4 * gg + (ps >> 3);
-          const unsigned py = 2 * (tile / TXN) + ap, px = 2 * (tile % TXN) + ((ps >> 2) & 1);
-          const unsigned off = py * rs + px * cs + q4;
           f32x4 v = *reinterpret_cast<const f32x4*>(&scratch[ps * 32 + (q4 ^ ((gg >> 1) << 4))]);
           if (q4 >= 16 * NH) continue;  // NH = 1: only 16 columns exist
-          if (gbase != nullptr) {
-            const f32x4 gt = *reinterpret_cast<const f32x4*>(gbase + off);
-            if (!O.gate_sum) {
+          if (has_gate && !O.gate_sum) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = (gt[e] > 0.f) ? v[e] : 0.f;
-            }
-            if (O.accumulate) {
-              const f32x4 old = *reinterpret_cast<const f32x4*>(obase + off);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += old[e];
-            }
-            if (O.gate_sum) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = (gt[e] > 0.f) ? v[e] : 0.f;
-            }
-          } else if (O.accumulate) {
-            const f32x4 old = *reinterpret_cast<const f32x4*>(obase + off);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += old[e];
+            for (int e = 0; e < 4; ++e) v[e] = (gt[pass][e] > 0.f) ? v[e] : 0.f;
           }
-          *reinterpret_cast<f32x4*>(obase + off) = v;
+          if (acc_out) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += old[pass][e];
+          }
+          if (has_gate && O.gate_sum) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (gt[pass][e] > 0.f) ? v[e] : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(obase + off[pass]) = v;
         }
         __builtin_amdgcn_wave_barrier();
       }
