@@ -651,3 +651,43 @@ def test_partial_sum_reductions_two_stage(dev, rows, c):
     assert _lib.lib().unetpp_bn_bwd_finalize_ws(p(part), rows, c, p(dgamma), p(dbeta), None if ws is None else p(ws),
                                                 ops._WS_ROWS, None) == 0
     assert torch.allclose(dbeta.double().cpu(), tot[:, 0], rtol=1e-6) and torch.allclose(dgamma.double().cpu(), tot[:, 1], rtol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, [32], 32), (1, 64, 64, [32, 32, 32, 32], 32), (2, 24, 40, [8, 16], 24),
+                                   (1, 5, 7, [8], 8), (3, 16, 16, [64, 32], 96), (1, 128, 128, [64], 64)])
+@pytest.mark.parametrize("fold", [False, True])
+def test_wino_lean_and_general_kernels_agree(dev, shape, fold, monkeypatch):
+    """The lean instantiations of the Winograd GEMM (buffer loads with hardware zero padding, staging inside the MFMA
+    groups; mode 2 with the BatchNorm fold) and the general one are the same function of their inputs, bit for bit:
+    output with bias + ReLU, gated accumulation, and the BatchNorm partial sums."""
+    from unet_nested4tiny_objects_keypoints_amd import engine, ops
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    b, h, w, cins, co = shape
+    g = torch.Generator().manual_seed(17)
+    srcs = [nhwc(torch.randn(b, c, h, w, generator=g)) for c in cins]
+    coef = [(torch.randn(c, generator=g).to(dev), torch.randn(c, generator=g).to(dev)) for c in cins]
+    wp = engine.pack_conv_fwd((torch.randn(co, sum(cins), 3, 3, generator=g) * 0.2).cuda())
+    bias = torch.randn(co, generator=g).cuda()
+    gate = nhwc(torch.randn(b, co, h, w, generator=g))
+    prev = nhwc(torch.randn(b, co, h, w, generator=g))
+
+    def views():
+        if not fold:
+            return [V(s) for s in srcs]
+        return [V(s, scale=sc, shift=sh, relu=(i % 2 == 0)) if i != 1 else V(s) for i, (s, (sc, sh)) in enumerate(zip(srcs, coef))]
+
+    res = []
+    for general in (False, True):
+        if general:
+            monkeypatch.setenv("UNETPP_WINO_NO_LEAN", "1")
+        else:
+            monkeypatch.delenv("UNETPP_WINO_NO_LEAN", raising=False)
+        out = torch.empty(b, h, w, co, device=dev)
+        part = torch.empty(ops.gemm_pixel_blocks(b, h, w) * co * 2, device=dev)
+        ops.gemm_fwd(b, h, w, 9, views(), [V(out, relu=True)], wp, bias, part)
+        acc = prev.clone()
+        ops.gemm_fwd(b, h, w, 9, views(), [V(acc, gate=gate, accumulate=True)], wp)
+        res.append((out, part, acc))
+    monkeypatch.delenv("UNETPP_WINO_NO_LEAN", raising=False)
+    for a, c in zip(res[0], res[1]):
+        assert torch.equal(a, c)
