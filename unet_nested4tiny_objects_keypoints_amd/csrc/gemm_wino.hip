@@ -68,6 +68,27 @@ __device__ __forceinline__ void wino_input_transform(const float (&dd)[16], floa
   }
 }
 
+// the same on register pairs: dd[2 * i + p] = (d[i][2p], d[i][2p + 1]); 16 packed adds, bit-identical results
+__device__ __forceinline__ void wino_input_transform_pk(const f32x2_t (&dd)[8], float (&V)[16]) {
+  f32x2_t t[8];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    t[0 + p] = pk_sub(dd[0 + p], dd[4 + p]);  // row 0 - row 2
+    t[2 + p] = pk_add(dd[2 + p], dd[4 + p]);  // row 1 + row 2
+    t[4 + p] = pk_sub(dd[4 + p], dd[2 + p]);  // row 2 - row 1
+    t[6 + p] = pk_sub(dd[2 + p], dd[6 + p]);  // row 1 - row 3
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2_t va = pk_sub_add_x(t[2 * i], t[2 * i + 1]);  // (t0 - t2, t1 + t2)
+    const f32x2_t vb = pk_cross_sub(t[2 * i], t[2 * i + 1]);  // (t2 - t1, t1 - t3)
+    V[4 * i + 0] = va[0];
+    V[4 * i + 1] = va[1];
+    V[4 * i + 2] = vb[0];
+    V[4 * i + 3] = vb[1];
+  }
+}
+
 constexpr int WKC = 8;      // channels per K chunk
 constexpr int WNC = 32;     // columns per unit
 constexpr int WP = 10;      // LDS pixel stride of the input patch (floats): 8 channels + 2 pad
@@ -580,11 +601,24 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     // ---- this chunk's first LDS operands are requested before the staging work below, which covers their latency
     const unsigned in_b = lds_offset(in_tile) + a_base * 4, w_b = lds_offset(w_tile) + b_base * 4;
     float dd[16], ddn[16], V[16];
+    // LEAN: the window is read pairwise (ds_read2_b32: elements j, j + 1 of a row are WP floats apart) into register
+    // pairs, one base register per window row, and transformed with packed adds: half the LDS and VALU instructions
+    f32x2_t dp[8], dpn[8];
+    unsigned row_b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) row_b[i] = in_b + i * HWp * WP * 4;
     f32x4 us[2][2];  // two register sets of four weight fragments (steps 4g .. 4g+3), read one group ahead
-    static_for<16>([&](auto ic) {
-      constexpr int e = decltype(ic)::v;
-      lds_read_b32<((e / 4) * HWp + (e % 4)) * WP * 4>(dd[e], in_b);
-    });
+    if constexpr (LEAN) {
+      static_for<8>([&](auto ic) {
+        constexpr int e = decltype(ic)::v, j = 2 * (e & 1);
+        lds_read2_b32<j * WP, (j + 1) * WP>(dp[e], row_b[e >> 1]);
+      });
+    } else {
+      static_for<16>([&](auto ic) {
+        constexpr int e = decltype(ic)::v;
+        lds_read_b32<((e / 4) * HWp + (e % 4)) * WP * 4>(dd[e], in_b);
+      });
+    }
     lds_read2st64_b64<0, 1>(us[0][0], w_b);
     lds_read2st64_b64<2, 3>(us[0][1], w_b);
 
@@ -630,9 +664,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     // channel (no back-to-back dependence).  Raised wave priority for the MFMA phase: the co-resident workgroup's wave
     // on this SIMD is usually in its staging or epilogue VALU code, and the matrix pipe should never wait behind that.
     __builtin_amdgcn_s_setprio(2);
-    lds_wait16(dd);
-    lds_wait(us[0][0], us[0][1]);
-    wino_input_transform(dd, V);
+    if constexpr (LEAN) {
+      lds_wait8x2(dp);
+      lds_wait(us[0][0], us[0][1]);
+      wino_input_transform_pk(dp, V);
+    } else {
+      lds_wait16(dd);
+      lds_wait(us[0][0], us[0][1]);
+      wino_input_transform(dd, V);
+    }
     static_for<8>([&](auto gc) {  // group g = steps 4g .. 4g+3 of the chunk's 32 ([s][xi]); 8 MFMAs each
       constexpr int g = decltype(gc)::v, cs = g & 1, ns = cs ^ 1;
       if constexpr (g + 1 < 8) {
@@ -640,10 +680,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
         lds_read2st64_b64<4 * (g + 1) + 2, 4 * (g + 1) + 3>(us[ns][1], w_b);
       }
       if constexpr (g == 0) {  // the second channel's window, needed from group 4 on
-        static_for<16>([&](auto ic) {
-          constexpr int e = decltype(ic)::v;
-          lds_read_b32<(((e / 4) * HWp + (e % 4)) * WP + 1) * 4>(ddn[e], in_b);
-        });
+        if constexpr (LEAN) {
+          static_for<8>([&](auto ic) {
+            constexpr int e = decltype(ic)::v, j = 2 * (e & 1);
+            lds_read2_b32<j * WP + 1, (j + 1) * WP + 1>(dpn[e], row_b[e >> 1]);
+          });
+        } else {
+          static_for<16>([&](auto ic) {
+            constexpr int e = decltype(ic)::v;
+            lds_read_b32<(((e / 4) * HWp + (e % 4)) * WP + 1) * 4>(ddn[e], in_b);
+          });
+        }
       }
       // fences: the group's MFMAs (and the transform arithmetic feeding them) stay between the reads issued above
       // and the wait below -- left alone, the scheduler puts the reads straight in front of the wait again
@@ -658,11 +705,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       }
       staging_piece(gc);
       WINO_FENCE();
-      if constexpr (g == 0) lds_wait16(ddn);
+      if constexpr (g == 0) {
+        if constexpr (LEAN) lds_wait8x2(dpn);
+        else lds_wait16(ddn);
+      }
       if constexpr (g + 1 < 8) lds_wait(us[ns][0], us[ns][1]);
       if constexpr (g == 3) {
         WINO_STAMP(2);  // 2: first half of the MFMA phase
-        wino_input_transform(ddn, V);  // (inside group 4's fences it interleaves with the MFMAs, and is 1 % slower)
+        if constexpr (LEAN) wino_input_transform_pk(dpn, V);
+        else wino_input_transform(ddn, V);  // (inside group 4's fences it interleaves with the MFMAs, and is 1 % slower)
       }
     });
     __builtin_amdgcn_s_setprio(0);

@@ -36,6 +36,37 @@ template <int O0, int O1>  // two 8-byte reads 512 * O0 and 512 * O1 bytes above
 __device__ __forceinline__ void lds_read2st64_b64(f32x4& v, unsigned addr) {
   asm volatile("ds_read2st64_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1));
 }
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <int O0, int O1>  // two 4-byte reads 4 * O0 and 4 * O1 bytes above addr (O0, O1 <= 255) into a register pair
+__device__ __forceinline__ void lds_read2_b32(f32x2_t& v, unsigned addr) {
+  asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1));
+}
+__device__ __forceinline__ void lds_wait8x2(f32x2_t (&d)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]));
+}
+// Packed fp32 adds on register pairs (v_pk_add_f32, one issue slot for two adds; tools/probes/pk_add_probe.hip checks
+// the operand-select / negate modifiers on the device).  Results are bit-identical to the scalar expressions.
+__device__ __forceinline__ f32x2_t pk_add(f32x2_t a, f32x2_t b) {  // (a.x + b.x, a.y + b.y)
+  f32x2_t r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x2_t pk_sub(f32x2_t a, f32x2_t b) {  // (a.x - b.x, a.y - b.y)
+  f32x2_t r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x2_t pk_sub_add_x(f32x2_t a, f32x2_t b) {  // (a.x - b.x, a.y + b.x)
+  f32x2_t r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f32x2_t pk_cross_sub(f32x2_t a, f32x2_t b) {  // (b.x - a.y, a.y - b.y)
+  f32x2_t r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(b), "v"(a));
+  return r;
+}
 __device__ __forceinline__ void lds_wait(f32x4& a, f32x4& b) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
 }
