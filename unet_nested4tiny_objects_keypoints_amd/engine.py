@@ -99,6 +99,17 @@ class _Saved:
     pass
 
 
+# nn.BatchNorm2d counts its training batches; the counters of a pass are bumped together by one multi-tensor add
+# at the end of the forward (eight separate one-element adds cost 5 us of device time each)
+_PENDING_COUNTERS: list = []
+
+
+def flush_batch_counters():
+    if _PENDING_COUNTERS:
+        torch._foreach_add_(_PENDING_COUNTERS, 1)
+        _PENDING_COUNTERS.clear()
+
+
 def _conv_bn_fwd(ins, conv, bn, y, b, h, w, training):
     """conv3x3 + bias -> y, with the BatchNorm partial sums taken in the GEMM epilogue (training)."""
     co = conv.out_channels
@@ -109,7 +120,7 @@ def _conv_bn_fwd(ins, conv, bn, y, b, h, w, training):
         ops.gemm_fwd(b, h, w, 9, ins, [V(y)], wp, conv.bias.detach(), partial)
         stats = ops.bn_finalize(partial, blocks, co, b * h * w, bn.weight.detach(), bn.bias.detach(), bn.eps,
                                 bn.momentum, bn.running_mean, bn.running_var)
-        bn.num_batches_tracked.add_(1)
+        _PENDING_COUNTERS.append(bn.num_batches_tracked)
         return stats  # (mean, invstd, scale, shift)
     ops.gemm_fwd(b, h, w, 9, ins, [V(y)], wp, conv.bias.detach(), None)
     scale, shift = ops.bn_eval_coeffs(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps)
@@ -212,15 +223,19 @@ def _dropout_config(model, training):
 def forward_impl(model, x, training: bool, save: bool):
     """Runs the forward DAG of models/unet.py:255-300.  Returns (outputs, saved-for-backward or None)."""
     _check_input(model, x)
-    if not USE_PACK_PLAN:
-        return _forward_impl(model, x, training, save)
-    plan = _plan_of(model)
-    plan.begin("fwd")  # every weight image of the pass in one launch (after the first pass recorded the jobs)
-    ops.set_pack_plan(plan)
+    _PENDING_COUNTERS.clear()
     try:
-        return _forward_impl(model, x, training, save)
+        if not USE_PACK_PLAN:
+            return _forward_impl(model, x, training, save)
+        plan = _plan_of(model)
+        plan.begin("fwd")  # every weight image of the pass in one launch (after the first pass recorded the jobs)
+        ops.set_pack_plan(plan)
+        try:
+            return _forward_impl(model, x, training, save)
+        finally:
+            ops.set_pack_plan(None)
     finally:
-        ops.set_pack_plan(None)
+        flush_batch_counters()
 
 
 def _plan_of(model) -> "ops.PackPlan":

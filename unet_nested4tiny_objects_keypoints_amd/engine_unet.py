@@ -139,15 +139,18 @@ def _backward(model, s, d_out, want_input_grad: bool):
 
 
 def _with_plan(model, phase, fn):
-    if not engine.USE_PACK_PLAN:
-        return fn()
-    plan = _plan_of(model)
-    plan.begin(phase)
-    ops.set_pack_plan(plan)
     try:
-        return fn()
+        if not engine.USE_PACK_PLAN:
+            return fn()
+        plan = _plan_of(model)
+        plan.begin(phase)
+        ops.set_pack_plan(plan)
+        try:
+            return fn()
+        finally:
+            ops.set_pack_plan(None)
     finally:
-        ops.set_pack_plan(None)
+        engine.flush_batch_counters()  # the BatchNorm batch counters of a training forward, one multi-tensor add
 
 
 class _UNetFn(torch.autograd.Function):
