@@ -461,3 +461,31 @@ def test_bf16_unsupported_configurations_raise(dev):
             m(x)
     with pytest.raises(ValueError):
         UNet_Nested().set_activation_dtype(torch.float16)
+
+
+def test_bf16_batched_weight_images_match_single_packing(dev):
+    """The row-wise batched packer (unetpp_gemm_pack_weight_images) and the per-launch packer build the same bf16
+    images: a model stepped with the pack plan and a copy stepped without it stay bit-identical."""
+    import copy
+
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, UNet_Nested, engine, train_step
+    torch.manual_seed(23)
+    m = UNet_Nested(in_channels=3, n_classes=4, feature_scale=4).to(dev).train()
+    m.drop_out.p = 0.0
+    m.set_activation_dtype(torch.bfloat16)
+    ref = copy.deepcopy(m)
+    x = torch.randn(2, 3, 32, 48, device=dev)
+    t = torch.rand(2, 4, 32, 48, device=dev)
+    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+    opt_m, opt_r = torch.optim.SGD(m.parameters(), lr=0.05), torch.optim.SGD(ref.parameters(), lr=0.05)
+    for step in range(3):
+        outs_m, loss_m = train_step(m, opt_m, crit, x, t)
+        engine.USE_PACK_PLAN = False
+        try:
+            outs_r, loss_r = train_step(ref, opt_r, crit, x, t)
+        finally:
+            engine.USE_PACK_PLAN = True
+        assert all(torch.equal(a, b) for a, b in zip(outs_m, outs_r)), step
+        assert torch.equal(loss_m, loss_r)
+        for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+            assert torch.equal(p, q), (step, k)

@@ -44,6 +44,93 @@ __device__ __forceinline__ float wsrc_at(const unetpp_weight_src& w, int taps, i
   return w.src[tt * w.s_t + ki * w.s_k + ko * w.s_ko + ni * w.s_n + no * w.s_no];
 }
 
+// (tile, chunk) of an image row -> input view / first GEMM row of the chunk, output view / first GEMM column of the tile
+struct RowOrigin {
+  int k0, k_room;  // GEMM row of the chunk's channel 0; channels left in its view from there
+  int n0, n_room;  // GEMM column of the tile's column 0; columns left in its view from there
+};
+__device__ __forceinline__ RowOrigin row_origin(const PackGeom& g, int nt, int chunk) {
+  int kbase = 0, v = 0;
+  for (; v < g.n_in - 1; ++v) {
+    const int ch = (g.in_len[v] + g.kc - 1) / g.kc;
+    if (chunk < ch) break;
+    chunk -= ch;
+    kbase += g.in_len[v];
+  }
+  int col_base = 0, ov = 0;
+  for (; ov < g.n_out - 1; ++ov) {
+    const int tv = (g.out_len[ov] + g.ncol - 1) / g.ncol;
+    if (nt < tv) break;
+    nt -= tv;
+    col_base += g.out_len[ov];
+  }
+  RowOrigin o;
+  o.k0 = kbase + chunk * g.kc;
+  o.k_room = g.in_len[v] - chunk * g.kc;
+  o.n0 = col_base + nt * g.ncol;
+  o.n_room = g.out_len[ov] - nt * g.ncol;
+  return o;
+}
+
+// The batched pack kernel walks whole image rows: row = (tile, chunk[, tap]) is decoded once per workgroup iteration
+// (uniform: scalar unit), a thread only splits its slot's bit fields.  (Decoding per element cost ~80 instructions
+// per 4 bytes written: 175 us per launch for the 73 MB of bf16 images of the depth-5 network.)
+__device__ __forceinline__ void fill_image_row(const PackGeom& g, const unetpp_weight_src& w, long row, float* __restrict__ img) {
+  const int tid = threadIdx.x;
+  if (g.kind == kKindWino) {  // row = (tile, chunk): 256 (channel, column) pairs x 16 transform elements
+    const RowOrigin o = row_origin(g, static_cast<int>(row / g.n_chunks), static_cast<int>(row % g.n_chunks));
+    const int t = tid;  // nh | col << 1 | gq << 5 | s << 7
+    const int kk = 2 * ((t >> 5) & 3) + ((t >> 7) & 1), cl = 16 * (t & 1) + ((t >> 1) & 15);
+    float* dst = img + row * 4096 + (t & 127) + (static_cast<long>(t >> 7) << 11);
+    if (kk >= o.k_room || cl >= o.n_room) {
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) dst[xi << 7] = 0.f;
+      return;
+    }
+    const int k = o.k0 + kk, n = o.n0 + cl;
+    float tr[4][3];  // G g: row ra of G down the filter rows, per filter column
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float w0 = wsrc_at(w, 9, 0 * 3 + c, k, n), w1 = wsrc_at(w, 9, 1 * 3 + c, k, n), w2 = wsrc_at(w, 9, 2 * 3 + c, k, n);
+      tr[0][c] = w0;
+      tr[1][c] = 0.5f * (w0 + w1 + w2);
+      tr[2][c] = 0.5f * (w0 - w1 + w2);
+      tr[3][c] = w2;
+    }
+#pragma unroll
+    for (int ra = 0; ra < 4; ++ra) {
+      dst[(4 * ra + 0) << 7] = tr[ra][0];
+      dst[(4 * ra + 1) << 7] = 0.5f * (tr[ra][0] + tr[ra][1] + tr[ra][2]);
+      dst[(4 * ra + 2) << 7] = 0.5f * (tr[ra][0] - tr[ra][1] + tr[ra][2]);
+      dst[(4 * ra + 3) << 7] = tr[ra][2];
+    }
+    return;
+  }
+  // direct kernels: row = (tile, chunk, tap), 512 four-byte slots
+  const int tap = static_cast<int>(row % g.taps);
+  const long rc = row / g.taps;
+  const RowOrigin o = row_origin(g, static_cast<int>(rc / g.n_chunks), static_cast<int>(rc % g.n_chunks));
+  float* dst = img + row * 512;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int e = tid + q * 256;
+    if (g.kind == kKindBf16) {  // slot = two bf16: elements 2e, 2e+1 of [g 2][col 32][h 2][8]
+      const int i0 = 2 * e;
+      const int kk = 16 * ((i0 >> 9) & 1) + 8 * ((i0 >> 3) & 1) + (i0 & 7), cl = (i0 >> 4) & 31;
+      float a = 0.f, b = 0.f;
+      if (cl < o.n_room) {
+        if (kk < o.k_room) a = wsrc_at(w, g.taps, tap, o.k0 + kk, o.n0 + cl);
+        if (kk + 1 < o.k_room) b = wsrc_at(w, g.taps, tap, o.k0 + kk + 1, o.n0 + cl);
+      }
+      dst[e] = __uint_as_float(pack_bf2(a, b));
+    } else {  // [g 2][col 32][half' 2][4], half' = half ^ ((col>>3)&1)
+      const int j = (e >> 3) & 31;
+      const int kk = 8 * ((e >> 8) & 1) + 4 * (((e >> 2) & 1) ^ ((j >> 3) & 1)) + (e & 3);
+      dst[e] = (kk < o.k_room && j < o.n_room) ? wsrc_at(w, g.taps, tap, o.k0 + kk, o.n0 + j) : 0.f;
+    }
+  }
+}
+
 // value of image element i
 __device__ __forceinline__ float image_element(const PackGeom& g, const unetpp_weight_src& w, long i) {
   int kk, cin_local, tap = 0, xi = 0;
@@ -101,58 +188,6 @@ __device__ __forceinline__ float image_element(const PackGeom& g, const unetpp_w
   return rb == 0 ? t[0] : (rb == 1 ? 0.5f * (t[0] + t[1] + t[2]) : (rb == 2 ? 0.5f * (t[0] - t[1] + t[2]) : t[2]));
 }
 
-// Winograd images, the fast way: one thread per (tile, chunk, channel, column) reads the nine filter taps once and writes
-// all 16 elements of U = G g G^T (image_element recomputes the taps for every element: 16 x the loads and the index
-// arithmetic, ~70 us per pass of the headline network).  Same expressions, bit-identical values.
-// u = (tile * n_chunks + chunk) * 256 + t,  t = nh | col << 1 | gq << 5 | s << 7  (the image index without its xi bits)
-__device__ __forceinline__ void image_wino_column(const PackGeom& g, const unetpp_weight_src& w, long u, float* __restrict__ img) {
-  const int t = static_cast<int>(u & 255);
-  const long r = u >> 8;
-  const int nh = t & 1, col = (t >> 1) & 15, gq = (t >> 5) & 3, s = (t >> 7) & 1;
-  const int kk = 2 * gq + s, cin_local = 16 * nh + col;
-  int chunk = static_cast<int>(r % g.n_chunks);
-  int nt = static_cast<int>(r / g.n_chunks);
-  int kbase = 0, v = 0;
-  for (; v < g.n_in - 1; ++v) {
-    const int ch = (g.in_len[v] + g.kc - 1) / g.kc;
-    if (chunk < ch) break;
-    chunk -= ch;
-    kbase += g.in_len[v];
-  }
-  const int kin = chunk * g.kc + kk;
-  int col_base = 0, ov = 0;
-  for (; ov < g.n_out - 1; ++ov) {
-    const int tv = (g.out_len[ov] + g.ncol - 1) / g.ncol;
-    if (nt < tv) break;
-    nt -= tv;
-    col_base += g.out_len[ov];
-  }
-  const int cin = nt * g.ncol + cin_local;
-  float* dst = img + r * 4096 + (t & 127) + (static_cast<long>(s) << 11);
-  if (kin >= g.in_len[v] || cin >= g.out_len[ov]) {
-#pragma unroll
-    for (int xi = 0; xi < 16; ++xi) dst[xi << 7] = 0.f;
-    return;
-  }
-  const int k = kbase + kin, n = col_base + cin;
-  float tr[4][3];  // G g: row ra of G down the filter rows, per filter column
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float w0 = wsrc_at(w, 9, 0 * 3 + c, k, n), w1 = wsrc_at(w, 9, 1 * 3 + c, k, n), w2 = wsrc_at(w, 9, 2 * 3 + c, k, n);
-    tr[0][c] = w0;
-    tr[1][c] = 0.5f * (w0 + w1 + w2);
-    tr[2][c] = 0.5f * (w0 - w1 + w2);
-    tr[3][c] = w2;
-  }
-#pragma unroll
-  for (int ra = 0; ra < 4; ++ra) {
-    dst[(4 * ra + 0) << 7] = tr[ra][0];
-    dst[(4 * ra + 1) << 7] = 0.5f * (tr[ra][0] + tr[ra][1] + tr[ra][2]);
-    dst[(4 * ra + 2) << 7] = 0.5f * (tr[ra][0] - tr[ra][1] + tr[ra][2]);
-    dst[(4 * ra + 3) << 7] = tr[ra][2];
-  }
-}
-
 // slot i of the image: one float, or two bf16 (elements 2i, 2i+1) in the same 4 bytes
 __device__ __forceinline__ float image_slot(const PackGeom& g, const unetpp_weight_src& w, long i) {
   if (g.kind != kKindBf16) return image_element(g, w, i);
@@ -184,16 +219,8 @@ __global__ void pack_image_jobs_kernel(const unetpp_pack_job* __restrict__ jobs)
     finish_geom(g);
   }
   __syncthreads();
-  if (g.kind == kKindWino) {
-    const long units = g.floats >> 4;  // (tile, chunk, channel, column) quadruples
-    for (long u = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x; u < units;
-         u += static_cast<long>(gridDim.x) * blockDim.x)
-      image_wino_column(g, j.src, u, j.image);
-    return;
-  }
-  for (long i = blockIdx.x * static_cast<long>(blockDim.x) + threadIdx.x; i < g.floats;
-       i += static_cast<long>(gridDim.x) * blockDim.x)
-    j.image[i] = image_slot(g, j.src, i);
+  const long rows = g.floats / (g.kind == kKindWino ? 4096 : 512);
+  for (long row = blockIdx.x; row < rows; row += gridDim.x) fill_image_row(g, j.src, row, j.image);
 }
 
 bool geom_of(const unetpp_gemm_desc* d, PackGeom& g) {
