@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNETPP_ABI_VERSION 6
+#define UNETPP_ABI_VERSION 5
 #define UNETPP_MAX_VIEWS 8
 
 #define UNETPP_OK 0
@@ -171,14 +171,6 @@ int unetpp_bn_finalize(const float* partial, int64_t n_blocks, int32_t C, int64_
                        const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var,
                        float* mean, float* invstd, float* scale, float* shift, void* stream);
-/* The same with a caller-provided workspace of ws_rows x 2C doubles (not shared with a concurrent launch): layers with
- * many rows (one per 256-pixel patch: 8192 at 256x256, batch 32) are reduced in two coalesced stages, 4 us instead of
- * 13.  Few rows, or workspace == NULL: the one-kernel form above.  Totals are accumulated in double either way. */
-int unetpp_bn_finalize_ws(const float* partial, int64_t n_blocks, int32_t C, int64_t count,
-                          const float* gamma, const float* beta, float eps, float momentum,
-                          float* running_mean, float* running_var,
-                          float* mean, float* invstd, float* scale, float* shift,
-                          double* workspace, int64_t ws_rows, void* stream);
 /* eval mode: scale/shift from running statistics */
 int unetpp_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                           const float* running_var, float eps, int32_t C, float* scale, float* shift,
@@ -200,8 +192,6 @@ int unetpp_bn_bwd_reduce(const float* d_act, const float* y, const float* scale,
 /* sums the partials -> dgamma, dbeta; then dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M) (dy may alias d_act) */
 int unetpp_bn_bwd_finalize(const float* partial, int64_t n_blocks, int32_t C, float* dgamma, float* dbeta,
                            void* stream);
-int unetpp_bn_bwd_finalize_ws(const float* partial, int64_t n_blocks, int32_t C, float* dgamma, float* dbeta,
-                              double* workspace, int64_t ws_rows, void* stream);  /* see unetpp_bn_finalize_ws */
 int unetpp_bn_bwd_apply(const float* d_act, const float* y, const float* scale, const float* shift,
                         const float* mean, const float* invstd, const float* gamma,
                         const float* dgamma, const float* dbeta, int64_t pixels, int32_t C,

@@ -615,44 +615,6 @@ def test_layout_converters(dev):
     assert torch.equal(ops.nhwc_to_nchw(x.permute(0, 2, 3, 1).contiguous().cuda()).cpu(), x)
 
 
-@pytest.mark.parametrize("rows,c", [(8192, 32), (2048, 64), (777, 24), (300, 256), (130, 8), (40, 32)])
-def test_partial_sum_reductions_two_stage(dev, rows, c):
-    """BatchNorm forward / backward finalize over many partial rows: the two-stage workspace form (ops) against the
-    one-kernel form (called directly) and a float64 sum; both accumulate in double, so the results agree to the last
-    float bit or one ulp."""
-    import ctypes as C
-    from unet_nested4tiny_objects_keypoints_amd import _lib, ops
-    g = torch.Generator().manual_seed(31)
-    part = (torch.randn(rows, c, 2, generator=g) * 3 + 1).to(dev)
-    part[..., 1] = part[..., 1].abs() * 40 + 20  # sums of squares dominate the squared means
-    gamma, beta = torch.randn(c, generator=g).to(dev), torch.randn(c, generator=g).to(dev)
-    count = rows * 256
-    rm0, rv0 = torch.randn(c, generator=g).to(dev), torch.rand(c, generator=g).to(dev)
-    rm, rv = rm0.clone(), rv0.clone()
-    got = ops.bn_finalize(part.view(-1), rows, c, count, gamma, beta, 1e-5, 0.1, rm, rv)
-    rm1, rv1 = rm0.clone(), rv0.clone()
-    one = [torch.empty(c, device=dev) for _ in range(4)]
-    p = lambda t: C.c_void_p(t.data_ptr())
-    assert _lib.lib().unetpp_bn_finalize(p(part), rows, c, count, p(gamma), p(beta), 1e-5, 0.1, p(rm1), p(rv1),
-                                         *[p(t) for t in one], None) == 0
-    tot = part.double().sum(0).cpu()
-    m = tot[:, 0] / count
-    var = (tot[:, 1] / count - m * m).clamp_min(0)
-    inv = 1.0 / torch.sqrt(var + 1e-5)
-    ref = [m, inv, gamma.double().cpu() * inv, beta.double().cpu() - m * gamma.double().cpu() * inv]
-    for a, b, r in zip(got, one, ref):
-        assert torch.allclose(a, b, rtol=3e-7, atol=0)
-        assert torch.allclose(a.double().cpu(), r, rtol=1e-6, atol=1e-7)
-    assert torch.allclose(rm, rm1, rtol=3e-7, atol=0) and torch.allclose(rv, rv1, rtol=3e-7, atol=0)
-    # backward finalize: dbeta = sum of column 0, dgamma = sum of column 1
-    dgamma, dbeta = torch.empty(c, device=dev), torch.empty(c, device=dev)
-    ws = ops._reduce_workspace(rows, c, part.device)
-    assert (ws is None) == (rows < 128)
-    assert _lib.lib().unetpp_bn_bwd_finalize_ws(p(part), rows, c, p(dgamma), p(dbeta), None if ws is None else p(ws),
-                                                ops._WS_ROWS, None) == 0
-    assert torch.allclose(dbeta.double().cpu(), tot[:, 0], rtol=1e-6) and torch.allclose(dgamma.double().cpu(), tot[:, 1], rtol=1e-6)
-
-
 @pytest.mark.parametrize("shape", [(2, 32, 32, [32], 32), (1, 64, 64, [32, 32, 32, 32], 32), (2, 24, 40, [8, 16], 24),
                                    (1, 5, 7, [8], 8), (3, 16, 16, [64, 32], 96), (1, 128, 128, [64], 64)])
 @pytest.mark.parametrize("fold", [False, True])

@@ -18,7 +18,7 @@ INCLUDE = os.path.join(_REPO, "include")
 SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_wino.hip", "gemm_bf16.hip", "wgrad_bf16.hip", "pointwise_bf16.hip", "keypoints.hip", "weight_image.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "wgrad_wino.hip", "first_layer.hip", "pointwise.hip", "caller.hip")
 HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h", "lds_asm.h", "bf16_common.h", "dropout.h")
 MAX_VIEWS = 8
-ABI_VERSION = 6
+ABI_VERSION = 5
 # packed-f32 VALU (SLP-vectorised add pairs) costs issue slots beside MFMAs: keep the Winograd transforms scalar
 EXTRA_FLAGS = {"gemm_wino.hip": ("-fno-slp-vectorize",), "wgrad_wino.hip": ("-fno-slp-vectorize",)}
 GEMM_DIRECT = 1  # unetpp_gemm_desc.flags: direct summation only (no Winograd)
@@ -98,14 +98,12 @@ SIGNATURES = {
     "unetpp_wgrad_finish": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _I64, _I64, _I64, _I64, _P, _P]),
     "unetpp_pack_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _P]),
     "unetpp_bn_finalize": (C.c_int, [_P, _I64, _I32, _I64, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
-    "unetpp_bn_finalize_ws": (C.c_int, [_P, _I64, _I32, _I64, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "unetpp_bn_eval_coeffs": (C.c_int, [_P, _P, _P, _P, _F, _I32, _P, _P, _P]),
     "unetpp_affine_relu_pool": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
     "unetpp_maxpool_bwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "unetpp_bn_bwd_blocks": (_I64, [_I64, _I32]),
     "unetpp_bn_bwd_reduce": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P]),
     "unetpp_bn_bwd_finalize": (C.c_int, [_P, _I64, _I32, _P, _P, _P]),
-    "unetpp_bn_bwd_finalize_ws": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _I64, _P]),
     "unetpp_bn_bwd_apply": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P]),
     "unetpp_bn_bwd_pool_ok": (C.c_int, [_I32, _I32, _I32, _I32]),
     "unetpp_bn_bwd_reduce_pool": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),

@@ -112,102 +112,6 @@ __global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(const float* p
   }
 }
 
-// ---- two-stage variant for many rows (the level-0 layers hold one row per 256-pixel patch: 8192 rows at 256x256,
-// batch 32): stage 1 reads the rows COALESCED -- consecutive threads take consecutive (channel, sum / sum of squares)
-// elements of a row, groups of threads take different rows -- and leaves one double row per workgroup in a
-// caller-provided workspace; stage 2 adds those rows in workgroup order.  (The one-kernel form above reads 8 bytes
-// per thread at a 2C-float stride with one workgroup per channel: 13 us for the 2 MB of a level-0 layer.)
-constexpr int kRedThreads = 256;
-__global__ __launch_bounds__(kRedThreads) void bn_partials_stage1_kernel(const float* __restrict__ partial, long n_blocks,
-                                                                        int E, double* __restrict__ ws) {
-  __shared__ double red[kRedThreads];
-  const int tid = threadIdx.x;
-  const long per = (n_blocks + gridDim.x - 1) / gridDim.x;
-  const long lo = blockIdx.x * per, hi = min(lo + per, n_blocks);
-  if (E <= kRedThreads) {
-    const int R = kRedThreads / E;  // rows read side by side
-    const int sr = tid / E, e = tid - sr * E;
-    double acc = 0.0;
-    if (sr < R) {
-      long r = lo + sr;
-      for (; r + 3L * R < hi; r += 4L * R) {
-        float v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = partial[(r + static_cast<long>(u) * R) * E + e];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc += static_cast<double>(v[u]);
-      }
-      for (; r < hi; r += R) acc += static_cast<double>(partial[r * E + e]);
-    }
-    red[tid] = acc;
-    __syncthreads();
-    if (tid < E) {
-      double t = 0.0;
-      for (int q = 0; q < R; ++q) t += red[q * E + tid];  // fixed order
-      ws[static_cast<long>(blockIdx.x) * E + tid] = t;
-    }
-  } else {
-    for (int e = tid; e < E; e += kRedThreads) {
-      double acc = 0.0;
-      for (long r = lo; r < hi; ++r) acc += static_cast<double>(partial[r * E + e]);
-      ws[static_cast<long>(blockIdx.x) * E + e] = acc;
-    }
-  }
-}
-// totals of channel c from the workspace rows: one wave per channel, lane l takes rows l, l + 64, ...; fixed shuffle tree
-__device__ __forceinline__ void sum_ws_rows(const double* __restrict__ ws, int rows, int E, int c, double& s1, double& s2) {
-  double a = 0.0, b = 0.0;
-  for (int w = threadIdx.x; w < rows; w += 64) {
-    const double2 v = *reinterpret_cast<const double2*>(ws + static_cast<long>(w) * E + 2 * c);
-    a += v.x;
-    b += v.y;
-  }
-#pragma unroll
-  for (int m = 32; m > 0; m >>= 1) {
-    a += __shfl_xor(a, m);
-    b += __shfl_xor(b, m);
-  }
-  s1 = a;
-  s2 = b;
-}
-__device__ __forceinline__ void bn_finish_channel(int c, double s1, double s2, long count, const float* gamma,
-                                                   const float* beta, float eps, float momentum, float* running_mean,
-                                                   float* running_var, float* mean, float* invstd, float* scale,
-                                                   float* shift) {
-  const double m = s1 / static_cast<double>(count);
-  double var = s2 / static_cast<double>(count) - m * m;
-  if (var < 0.0) var = 0.0;
-  const double is = 1.0 / sqrt(var + static_cast<double>(eps));
-  const double sc = static_cast<double>(gamma[c]) * is;
-  mean[c] = static_cast<float>(m);
-  invstd[c] = static_cast<float>(is);
-  scale[c] = static_cast<float>(sc);
-  shift[c] = static_cast<float>(static_cast<double>(beta[c]) - m * sc);
-  if (running_mean != nullptr) {
-    const double unbiased = count > 1 ? var * static_cast<double>(count) / static_cast<double>(count - 1) : var;
-    running_mean[c] = static_cast<float>((1.0 - momentum) * running_mean[c] + momentum * m);
-    running_var[c] = static_cast<float>((1.0 - momentum) * running_var[c] + momentum * unbiased);
-  }
-}
-__global__ void bn_finalize_stage2_kernel(const double* __restrict__ ws, int rows, int C, long count, const float* gamma,
-                                          const float* beta, float eps, float momentum, float* running_mean,
-                                          float* running_var, float* mean, float* invstd, float* scale, float* shift) {
-  const int c = blockIdx.x;  // one 64-thread workgroup per channel
-  double s1, s2;
-  sum_ws_rows(ws, rows, 2 * C, c, s1, s2);
-  if (threadIdx.x == 0)
-    bn_finish_channel(c, s1, s2, count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
-}
-__global__ void bn_bwd_finalize_stage2_kernel(const double* __restrict__ ws, int rows, int C, float* dgamma, float* dbeta) {
-  const int c = blockIdx.x;
-  double s1, s2;
-  sum_ws_rows(ws, rows, 2 * C, c, s1, s2);
-  if (threadIdx.x == 0) {
-    dbeta[c] = static_cast<float>(s1);
-    dgamma[c] = static_cast<float>(s2);
-  }
-}
-
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                       int C, float* scale, float* shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1102,46 +1006,6 @@ extern "C" int unetpp_bn_finalize(const float* partial, int64_t n_blocks, int32_
   if ((reinterpret_cast<uintptr_t>(partial) & 7) != 0) return UNETPP_EINVAL;  // rows are read as (sum, sum of squares) pairs
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(fin_threads(n_blocks)), 0, ST(stream), partial, n_blocks, C,
                      count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
-  return launch_status();
-}
-
-namespace {
-// stage-1 grid of the workspace variants: every workgroup should own at least 16 rows, and there is no point in more
-// workgroups than the workspace has rows
-inline int ws_grid(int64_t n_blocks, int64_t ws_rows) {
-  long g = n_blocks / 16;
-  if (g > ws_rows) g = ws_rows;
-  if (g > 512) g = 512;
-  return static_cast<int>(g);
-}
-}  // namespace
-
-extern "C" int unetpp_bn_finalize_ws(const float* partial, int64_t n_blocks, int32_t C, int64_t count, const float* gamma,
-                                     const float* beta, float eps, float momentum, float* running_mean,
-                                     float* running_var, float* mean, float* invstd, float* scale, float* shift,
-                                     double* workspace, int64_t ws_rows, void* stream) {
-  const int g = (workspace != nullptr && C >= 1) ? ws_grid(n_blocks, ws_rows) : 0;
-  if (g < 8)  // few rows (or no workspace): the one-kernel form
-    return unetpp_bn_finalize(partial, n_blocks, C, count, gamma, beta, eps, momentum, running_mean, running_var, mean,
-                              invstd, scale, shift, stream);
-  if (!partial || n_blocks < 1 || count < 1 || !gamma || !beta || !mean || !invstd || !scale || !shift) return UNETPP_EINVAL;
-  if ((running_mean == nullptr) != (running_var == nullptr)) return UNETPP_EINVAL;
-  hipLaunchKernelGGL(bn_partials_stage1_kernel, dim3(g), dim3(kRedThreads), 0, ST(stream), partial, n_blocks, 2 * C,
-                     workspace);
-  hipLaunchKernelGGL(bn_finalize_stage2_kernel, dim3(C), dim3(64), 0, ST(stream), workspace, g, C, count,
-                     gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
-  return launch_status();
-}
-
-extern "C" int unetpp_bn_bwd_finalize_ws(const float* partial, int64_t n_blocks, int32_t C, float* dgamma, float* dbeta,
-                                         double* workspace, int64_t ws_rows, void* stream) {
-  const int g = (workspace != nullptr && C >= 1) ? ws_grid(n_blocks, ws_rows) : 0;
-  if (g < 8) return unetpp_bn_bwd_finalize(partial, n_blocks, C, dgamma, dbeta, stream);
-  if (!partial || n_blocks < 1 || !dgamma || !dbeta) return UNETPP_EINVAL;
-  hipLaunchKernelGGL(bn_partials_stage1_kernel, dim3(g), dim3(kRedThreads), 0, ST(stream), partial, n_blocks, 2 * C,
-                     workspace);
-  hipLaunchKernelGGL(bn_bwd_finalize_stage2_kernel, dim3(C), dim3(64), 0, ST(stream), workspace, g, C, dgamma,
-                     dbeta);
   return launch_status();
 }
 

@@ -395,24 +395,12 @@ def wgrad(n: int, h: int, w: int, taps: int, xs: Sequence[V], dys: Sequence[V], 
                                   dw_strides[2], dw_strides[3], _ptr(db), _stream()), "unetpp_wgrad_finish")
 
 
-_WS_ROWS = 256  # rows of the two-stage reductions' workspace (stage-1 workgroups)
-
-
-def _reduce_workspace(n_blocks, c, dev):
-    """Workspace of the two-stage partial-sum reductions (a fresh caching-allocator block per call: stream ordered, never
-    shared by two launches in flight); None when the layer has too few rows for the two-stage form to pay."""
-    if n_blocks < 128 or os.environ.get("UNETPP_NO_REDUCE_WS"):
-        return None
-    return torch.empty(_WS_ROWS * 2 * c, dtype=torch.float64, device=dev)
-
-
 def bn_finalize(partial, n_blocks, c, count, gamma, beta, eps, momentum, running_mean, running_var):
     dev = partial.device
     mean, invstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(4))
-    ws = _reduce_workspace(n_blocks, c, dev)
-    check(_lib.lib().unetpp_bn_finalize_ws(_ptr(partial), n_blocks, c, count, _ptr(gamma), _ptr(beta), eps, momentum,
-                                           _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(invstd), _ptr(scale),
-                                           _ptr(shift), _ptr(ws), _WS_ROWS, _stream()), "unetpp_bn_finalize_ws")
+    check(_lib.lib().unetpp_bn_finalize(_ptr(partial), n_blocks, c, count, _ptr(gamma), _ptr(beta), eps, momentum,
+                                        _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(invstd), _ptr(scale),
+                                        _ptr(shift), _stream()), "unetpp_bn_finalize")
     return mean, invstd, scale, shift
 
 
@@ -459,9 +447,7 @@ def _bn_backward_bf16(d_act, y, scale, shift, mean, invstd, gamma, dy_out, dgamm
     st = _stream()
     check(lib.unetpp_bn_bwd_reduce_bf16(_ptr(d_act), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _ptr(dp),
                                         _ptr(pi), n, h, w, c, _ptr(partial), st), "unetpp_bn_bwd_reduce_bf16")
-    ws = _reduce_workspace(blocks, c, y.device)
-    check(lib.unetpp_bn_bwd_finalize_ws(_ptr(partial), blocks, c, _ptr(dgamma), _ptr(dbeta), _ptr(ws), _WS_ROWS, st),
-          "unetpp_bn_bwd_finalize_ws")
+    check(lib.unetpp_bn_bwd_finalize(_ptr(partial), blocks, c, _ptr(dgamma), _ptr(dbeta), st), "unetpp_bn_bwd_finalize")
     check(lib.unetpp_bn_bwd_apply_bf16(_ptr(d_act), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), _ptr(gamma),
                                        _ptr(dgamma), _ptr(dbeta), _ptr(dp), _ptr(pi), n, h, w, c, _ptr(dy_out), st),
           "unetpp_bn_bwd_apply_bf16")
@@ -495,9 +481,7 @@ def bn_backward(d_act, y, scale, shift, mean, invstd, gamma, dy_out, dgamma=None
         check(lib.unetpp_bn_bwd_reduce_pool(_ptr(d_act), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd),
                                             _ptr(d_pooled), _ptr(pool_idx), n, h, w, c, _ptr(partial), st),
               "unetpp_bn_bwd_reduce_pool")
-    ws = _reduce_workspace(blocks, c, y.device)
-    check(lib.unetpp_bn_bwd_finalize_ws(_ptr(partial), blocks, c, _ptr(dgamma), _ptr(dbeta), _ptr(ws), _WS_ROWS, st),
-          "unetpp_bn_bwd_finalize_ws")
+    check(lib.unetpp_bn_bwd_finalize(_ptr(partial), blocks, c, _ptr(dgamma), _ptr(dbeta), st), "unetpp_bn_bwd_finalize")
     if pool is None:
         check(lib.unetpp_bn_bwd_apply(_ptr(d_act), _ptr(y), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd),
                                       _ptr(gamma), _ptr(dgamma), _ptr(dbeta), pixels, c, _ptr(dy_out), st),
