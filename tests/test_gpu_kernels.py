@@ -653,3 +653,25 @@ def test_wino_lean_and_general_kernels_agree(dev, shape, fold, monkeypatch):
     monkeypatch.delenv("UNETPP_WINO_NO_LEAN", raising=False)
     for a, c in zip(res[0], res[1]):
         assert torch.equal(a, c)
+
+
+def test_conv3x3_view_larger_than_2gb_takes_the_general_kernel(dev):
+    """The lean Winograd instantiations address a view through a buffer resource with 32-bit byte offsets (<= 2 GB);
+    a 2.7 GB input (below the 2^31-element limit of the fast path) must run through the general instantiation and give
+    the same numbers: checked on two crops (top-left border, last image) against the fp64 statement."""
+    from unet_nested4tiny_objects_keypoints_amd import engine, ops
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    b, h, w, ci, co = 5, 1024, 1024, 128, 8
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(b, h, w, ci, device=dev, generator=g)
+    assert x.numel() * 4 > 2 ** 31 and x.numel() < 2 ** 31
+    wt = (torch.randn(co, ci, 3, 3, generator=torch.Generator().manual_seed(4)) * 0.1)
+    out = torch.empty(b, h, w, co, device=dev)
+    ops.gemm_fwd(b, h, w, 9, [V(x)], [V(out)], engine.pack_conv_fwd(wt.cuda()), None)
+    for (n, y0, x0) in ((0, 0, 0), (b - 1, h - 40, w - 48)):
+        ys, xs = slice(max(y0 - 1, 0), min(y0 + 41, h)), slice(max(x0 - 1, 0), min(x0 + 49, w))
+        crop = x[n, ys, xs].permute(2, 0, 1).unsqueeze(0).double().cpu()
+        pad = (1 if x0 == 0 else 0, 1 if x0 + 48 == w else 0, 1 if y0 == 0 else 0, 1 if y0 + 40 == h else 0)
+        ref = F.conv2d(F.pad(crop, pad), wt.double())
+        got = out[n, y0:y0 + 40, x0:x0 + 48].permute(2, 0, 1).unsqueeze(0).cpu()
+        assert rel_err(got, ref.float()) < TOL
