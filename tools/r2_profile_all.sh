@@ -11,6 +11,7 @@ python bench.py --dtype f32 --size 512 --batch 8 --no-cpu-baseline > $O/bench_f3
 python bench.py --dtype bf16 --depth 5 --feature-scale 0.5 --in-channels 3 --n-classes 5 --size 384 --batch 4 --no-cpu-baseline > $O/bench_bf16_c5.log 2>&1
 python bench.py --dtype f32 --depth 5 --feature-scale 0.5 --in-channels 3 --n-classes 5 --size 384 --batch 4 --no-cpu-baseline > $O/bench_f32_c5.log 2>&1
 UNETPP_BENCH_SINGLE_DEVICE=1 UNETPP_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 3 --prewarm 3 --batch 8 > $O/bench_2rank_rehearsal.log 2>&1
+python tools/x00_probe.py > $O/x00_probe.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_f32_c2 -o p -- python3 $R/bench.py --steps 5 --warmup 2 --prewarm 3 --no-cpu-baseline --no-launch-timing > $O/prof_f32_c2.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bf16_c4 -o p -- python3 $R/bench.py --dtype bf16 --size 512 --batch 8 --steps 5 --warmup 2 --prewarm 3 --no-cpu-baseline --no-launch-timing > $O/prof_bf16_c4.log 2>&1
