@@ -633,7 +633,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       load_inputs();
     }
     WINO_STAMP(1);  // 1: staging store, cursor, load issue
-    // LEAN: the staging of the next chunk is a hundred instructions; they are spread over the first MFMA groups below,
+    // LEAN: the staging of the next chunk is a hundred instructions; they are spread over the first three MFMA groups below,
     // where they issue in the shadow of this wave's own MFMAs.  Order: the LDS stores of the inputs requested most of a
     // chunk ago, then the weight DMA (hipcc makes any LDS store that follows a DMA wait for vmcnt(0)), the cursor, and
     // the requests for the chunk after next, which must stay the YOUNGEST vector-memory operations: the barrier waits
@@ -648,14 +648,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       if constexpr (g == 0) store_chunk(other);
 #endif
 #ifndef UNETPP_WINO_EXP_NO_DMA
-      if constexpr (g == 1) dma_weights(other + IN_FLOATS, dma_source());
+      if constexpr (g == 0) dma_weights(other + IN_FLOATS, dma_source());
 #endif
-      if constexpr (g == 2) {
+      if constexpr (g == 1) {
         advance();
         load_coeffs();
       }
 #ifndef UNETPP_WINO_EXP_NO_LOADS
-      if constexpr (g == 3) load_inputs();
+      if constexpr (g == 2) load_inputs();
 #endif
 #endif
     };
