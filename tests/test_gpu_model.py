@@ -508,3 +508,32 @@ def test_resumed_checkpoint_runs_the_hip_path(dev, tmp_path, fmt):
     back = torch.load(saved, map_location="cpu")
     assert list(back.keys()) == list(state.keys())
     assert all(torch.equal(back[k], state[k]) for k in state)
+
+
+def test_graphed_eval_forward_matches_eager_and_tracks_parameters(dev):
+    """serving.GraphedForward: the eval forward replayed from a HIP graph equals the eager one bit for bit, for new
+    inputs and after the parameters change in place (the weight images are rebuilt inside the graph); wrong shapes and
+    training mode are refused."""
+    from unet_nested4tiny_objects_keypoints_amd import GraphedForward, UNet_Nested
+    torch.manual_seed(5)
+    m = UNet_Nested(in_channels=1, n_classes=4, feature_scale=4).to(dev).eval()
+    x0 = torch.randn(1, 1, 64, 64, device=dev)
+    g = GraphedForward(m, x0)
+    for seed in (1, 2):
+        x = torch.randn(1, 1, 64, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
+        with torch.no_grad():
+            ref = m(x)
+        got = g(x)
+        assert all(torch.equal(a, b) for a, b in zip(got, ref))
+    with torch.no_grad():
+        for p in m.parameters():
+            p.data.mul_(1.25)
+        ref = m(x0)
+    got = g(x0)
+    assert all(torch.equal(a, b) for a, b in zip(got, ref))
+    with pytest.raises(ValueError):
+        g(torch.randn(2, 1, 64, 64, device=dev))
+    m.train()
+    with pytest.raises(RuntimeError):
+        g(x0)
+    m.eval()
