@@ -390,6 +390,23 @@ __global__ __launch_bounds__(kThreads, UNETPP_BF16_WGS(TAPS, NT)) void gemm_bf16
         const int py = epi_py[mt], px = epi_px[mt];
         const bool pix_ok = (g.ty0 + py < d.H) && (g.tx0 + px < d.W);
         const unsigned pbase = tile_base + static_cast<unsigned>(py) * row_stride + static_cast<unsigned>(px) * col_stride;
+        // Read-modify-write launches (ReLU gate and / or accumulation: the input gradients): the gate and previous values
+        // of both 16-byte pieces of this pixel are requested here, in front of the packing arithmetic -- vmcnt counts
+        // in order, so a read issued between two stores waits for the store in front of it.  Only in the two-tile 3x3
+        // instantiation, which has the registers (256-register bound); the others spill with 16 more live registers.
+        constexpr bool kHoist = TAPS == 9 && NT == 2;
+        u32x4 gate_raw[2], old_raw[2];
+        if constexpr (kHoist) {
+          if (rmw) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              const int c0 = 16 * half + 8 * (1 - h);
+              const unsigned off = (pix_ok && c0 < tc.n_cnt) ? pbase + c0 : tile_base;  // dead pieces: any valid address
+              if (gptr != nullptr) gate_raw[half] = *reinterpret_cast<const u32x4*>(gptr + off);
+              if (O.accumulate) old_raw[half] = *reinterpret_cast<const u32x4*>(optr + off);
+            }
+          }
+        }
         unsigned pk[4][2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -423,14 +440,14 @@ __global__ __launch_bounds__(kThreads, UNETPP_BF16_WGS(TAPS, NT)) void gemm_bf16
               float v[8];
               unpack8(out, v);
               float gt[8];
-              if (gptr != nullptr) unpack8(*reinterpret_cast<const u32x4*>(gptr + off), gt);
+              if (gptr != nullptr) unpack8(kHoist ? gate_raw[half] : *reinterpret_cast<const u32x4*>(gptr + off), gt);
               if (gptr != nullptr && !O.gate_sum) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (gt[e] > 0.f) ? v[e] : 0.f;
               }
               if (O.accumulate) {
                 float old[8];
-                unpack8(*reinterpret_cast<const u32x4*>(optr + off), old);
+                unpack8(kHoist ? old_raw[half] : *reinterpret_cast<const u32x4*>(optr + off), old);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += old[e];
               }
