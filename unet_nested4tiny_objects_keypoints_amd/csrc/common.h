@@ -31,6 +31,13 @@ inline TileGeom tile_geom(int H, int W) {
   return g;
 }
 
+// slab groups of the weight-gradient finish kernels for n_split slabs: the smallest power of two >= n_split, at most 16
+inline int finish_log2_groups(int n_split) {
+  int l = 0;
+  while ((1 << l) < n_split && l < 4) ++l;
+  return l;
+}
+
 inline bool view_ok(const unetpp_view& v, bool need_ptr = true) {
   if (need_ptr && v.ptr == nullptr) return false;
   if (v.C <= 0 || v.c_len <= 0 || v.c_off < 0 || v.c_off + v.c_len > v.C) return false;

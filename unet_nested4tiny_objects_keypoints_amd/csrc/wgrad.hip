@@ -156,39 +156,40 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(const WgradArgs a) {
 
 __global__ void wgrad_finish_kernel(const float* __restrict__ slabs, int n_split, int taps, int K, int Ncols,
                                     int n_inner, float* __restrict__ dw, long d_t, long d_k, long d_n, long d_o,
-                                    float* __restrict__ db) {
-  // 1024 threads = 64 consecutive slab elements x 16 slab groups; the groups are combined through LDS in fixed order
-  // -> reproducible, and 16x the parallelism of a one-thread-per-element loop over up to 1024 slabs.
-  constexpr int SG = 16;  // slab groups: group g sums slabs g, g+16, ... -- 1024 threads, all loads independent
-  __shared__ float part[SG][64];
+                                    float* __restrict__ db, int log2_sg) {
+  // 1024 threads = EPB consecutive slab elements x SG slab groups (SG = 2^log2_sg <= 16, EPB = 1024 / SG): group g sums
+  // slabs g, g + SG, ...; the groups are combined through LDS in fixed order -> reproducible.  Few slabs (wide layers:
+  // many (channel tile, column tile) pairs, n_split = 2..8) take few groups and more elements per block instead of
+  // leaving 7/8 of the threads idle; the value of every sum is that of the 16-group form (empty groups add zeros).
+  const int SG = 1 << log2_sg, EPB = 1024 >> log2_sg;
+  __shared__ float part[1024];  // [SG][EPB]
   const long rows = static_cast<long>(taps) * K + 1;
   const long total = rows * Ncols;
-  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const long base_blocks = (total + 63) / 64;
+  const int e = threadIdx.x & (EPB - 1), g = threadIdx.x >> (10 - log2_sg);
+  const long base_blocks = (total + EPB - 1) / EPB;
   if (static_cast<long>(blockIdx.x) >= base_blocks) {
     // extra blocks, 2x2 deconvolution only (n_inner < Ncols): the bias gradient of an output channel is the sum of
-    // its (up to 4) pixel-phase columns -- 16 channels x 4 phases per block, fixed order
+    // its (up to 4) pixel-phase columns -- 16 channels x 4 phases per block (64 threads per slab group), fixed order
     const int n_outer = Ncols / n_inner;
     const int o = e >> 4;
     const long nn = (blockIdx.x - base_blocks) * 16L + (e & 15);
     float u = 0.f;
-    if (o < n_outer && nn < n_inner)
+    if (e < 64 && o < n_outer && nn < n_inner)
       for (int b = g; b < n_split; b += SG) u += slabs[static_cast<long>(b) * total + (rows - 1) * Ncols + o * n_inner + nn];
-    part[g][e] = u;
+    part[g * EPB + e] = u;
     __syncthreads();
     if (g == 0 && e < 16 && nn < n_inner && db != nullptr) {
       float t = 0.f;
       for (int oo = 0; oo < n_outer; ++oo) {
         float v = 0.f;
-#pragma unroll
-        for (int q = 0; q < SG; ++q) v += part[q][oo * 16 + e];
+        for (int q = 0; q < SG; ++q) v += part[q * EPB + oo * 16 + e];
         t += v;
       }
       db[nn] = t;
     }
     return;
   }
-  const long i = blockIdx.x * 64L + e;
+  const long i = blockIdx.x * static_cast<long>(EPB) + e;
   float s = 0.f;
   if (i < total) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -202,12 +203,11 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ slabs, int n_split
     for (; b < n_split; b += SG) s0 += slabs[static_cast<long>(b) * total + i];
     s = (s0 + s1) + (s2 + s3);
   }
-  part[g][e] = s;
+  part[g * EPB + e] = s;
   __syncthreads();
   if (g != 0 || i >= total) return;
   s = 0.f;
-#pragma unroll
-  for (int q = 0; q < SG; ++q) s += part[q][e];  // fixed order
+  for (int q = 0; q < SG; ++q) s += part[q * EPB + e];  // fixed order
   const long row = i / Ncols;
   const int nn = static_cast<int>(i - row * Ncols);
   if (row == rows - 1) {  // bias gradient of a plain convolution: the sum just formed (deconvolution: extra blocks)
@@ -315,9 +315,11 @@ extern "C" int unetpp_wgrad_finish(const float* slabs, int32_t n_split, int32_t 
   }
   const long total = (static_cast<long>(taps) * K + 1) * Ncols;
   if (Ncols / n_inner > 4) return UNETPP_EINVAL;  // at most 4 pixel phases per output channel
-  const unsigned blocks = static_cast<unsigned>((total + 63) / 64 + (n_inner != Ncols ? (n_inner + 15) / 16 : 0));
+  const int log2_sg = finish_log2_groups(n_split);
+  const long epb = 1024 >> log2_sg;
+  const unsigned blocks = static_cast<unsigned>((total + epb - 1) / epb + (n_inner != Ncols ? (n_inner + 15) / 16 : 0));
   hipLaunchKernelGGL(wgrad_finish_kernel, dim3(blocks), dim3(1024), 0, static_cast<hipStream_t>(stream), slabs,
-                     n_split, taps, K, Ncols, n_inner, dw, d_t, d_k, d_n, d_o, db);
+                     n_split, taps, K, Ncols, n_inner, dw, d_t, d_k, d_n, d_o, db, log2_sg);
   return launch_status();
 }
 

@@ -421,36 +421,36 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
   }
 }
 
-// slab sum + G^T . G: 1024 threads = 16 slab groups x (4 (k, n) pairs x 16 planes = 64 consecutive slab floats); the
-// bias row is summed by extra blocks
+// slab sum + G^T . G: 1024 threads = SG slab groups x EPB consecutive slab floats (EPB / 16 (k, n) pairs x 16 planes);
+// SG = 2^log2_sg <= 16 by the number of slabs (see wgrad_finish_kernel); the bias row is summed by extra blocks
 __global__ void wgrad_finish_wino_kernel(const float* __restrict__ slabs, int n_split, int K, int Ncols,
-                                         float* __restrict__ dw, long d_t, long d_k, long d_n, float* __restrict__ db) {
-  constexpr int SG = 16;  // slab groups: group g sums slabs g, g+16, ... -- 1024 threads, all loads independent
-  __shared__ float part[SG][64];
+                                         float* __restrict__ dw, long d_t, long d_k, long d_n, float* __restrict__ db,
+                                         int log2_sg) {
+  const int SG = 1 << log2_sg, EPB = 1024 >> log2_sg;  // group g sums slabs g, g + SG, ... -- all loads independent
+  __shared__ float part[1024];                          // [SG][EPB]
   const long pairs = static_cast<long>(K) * Ncols;
   const long total = (16L * K + 1) * Ncols;
-  const long pair_blocks = (pairs + 3) / 4;
-  const int e = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const int ppb = EPB >> 4;  // (k, n) pairs per block
+  const long pair_blocks = (pairs + ppb - 1) / ppb;
+  const int e = threadIdx.x & (EPB - 1), sg = threadIdx.x >> (10 - log2_sg);
   if (static_cast<long>(blockIdx.x) >= pair_blocks) {  // bias row: 64 columns per block
     const long n = (blockIdx.x - pair_blocks) * 64L + e;
     float s = 0.f;
-    if (n < Ncols)
+    if (e < 64 && n < Ncols)
       for (int b = sg; b < n_split; b += SG) s += slabs[static_cast<long>(b) * total + 16L * pairs + n];
-    part[sg][e] = s;
+    part[sg * EPB + e] = s;
     __syncthreads();
-    if (sg == 0 && n < Ncols && db != nullptr) {
+    if (sg == 0 && e < 64 && n < Ncols && db != nullptr) {
       float t = 0.f;
-#pragma unroll
-      for (int q = 0; q < SG; ++q) t += part[q][e];
+      for (int q = 0; q < SG; ++q) t += part[q * EPB + e];
       db[n] = t;
     }
     return;
   }
-  const int xi = e & 15;
-  const long pair = blockIdx.x * 4L + (e >> 4);
+  const long pair = blockIdx.x * static_cast<long>(ppb) + (e >> 4);
   float s = 0.f;
   if (pair < pairs) {
-    const long i = pair * 16 + xi;  // 64 consecutive floats per block
+    const long i = pair * 16 + (e & 15);  // EPB consecutive floats per block
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int b = sg;
     for (; b + 3 * SG < n_split; b += 4 * SG) {
@@ -462,18 +462,17 @@ __global__ void wgrad_finish_wino_kernel(const float* __restrict__ slabs, int n_
     for (; b < n_split; b += SG) s0 += slabs[static_cast<long>(b) * total + i];
     s = (s0 + s1) + (s2 + s3);
   }
-  part[sg][e] = s;
+  part[sg * EPB + e] = s;
   __syncthreads();
-  if (threadIdx.x < 64) {
+  if (sg == 0) {
     float t = 0.f;
-#pragma unroll
-    for (int q = 0; q < SG; ++q) t += part[q][e];  // fixed order
-    part[0][e] = t;
+    for (int q = 0; q < SG; ++q) t += part[q * EPB + e];  // fixed order
+    part[e] = t;
   }
   __syncthreads();
-  if (threadIdx.x >= 36 || dw == nullptr) return;
-  const int pl = threadIdx.x & 3, tap = threadIdx.x >> 2;  // 9 taps x 4 pairs
-  const long p = blockIdx.x * 4L + pl;
+  if (static_cast<int>(threadIdx.x) >= 9 * ppb || dw == nullptr) return;
+  const int pl = threadIdx.x % ppb, tap = threadIdx.x / ppb;  // 9 taps x ppb pairs
+  const long p = blockIdx.x * static_cast<long>(ppb) + pl;
   if (p >= pairs) return;
   const int r = tap / 3, c = tap - 3 * r;
   // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; column r of G, with the sign of the kernel's unsigned last row
@@ -484,7 +483,7 @@ __global__ void wgrad_finish_wino_kernel(const float* __restrict__ slabs, int n_
   for (int aa = 0; aa < 4; ++aa) {
     float rowsum = 0.f;
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb) rowsum = fmaf(gc[bb], part[0][pl * 16 + aa * 4 + bb], rowsum);
+    for (int bb = 0; bb < 4; ++bb) rowsum = fmaf(gc[bb], part[pl * 16 + aa * 4 + bb], rowsum);
     out = fmaf(gr[aa], rowsum, out);
   }
   const long k = p / Ncols, n = p - k * Ncols;
@@ -560,9 +559,11 @@ int launch_wgrad_wino(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_til
 int launch_wgrad_finish_wino(const float* slabs, int n_split, int K, int Ncols, float* dw, long d_t, long d_k, long d_n,
                              float* db, hipStream_t st) {
   const long pairs = static_cast<long>(K) * Ncols;
-  const unsigned blocks = static_cast<unsigned>((pairs + 3) / 4 + (Ncols + 63) / 64);
+  const int log2_sg = finish_log2_groups(n_split);
+  const long ppb = (1024 >> log2_sg) >> 4;  // (k, n) pairs per block
+  const unsigned blocks = static_cast<unsigned>((pairs + ppb - 1) / ppb + (Ncols + 63) / 64);
   hipLaunchKernelGGL(wgrad_finish_wino_kernel, dim3(blocks), dim3(1024), 0, st, slabs, n_split, K, Ncols, dw, d_t, d_k,
-                     d_n, db);
+                     d_n, db, log2_sg);
   return launch_status();
 }
 
