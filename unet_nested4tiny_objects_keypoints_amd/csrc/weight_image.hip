@@ -131,6 +131,60 @@ __device__ __forceinline__ void fill_image_row(const PackGeom& g, const unetpp_w
   }
 }
 
+// bf16 3x3 images, nine rows at a time: the 32 x 32 x 9 source block of a (tile, chunk) goes through LDS, read in the
+// order it lies in memory (the taps of a (channel, column) pair are adjacent, then whichever of channel / column has
+// the smaller stride) -- fill_image_row reads it as 4-byte pieces 36 bytes apart, nine times over (once per tap) --
+// and leaves as 16-byte stores.
+__device__ __forceinline__ void fill_bf16_3x3_block(const PackGeom& g, const unetpp_weight_src& w, long rc,
+                                                     float* __restrict__ img, float* lds /* [9][32][33] */) {
+  const int tid = threadIdx.x;
+  const RowOrigin o = row_origin(g, static_cast<int>(rc / g.n_chunks), static_cast<int>(rc % g.n_chunks));
+  const bool k_inner_most = w.s_k < w.s_n;  // forward layout [co][ci][3][3]: channel k = ci runs faster than column n = co
+  __syncthreads();  // the previous block's readers are done
+  // 16-byte reads where the nine taps of 32 consecutive inner indices form one aligned 1152-byte run (plain conv
+  // parameters: tap stride 1, inner stride 9, 16-byte aligned block origin), 4-byte reads otherwise
+  const long inner_stride = k_inner_most ? w.s_k : w.s_n, outer_stride = k_inner_most ? w.s_n : w.s_k;
+  const int inner_room = k_inner_most ? o.k_room : o.n_room, outer_room = k_inner_most ? o.n_room : o.k_room;
+  const long origin = static_cast<long>(o.k0) * w.s_k + static_cast<long>(o.n0) * w.s_n;
+  const bool wide = w.s_t == 1 && inner_stride == 9 && w.k_inner <= 0 && w.n_inner <= 0 && inner_room >= 32 &&
+                    ((reinterpret_cast<uintptr_t>(w.src + origin) | static_cast<uintptr_t>(outer_stride * 4)) & 15) == 0;
+  if (wide) {
+#pragma unroll 3
+    for (int q = tid; q < 32 * 72; q += 256) {  // 72 float4 per outer index
+      const int oo = q / 72, r4 = q - oo * 72;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (oo < outer_room) v = *reinterpret_cast<const f32x4*>(w.src + origin + oo * outer_stride + 4 * r4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int f = 4 * r4 + c, m = f / 9;
+        const int tap_m = f - 9 * m, tap = w.flip ? 8 - tap_m : tap_m;
+        const int kk = k_inner_most ? m : oo, cl = k_inner_most ? oo : m;
+        lds[(tap * 32 + kk) * 33 + cl] = v[c];
+      }
+    }
+  } else {
+#pragma unroll 6
+    for (int idx = tid; idx < 9 * 32 * 32; idx += 256) {
+      const int tap = idx % 9, m = (idx / 9) & 31, oo = idx / (9 * 32);
+      const int kk = k_inner_most ? m : oo, cl = k_inner_most ? oo : m;
+      lds[(tap * 32 + kk) * 33 + cl] = (kk < o.k_room && cl < o.n_room) ? wsrc_at(w, 9, tap, o.k0 + kk, o.n0 + cl) : 0.f;
+    }
+  }
+  __syncthreads();
+  // one 16-byte store per thread and round: four slots = the eight channels 16 gq + 8 hs .. + 7 of one column
+  f32x4* dst4 = reinterpret_cast<f32x4*>(img + rc * 9 * 512);
+#pragma unroll 3
+  for (int s4 = tid; s4 < 9 * 128; s4 += 256) {
+    const int tap = s4 >> 7, e4 = s4 & 127;  // slots 4 e4 .. 4 e4 + 3 of the tap's row
+    const int cl = (e4 >> 1) & 31, kk0 = 16 * ((e4 >> 6) & 1) + 8 * (e4 & 1);
+    f32x4 out;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      out[c] = __uint_as_float(pack_bf2(lds[(tap * 32 + kk0 + 2 * c) * 33 + cl], lds[(tap * 32 + kk0 + 2 * c + 1) * 33 + cl]));
+    dst4[s4] = out;
+  }
+}
+
 // value of image element i
 __device__ __forceinline__ float image_element(const PackGeom& g, const unetpp_weight_src& w, long i) {
   int kk, cin_local, tap = 0, xi = 0;
@@ -219,6 +273,12 @@ __global__ void pack_image_jobs_kernel(const unetpp_pack_job* __restrict__ jobs)
     finish_geom(g);
   }
   __syncthreads();
+  if (g.kind == kKindBf16 && g.taps == 9) {
+    __shared__ float stage[9 * 32 * 33];
+    const long blocks = g.floats / (9 * 512);
+    for (long rc = blockIdx.x; rc < blocks; rc += gridDim.x) fill_bf16_3x3_block(g, j.src, rc, j.image, stage);
+    return;
+  }
   const long rows = g.floats / (g.kind == kKindWino ? 4096 : 512);
   for (long row = blockIdx.x; row < rows; row += gridDim.x) fill_image_row(g, j.src, row, j.image);
 }
