@@ -31,6 +31,20 @@ inline TileGeom tile_geom(int H, int W) {
   return g;
 }
 
+// Value of lane (lane ^ OFF), OFF a compile-time power of two below 32, without the LDS crossbar address path of
+// __shfl_xor (v_mbcnt + shift + ds_bpermute_b32 + wait): OFF 1 and 2 are DPP quad permutations (a VALU move), 4..16 a
+// ds_swizzle in bit mode (no address register).
+template <int OFF>
+__device__ __forceinline__ float xor_lane(float v) {
+  static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8 || OFF == 16, "xor_lane: 1, 2, 4, 8 or 16");
+  const int i = __builtin_bit_cast(int, v);
+  int r;
+  if constexpr (OFF == 1) r = __builtin_amdgcn_mov_dpp(i, 0xB1, 0xF, 0xF, true);        // quad_perm [1, 0, 3, 2]
+  else if constexpr (OFF == 2) r = __builtin_amdgcn_mov_dpp(i, 0x4E, 0xF, 0xF, true);   // quad_perm [2, 3, 0, 1]
+  else r = __builtin_amdgcn_ds_swizzle(i, 0x1F | (OFF << 10));                            // bit mode: and 0x1F, xor OFF
+  return __builtin_bit_cast(float, r);
+}
+
 // slab groups of the weight-gradient finish kernels for n_split slabs: the smallest power of two >= n_split, at most 16
 inline int finish_log2_groups(int n_split) {
   int l = 0;

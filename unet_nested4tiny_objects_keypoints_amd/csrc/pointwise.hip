@@ -3,6 +3,7 @@
 // and the NCHW<->NHWC converters used at the network edge.  All NHWC fp32; 16-byte vector
 // accesses whenever the channel count is a multiple of 4, scalar fallback otherwise.
 #include "common.h"
+#include "lds_asm.h"
 #include "dropout.h"
 
 namespace unetpp {
@@ -577,40 +578,49 @@ __global__ __launch_bounds__(64) void head_fwd_tiled_kernel(const float* __restr
 // coalesced 16-byte load per item, the class weights of the quad in registers.  The P per-class partial dot products
 // of a lane are summed over the C/4 lanes of the pixel by a reduce-scatter (each exchange step halves the classes a
 // lane still carries: P-1 + log2(G/P) shuffles instead of P log2 G), fixed order.  No LDS tile, no transposition.
-template <int LOG2G, int P>  // P = classes padded to a power of two (4 or 8), P <= G
+// DROP: 0 = no dropout, 1 = keep flags from the counter hash, 2 = keep flags from a mask tensor -- three instantiations so
+// that the loop body is straight-line code (as one kernel it carried ~16 uniform branches per item).  32-bit element
+// offsets (the launcher takes this path for tensors below 2^31 elements); C = 4 G, so pixel -> element offset and
+// pixel -> hash counter are shifts; the (image, position) pair of the NCHW output is carried along instead of divided
+// out per item.
+template <int LOG2G, int P, int DROP>  // P = classes padded to a power of two (4 or 8), P <= G
 __global__ __launch_bounds__(kThreads) void head_fwd_stream_kernel(const float* __restrict__ x, const float* __restrict__ weight,
-                                                                   const float* __restrict__ bias, long pixels, int HW, int C,
+                                                                   const float* __restrict__ bias, unsigned pixels, unsigned HW,
                                                                    int n_cls, float keep_scale, uint32_t thr16, uint64_t seed,
-                                                                   const uint8_t* __restrict__ mask, int use_drop,
-                                                                   float* __restrict__ out) {
+                                                                   const uint8_t* __restrict__ mask, float* __restrict__ out) {
   constexpr int G = 1 << LOG2G;  // lanes (channel quads) per pixel
   const int gq = threadIdx.x & (G - 1);
   f32x4 wq[P];
 #pragma unroll
   for (int k = 0; k < P; ++k)
-    wq[k] = (k < n_cls) ? *reinterpret_cast<const f32x4*>(weight + k * C + 4 * gq) : f32x4{0.f, 0.f, 0.f, 0.f};
-  const long ppb = kThreads >> LOG2G;  // pixels per block and slot
-  constexpr int U = 4;                 // pixels per thread and iteration: 4 loads in flight
-  const long span = static_cast<long>(gridDim.x) * ppb;
-  const long p_first = blockIdx.x * ppb + (threadIdx.x >> LOG2G);
-  for (long p0 = p_first; p0 - (threadIdx.x >> LOG2G) < pixels; p0 += U * span) {  // wave-uniform trip count
+    wq[k] = (k < n_cls) ? *reinterpret_cast<const f32x4*>(weight + k * 4 * G + 4 * gq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr unsigned ppb = kThreads >> LOG2G;  // pixels per block and slot
+  constexpr int U = 4;                         // pixels per thread and iteration: 4 loads in flight
+  const unsigned span = gridDim.x * ppb, outer = U * span;
+  const unsigned pl = threadIdx.x >> LOG2G;
+  // (image, position) of this thread's first pixel and the step of one `span`, kept up to date by adds
+  const unsigned span_n = span / HW, span_hw = span - span_n * HW;
+  unsigned p0 = blockIdx.x * ppb + pl;
+  unsigned n0 = p0 / HW, hw0 = p0 - n0 * HW;
+  for (; p0 - pl < pixels; p0 += outer) {  // wave-uniform trip count
     f32x4 v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long p = p0 + u * span;
-      v[u] = (p < pixels) ? *reinterpret_cast<const f32x4*>(x + p * C + 4 * gq) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const unsigned p = p0 + u * span;
+      v[u] = (p < pixels) ? *reinterpret_cast<const f32x4*>(x + ((p << (LOG2G + 2)) + 4 * gq)) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long p = p0 + u * span;
+      const unsigned p = p0 + u * span;
       const bool valid = p < pixels;
-      if (use_drop && valid) {
-        const uint64_t bits = (mask == nullptr) ? keep_bits(seed, p, G, gq) : 0;
+      if constexpr (DROP == 1) {
+        const uint64_t bits = keep_bits(seed, p, G, gq);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const bool keep = (mask != nullptr) ? (mask[p * C + 4 * gq + q] != 0) : keep_one(bits, q, thr16);
-          v[u][q] = keep ? v[u][q] * keep_scale : 0.f;
-        }
+        for (int q = 0; q < 4; ++q) v[u][q] = keep_one(bits, q, thr16) ? v[u][q] * keep_scale : 0.f;
+      } else if constexpr (DROP == 2) {
+        const uint32_t m4 = valid ? *reinterpret_cast<const uint32_t*>(mask + ((p << (LOG2G + 2)) + 4 * gq)) : 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[u][q] = ((m4 >> (8 * q)) & 0xffu) != 0 ? v[u][q] * keep_scale : 0.f;
       }
       float acc[P];
 #pragma unroll
@@ -619,29 +629,43 @@ __global__ __launch_bounds__(kThreads) void head_fwd_stream_kernel(const float* 
       // reduce-scatter over the G lanes of the pixel: with `live` classes left, a lane keeps the half selected by its
       // bit `off` and adds the partner's partials of that half; once one class is left, a plain butterfly sum
       int cls = 0;  // class this lane ends up with
-#pragma unroll
-      for (int off = G >> 1, live = P; off >= 1; off >>= 1) {
-        if (live > 1) {
-          const int half = live >> 1;
+      static_for<LOG2G>([&](auto sc) {
+        constexpr int step = decltype(sc)::v, off = G >> (1 + step);
+        constexpr int live = (P >> step) > 1 ? (P >> step) : 1;  // classes a lane still carries before this step
+        if constexpr (live > 1) {
+          constexpr int half = live >> 1;
           const bool upper = (gq & off) != 0;
 #pragma unroll
           for (int i = 0; i < half; ++i) {
             const float send = upper ? acc[i] : acc[half + i];
             const float keep = upper ? acc[half + i] : acc[i];
-            acc[i] = keep + __shfl_xor(send, off);
+            acc[i] = keep + xor_lane<off>(send);
           }
           cls += upper ? half : 0;
-          live = half;
         } else {
-          acc[0] += __shfl_xor(acc[0], off);
+          acc[0] += xor_lane<off>(acc[0]);
         }
+      });
+      // this item's (image, position): u steps of `span` from the thread's first pixel of the iteration
+      unsigned n = n0 + u * span_n, hw = hw0 + u * span_hw;
+#pragma unroll
+      for (int c = 0; c < U - 1; ++c) {  // at most u carries
+        const bool carry = c < u && hw >= HW;
+        hw -= carry ? HW : 0u;
+        n += carry ? 1u : 0u;
       }
       constexpr int kDup = (G > P) ? G / P : 1;  // lanes that end with the same class total
-      if (valid && cls < n_cls && (gq & (kDup - 1)) == 0) {
-        const unsigned pu = static_cast<unsigned>(p);  // pixels < 2^31 (launcher): 32-bit division
-        const unsigned n = pu / static_cast<unsigned>(HW), hw = pu - n * static_cast<unsigned>(HW);
+      if (valid && cls < n_cls && (gq & (kDup - 1)) == 0)
         out[(static_cast<long>(n) * n_cls + cls) * HW + hw] = 1.0f / (1.0f + __expf(-(acc[0] + bias[cls])));
-      }
+    }
+    // advance the carried position by U spans
+    n0 += U * span_n;
+    hw0 += U * span_hw;
+#pragma unroll
+    for (int c = 0; c < U; ++c) {
+      const bool carry = hw0 >= HW;
+      hw0 -= carry ? HW : 0u;
+      n0 += carry ? 1u : 0u;
     }
   }
 }
@@ -1237,13 +1261,21 @@ extern "C" int unetpp_head_fwd(const float* x, const float* weight, const float*
   const int use_drop = p_drop > 0.f;
   const int g4 = C >> 2;
   const int pcls = n_cls <= 4 ? 4 : 8;
-  if ((C & 3) == 0 && aligned16(x) && aligned16(weight) && (g4 & (g4 - 1)) == 0 && g4 <= 32 && pcls <= g4 && pixels < 0x7fffffffL) {
+  if ((C & 3) == 0 && aligned16(x) && aligned16(weight) && (g4 & (g4 - 1)) == 0 && g4 <= 32 && pcls <= g4 && pixels * C < 0x7fffffffL &&
+      (mask == nullptr || (reinterpret_cast<uintptr_t>(mask) & 3) == 0)) {
     const long ppb = kThreads / g4;
     const long want = (pixels + ppb - 1) / ppb;
     const dim3 grid(static_cast<unsigned>(want < 256 * 16 ? want : 256 * 16));
-#define UNETPP_HEAD_STREAM(L, PC)                                                                                    \
-  hipLaunchKernelGGL((head_fwd_stream_kernel<L, PC>), grid, dim3(kThreads), 0, ST(stream), x, weight, bias, pixels,    \
-                     H * W, C, n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, use_drop, out_nchw)
+#define UNETPP_HEAD_STREAM_D(L, PC, D)                                                                              \
+  hipLaunchKernelGGL((head_fwd_stream_kernel<L, PC, D>), grid, dim3(kThreads), 0, ST(stream), x, weight, bias,         \
+                     static_cast<unsigned>(pixels), static_cast<unsigned>(H * W), n_cls, 1.0f / (1.0f - p_drop),        \
+                     keep_threshold(p_drop), seed, mask, out_nchw)
+#define UNETPP_HEAD_STREAM(L, PC)                              \
+  do {                                                         \
+    if (!use_drop) UNETPP_HEAD_STREAM_D(L, PC, 0);             \
+    else if (mask == nullptr) UNETPP_HEAD_STREAM_D(L, PC, 1);  \
+    else UNETPP_HEAD_STREAM_D(L, PC, 2);                       \
+  } while (0)
     if (pcls == 4) {
       switch (g4) {
         case 4: UNETPP_HEAD_STREAM(2, 4); break;
@@ -1259,6 +1291,7 @@ extern "C" int unetpp_head_fwd(const float* x, const float* weight, const float*
       }
     }
 #undef UNETPP_HEAD_STREAM
+#undef UNETPP_HEAD_STREAM_D
     return launch_status();
   }
   if ((C & 3) == 0 && aligned16(x)) {
