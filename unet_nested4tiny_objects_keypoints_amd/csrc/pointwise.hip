@@ -880,6 +880,134 @@ __global__ __launch_bounds__(kThreads, 4) void head_bwd_vec_kernel(const float* 
   if (tid < n_cls) dst[NW + tid] = bacc;
 }
 
+// The same for C = 4 * 2^LOG2G channels and tensors below 2^31 elements (every configuration of the reference): the
+// index arithmetic is shifts and 32-bit, a thread's channel quad is the same for all its pieces so its class weights
+// live in registers (the general kernel re-reads them from LDS per piece: 16 + 4 LDS reads per 16 bytes of x), the
+// (class, channel) pairs of the weight-gradient pass are decoded once instead of once per tile, and the dropout mode is
+// a template parameter (0 none, 1 counter hash, 2 mask tensor) so that the piece loop is straight-line code.
+template <int LOG2G, int DROP>
+__global__ __launch_bounds__(kThreads, 4) void head_bwd_pow2_kernel(const float* __restrict__ d_out,
+                                                                 const float* __restrict__ outp,
+                                                                 const float* __restrict__ x,
+                                                                 const float* __restrict__ weight, unsigned pixels,
+                                                                 unsigned HW, int n_cls, float keep_scale, uint32_t thr16,
+                                                                 uint64_t seed, const uint8_t* __restrict__ mask,
+                                                                 float* __restrict__ dx, int accumulate, int gate_x,
+                                                                 float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float hsm[];
+  constexpr int G = 1 << LOG2G, C = 4 * G, XS = C + 1;
+  constexpr int ITEMS = (64 * G + kThreads - 1) / kThreads;  // 16-byte pieces of a 64-pixel tile per thread
+  const int NW = n_cls * C;
+  float* xs = hsm;
+  float* dl = xs + 64 * XS;
+  float* scratch = dl + 64 * kHeadMaxCls;
+  const int tid = threadIdx.x;
+  const int gq = tid & (G - 1);  // channel quad of every piece of this thread (kThreads is a multiple of G)
+  f32x4 wq[kHeadMaxCls];
+#pragma unroll
+  for (int k = 0; k < kHeadMaxCls; ++k)
+    wq[k] = (k < n_cls) ? *reinterpret_cast<const f32x4*>(weight + k * C + 4 * gq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int kMaxPairs = (kHeadMaxCls * C + 127) / 128;  // (k, c) pairs per thread
+  float wacc[kMaxPairs];
+  int pair_k[kMaxPairs], pair_c[kMaxPairs];
+  const int pair0 = tid & 127, half = tid >> 7;
+#pragma unroll
+  for (int q = 0; q < kMaxPairs; ++q) {
+    wacc[q] = 0.f;
+    const int idx = pair0 + q * 128;
+    pair_k[q] = idx >> (LOG2G + 2);
+    pair_c[q] = idx & (C - 1);
+  }
+  float bacc = 0.f;
+  const unsigned n_tiles = (pixels + 63) / 64;
+  for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const unsigned p0 = tile * 64;
+    __syncthreads();
+    for (int it = tid; it < 64 * n_cls; it += kThreads) {
+      const int pl = it & 63, k = it >> 6;
+      const unsigned p = p0 + pl;
+      float v = 0.f;
+      if (p < pixels) {
+        const unsigned n = p / HW, hw = p - n * HW;
+        const long o = (static_cast<long>(n) * n_cls + k) * HW + hw;
+        const float pr = outp[o];
+        v = d_out[o] * pr * (1.f - pr);
+      }
+      dl[pl * kHeadMaxCls + k] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < ITEMS; ++u) {
+      const int it = tid + u * kThreads;
+      if (ITEMS * kThreads != 64 * G && it >= 64 * G) break;
+      const int pl = it >> LOG2G;
+      const unsigned p = p0 + pl;
+      f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+      float ms[4] = {1.f, 1.f, 1.f, 1.f};
+      if (p < pixels) {
+        const unsigned off = (p << (LOG2G + 2)) + 4 * gq;
+        xv = *reinterpret_cast<const f32x4*>(x + off);
+        if constexpr (DROP == 1) {
+          const uint64_t bits = keep_bits(seed, p, G, gq);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ms[q] = keep_one(bits, q, thr16) ? keep_scale : 0.f;
+        } else if constexpr (DROP == 2) {
+          const uint32_t m4 = *reinterpret_cast<const uint32_t*>(mask + off);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ms[q] = ((m4 >> (8 * q)) & 0xffu) != 0 ? keep_scale : 0.f;
+        }
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < kHeadMaxCls; ++k) {
+          if (k < n_cls) {
+            const float dk = dl[pl * kHeadMaxCls + k];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sacc[q] += wq[k][q] * dk;
+          }
+        }
+        f32x4 old = {0.f, 0.f, 0.f, 0.f};
+        if (accumulate) old = *reinterpret_cast<const f32x4*>(dx + off);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = sacc[q] * ms[q] + old[q];
+          if (gate_x) v = (xv[q] > 0.f) ? v : 0.f;
+          sacc[q] = v;
+        }
+        *reinterpret_cast<f32x4*>(dx + off) = sacc;
+      }
+      float* xd = &xs[pl * XS + 4 * gq];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xd[q] = xv[q] * ms[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kMaxPairs; ++q) {
+      if (pair0 + q * 128 < NW) {
+        const int k = pair_k[q], c = pair_c[q];
+        float sum = 0.f;
+#pragma unroll 4
+        for (int pl = 32 * half; pl < 32 * half + 32; ++pl) sum += dl[pl * kHeadMaxCls + k] * xs[pl * XS + c];
+        wacc[q] += sum;
+      }
+    }
+    if (tid < n_cls) {
+      float sum = 0.f;
+      for (int pl = 0; pl < 64; ++pl) sum += dl[pl * kHeadMaxCls + tid];
+      bacc += sum;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kMaxPairs; ++q) {
+    const int idx = pair0 + q * 128;
+    if (idx < NW) scratch[half * NW + idx] = wacc[q];
+  }
+  __syncthreads();
+  float* dst = partial + static_cast<long>(blockIdx.x) * (NW + n_cls);
+  for (int i = tid; i < NW; i += kThreads) dst[i] = scratch[i] + scratch[NW + i];
+  if (tid < n_cls) dst[NW + tid] = bacc;
+}
+
 __global__ void sum_partials_kernel(const float* __restrict__ partial, long n_blocks, long len, float* __restrict__ out) {
   // 16 outputs x 64 row groups per workgroup (1024 threads): a thread adds n_blocks / 64 rows (4 loads in flight);
   // the groups are combined through LDS in fixed order.  fp64 sums: thousands of same-sign partials.
@@ -1321,6 +1449,33 @@ extern "C" int unetpp_head_bwd(const float* d_out_nchw, const float* out_nchw, c
     return UNETPP_EINVAL;
   const long pixels = static_cast<long>(N) * H * W;
   const int use_drop = p_drop > 0.f;
+  const int g4 = C >> 2;
+  if ((C & 3) == 0 && aligned16(x) && aligned16(dx) && aligned16(weight) && (g4 & (g4 - 1)) == 0 && g4 >= 2 && g4 <= 32 &&
+      pixels * C < 0x7fffffffL && (mask == nullptr || (reinterpret_cast<uintptr_t>(mask) & 3) == 0)) {
+    const size_t lds = (64 * (C + 1) + 64 * kHeadMaxCls + 2 * n_cls * C) * sizeof(float);
+    const dim3 grid(static_cast<unsigned>(unetpp_head_bwd_blocks(pixels)));
+    const int drop = !use_drop ? 0 : (mask == nullptr ? 1 : 2);
+#define UNETPP_HEAD_BWD(L, D)                                                                                       \
+  hipLaunchKernelGGL((head_bwd_pow2_kernel<L, D>), grid, dim3(kThreads), lds, ST(stream), d_out_nchw, out_nchw, x,   \
+                     weight, static_cast<unsigned>(pixels), static_cast<unsigned>(H * W), n_cls, 1.0f / (1.0f - p_drop), \
+                     keep_threshold(p_drop), seed, mask, dx, accumulate, gate_x, partial)
+#define UNETPP_HEAD_BWD_L(L)              \
+  do {                                    \
+    if (drop == 0) UNETPP_HEAD_BWD(L, 0); \
+    else if (drop == 1) UNETPP_HEAD_BWD(L, 1); \
+    else UNETPP_HEAD_BWD(L, 2);           \
+  } while (0)
+    switch (g4) {
+      case 2: UNETPP_HEAD_BWD_L(1); break;
+      case 4: UNETPP_HEAD_BWD_L(2); break;
+      case 8: UNETPP_HEAD_BWD_L(3); break;
+      case 16: UNETPP_HEAD_BWD_L(4); break;
+      default: UNETPP_HEAD_BWD_L(5); break;
+    }
+#undef UNETPP_HEAD_BWD_L
+#undef UNETPP_HEAD_BWD
+    return launch_status();
+  }
   if ((C & 3) == 0 && aligned16(x) && aligned16(dx)) {
     const size_t lds = (64 * (C + 1) + 64 * kHeadMaxCls + kHeadMaxCls * C + 2 * n_cls * C) * sizeof(float);
     hipLaunchKernelGGL(head_bwd_vec_kernel, dim3(static_cast<unsigned>(unetpp_head_bwd_blocks(pixels))), dim3(kThreads),

@@ -10,6 +10,7 @@
 //                                  fp32 NCHW probabilities out (the loss stays fp32), bf16 feature gradient back
 #include "bf16_common.h"
 #include "common.h"
+#include "lds_asm.h"
 #include "dropout.h"
 
 namespace unetpp {
@@ -191,36 +192,44 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_bf16_kernel(const bf16_
   }
 }
 
-// ---- heads.  Forward: CG = C/8 lanes share a pixel (CG a power of two <= 16): every lane loads one octet, applies the
-// dropout keep mask, multiplies it with the n_cls weight octets and the CG partial sums are folded by wave shuffles.
+// ---- heads.  Forward: CG = C/8 lanes share a pixel (CG = 2^LOG2CG <= 16): every lane loads one octet, applies the
+// dropout keep mask, multiplies it with the n_cls weight octets and the CG partial sums are folded across the lanes by
+// DPP / ds_swizzle moves (xor_lane: the ds_bpermute shuffles of __shfl_xor made this kernel, like its fp32 twin,
+// instruction bound at a third of the HBM rate).  DROP: 0 = none, 1 = counter hash, 2 = mask tensor -- separate
+// instantiations keep the loop body straight-line.
+template <int LOG2CG, int DROP>
 __global__ __launch_bounds__(kThreads) void head_fwd_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ weight,
                                                                  const float* __restrict__ bias, long pixels, int HW,
-                                                                 int C, int CG, int n_cls, float keep_scale, uint32_t thr16,
+                                                                 int n_cls, float keep_scale, uint32_t thr16,
                                                                  uint64_t seed, const uint8_t* __restrict__ mask,
-                                                                 int use_drop, float* __restrict__ out) {
+                                                                 float* __restrict__ out) {
+  constexpr int CG = 1 << LOG2CG, C = 8 * CG;
   __shared__ float wsm[kHeadMaxCls * kHeadMaxC];  // (the class weights in registers, 64 VGPRs, ran 1.27x slower)
   for (int i = threadIdx.x; i < n_cls * C; i += kThreads) wsm[i] = weight[i];
   __syncthreads();
-  const int ppb = kThreads / CG;  // pixels per workgroup pass
-  const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+  constexpr int ppb = kThreads >> LOG2CG;  // pixels per workgroup pass
+  const int cg = threadIdx.x & (CG - 1), pl = threadIdx.x >> LOG2CG;
   const unsigned npix = static_cast<unsigned>(pixels), uhw = static_cast<unsigned>(HW);  // < 2^31 (launcher)
   const unsigned passes = (npix + ppb - 1) / ppb;
-  for (unsigned ps = blockIdx.x; ps < passes; ps += gridDim.x) {  // all lanes stay in the loop: shuffles below
+  for (unsigned ps = blockIdx.x; ps < passes; ps += gridDim.x) {  // all lanes stay in the loop: lane exchanges below
     const unsigned p = ps * ppb + pl;
     const bool live = p < npix;
     float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (live) {
-      unpack8(reinterpret_cast<const u32x4*>(x)[static_cast<long>(p) * CG + cg], f);
-      if (use_drop) {
+      unpack8(reinterpret_cast<const u32x4*>(x)[(static_cast<long>(p) << LOG2CG) + cg], f);
+      if constexpr (DROP == 1) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-          const uint64_t bits = (mask == nullptr) ? keep_bits(seed, p, C >> 2, 2 * cg + half) : 0;
+          const uint64_t bits = keep_bits(seed, p, 2 * CG, 2 * cg + half);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int e = 4 * half + q;
-            const bool keep = (mask != nullptr) ? (mask[static_cast<long>(p) * C + cg * 8 + e] != 0) : keep_one(bits, q, thr16);
-            f[e] = keep ? f[e] * keep_scale : 0.f;
-          }
+          for (int q = 0; q < 4; ++q) f[4 * half + q] = keep_one(bits, q, thr16) ? f[4 * half + q] * keep_scale : 0.f;
+        }
+      } else if constexpr (DROP == 2) {
+        const uint2 m8 = *reinterpret_cast<const uint2*>(mask + static_cast<long>(p) * C + cg * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned byte = ((e < 4 ? m8.x : m8.y) >> (8 * (e & 3))) & 0xffu;
+          f[e] = byte != 0 ? f[e] * keep_scale : 0.f;
         }
       }
     }
@@ -232,8 +241,8 @@ __global__ __launch_bounds__(kThreads) void head_fwd_bf16_kernel(const bf16_t* _
         float s = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) s = fmaf(f[e], wsm[k * C + cg * 8 + e], s);
-        for (int m = 1; m < CG; m <<= 1) s += __shfl_xor(s, m);  // every lane of the pixel holds the logit
-        if (live && (k % CG) == cg)                              // classes are dealt to the pixel's lanes round robin
+        static_for<LOG2CG>([&](auto mc) { s += xor_lane<(1 << decltype(mc)::v)>(s); });  // every lane of the pixel holds the logit
+        if (live && (k & (CG - 1)) == cg)                           // classes are dealt to the pixel's lanes round robin
           obase[static_cast<long>(k) * uhw] = 1.0f / (1.0f + __expf(-(s + bias[k])));
       }
     }
@@ -433,9 +442,28 @@ extern "C" int unetpp_head_fwd_bf16(const void* x, const float* weight, const fl
   if (pixels >= 0x7fffffffL) return UNETPP_EINVAL;
   const int CG = C >> 3;
   const long passes = (pixels + kThreads / CG - 1) / (kThreads / CG);
-  hipLaunchKernelGGL(head_fwd_bf16_kernel, dim3(static_cast<unsigned>(passes < 256 * 16 ? passes : 256 * 16)), dim3(kThreads),
-                     0, ST(stream), static_cast<const bf16_t*>(x), weight, bias, pixels, H * W, C, CG, n_cls,
-                     1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, p_drop > 0.f ? 1 : 0, out_nchw);
+  const dim3 grid(static_cast<unsigned>(passes < 256 * 16 ? passes : 256 * 16));
+  const int drop = p_drop > 0.f ? (mask == nullptr ? 1 : 2) : 0;
+  if (drop == 2 && (reinterpret_cast<uintptr_t>(mask) & 7) != 0) return UNETPP_EINVAL;  // mask octets are read as 8 bytes
+#define UNETPP_HEAD_BF(L, D)                                                                                          \
+  hipLaunchKernelGGL((head_fwd_bf16_kernel<L, D>), grid, dim3(kThreads), 0, ST(stream), static_cast<const bf16_t*>(x), \
+                     weight, bias, pixels, H * W, n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask,   \
+                     out_nchw)
+#define UNETPP_HEAD_BF_L(L)              \
+  do {                                   \
+    if (drop == 0) UNETPP_HEAD_BF(L, 0); \
+    else if (drop == 1) UNETPP_HEAD_BF(L, 1); \
+    else UNETPP_HEAD_BF(L, 2);           \
+  } while (0)
+  switch (CG) {
+    case 1: UNETPP_HEAD_BF_L(0); break;
+    case 2: UNETPP_HEAD_BF_L(1); break;
+    case 4: UNETPP_HEAD_BF_L(2); break;
+    case 8: UNETPP_HEAD_BF_L(3); break;
+    default: UNETPP_HEAD_BF_L(4); break;
+  }
+#undef UNETPP_HEAD_BF_L
+#undef UNETPP_HEAD_BF
   return launch_status();
 }
 
