@@ -249,33 +249,49 @@ __global__ __launch_bounds__(kThreads) void head_fwd_bf16_kernel(const bf16_t* _
   }
 }
 
-// Backward: 64-pixel tiles.  LDS: x*keep*scale fp32 [64][C+1], dlogit [64][8], W [8][C].
+// Backward: 64-pixel tiles.  LDS: x*keep*scale fp32 [64][C+1], dlogit [64][8].  C = 8 * 2^LOG2CG: index arithmetic in
+// shifts and 32 bits; a thread's octet position is the same for all its pieces, so its class weights stay in registers
+// (the first version read 32 weights from LDS per octet); the (class, channel) pairs of the weight-gradient pass are
+// decoded once; DROP (0 none, 1 counter hash, 2 mask tensor) keeps the piece loop free of per-element branches.
+template <int LOG2CG, int DROP>
 __global__ __launch_bounds__(kThreads) void head_bwd_bf16_kernel(const float* __restrict__ d_out, const float* __restrict__ outp,
                                                                  const bf16_t* __restrict__ x, const float* __restrict__ weight,
-                                                                 long pixels, int HW, int C, int n_cls, float keep_scale,
+                                                                 unsigned pixels, unsigned HW, int n_cls, float keep_scale,
                                                                  uint32_t thr16, uint64_t seed, const uint8_t* __restrict__ mask,
-                                                                 int use_drop, bf16_t* __restrict__ dx, int accumulate,
-                                                                 int gate_x, float* __restrict__ partial) {
+                                                                 bf16_t* __restrict__ dx, int accumulate, int gate_x,
+                                                                 float* __restrict__ partial) {
   extern __shared__ float hsm[];
-  const int XS = C + 1, CG = C >> 3;
-  float* xs = hsm;                         // [64][C+1]
-  float* dl = xs + 64 * XS;                // [64][8]
-  float* wsm = dl + 64 * kHeadMaxCls;      // [8][C]
+  constexpr int CG = 1 << LOG2CG, C = 8 * CG, XS = C + 1;
+  constexpr int ITEMS = (64 * CG + kThreads - 1) / kThreads;
+  float* xs = hsm;           // [64][C+1]
+  float* dl = xs + 64 * XS;  // [64][8]
   const int tid = threadIdx.x;
-  for (int i = tid; i < n_cls * C; i += kThreads) wsm[i] = weight[i];
+  const int cg = tid & (CG - 1);
+  float wq[kHeadMaxCls][8];  // class weights of this thread's octet
+#pragma unroll
+  for (int k = 0; k < kHeadMaxCls; ++k)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wq[k][e] = (k < n_cls) ? weight[k * C + cg * 8 + e] : 0.f;
   float wacc[4] = {0.f, 0.f, 0.f, 0.f};  // dW entries tid, tid+256, ... (n_cls*C <= 1024)
+  int pair_k[4], pair_c[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = tid + q * kThreads;
+    pair_k[q] = idx >> (LOG2CG + 3);
+    pair_c[q] = idx & (C - 1);
+  }
   float bacc = 0.f;
-  const long n_tiles = (pixels + 63) / 64;
-  for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const long p0 = tile * 64;
+  const unsigned n_tiles = (pixels + 63) / 64;
+  for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const unsigned p0 = tile * 64;
     __syncthreads();
     for (int it = tid; it < 64 * n_cls; it += kThreads) {  // dlogit = d_out * out * (1 - out)
       const int pl = it & 63, k = it >> 6;
-      const long p = p0 + pl;
+      const unsigned p = p0 + pl;
       float v = 0.f;
       if (p < pixels) {
-        const long n = p / HW, hw = p - n * HW;
-        const long o = (n * n_cls + k) * HW + hw;
+        const unsigned n = p / HW, hw = p - n * HW;
+        const long o = (static_cast<long>(n) * n_cls + k) * HW + hw;
         const float pr = outp[o];
         v = d_out[o] * pr * (1.f - pr);
       }
@@ -283,40 +299,47 @@ __global__ __launch_bounds__(kThreads) void head_bwd_bf16_kernel(const float* __
     }
     __syncthreads();
     // one pass over x in octets: keep mask, x*keep*scale -> LDS, dx = keep*scale * (W^T dlogit) (+ old dx, gate)
-    for (int it = tid; it < 64 * CG; it += kThreads) {
-      const int pl = it / CG, cg = it - pl * CG;
-      const long p = p0 + pl;
+#pragma unroll
+    for (int u = 0; u < ITEMS; ++u) {
+      const int it = tid + u * kThreads;
+      if (ITEMS * kThreads != 64 * CG && it >= 64 * CG) break;
+      const int pl = it >> LOG2CG;
+      const unsigned p = p0 + pl;
       float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ks[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) ks[e] = 1.f;
       if (p < pixels) {
+        const long oct = (static_cast<long>(p) << LOG2CG) + cg;
         float raw[8];
-        unpack8(reinterpret_cast<const u32x4*>(x)[p * CG + cg], raw);
-        if (use_drop) {
+        unpack8(reinterpret_cast<const u32x4*>(x)[oct], raw);
+        if constexpr (DROP == 1) {
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
-            const uint64_t bits = (mask == nullptr) ? keep_bits(seed, p, C >> 2, 2 * cg + half) : 0;
+            const uint64_t bits = keep_bits(seed, p, 2 * CG, 2 * cg + half);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int e = 4 * half + q;
-              const bool keep = (mask != nullptr) ? (mask[p * C + cg * 8 + e] != 0) : keep_one(bits, q, thr16);
-              ks[e] = keep ? keep_scale : 0.f;
-            }
+            for (int q = 0; q < 4; ++q) ks[4 * half + q] = keep_one(bits, q, thr16) ? keep_scale : 0.f;
           }
+        } else if constexpr (DROP == 2) {
+          const uint2 m8 = *reinterpret_cast<const uint2*>(mask + oct * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ks[e] = (((e < 4 ? m8.x : m8.y) >> (8 * (e & 3))) & 0xffu) != 0 ? keep_scale : 0.f;
         }
+        float dk[kHeadMaxCls];
+#pragma unroll
+        for (int k = 0; k < kHeadMaxCls; ++k) dk[k] = (k < n_cls) ? dl[pl * kHeadMaxCls + k] : 0.f;
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           f[e] = raw[e] * ks[e];
-          float s = 0.f;
+          float sum = 0.f;
 #pragma unroll
           for (int k = 0; k < kHeadMaxCls; ++k)
-            if (k < n_cls) s = fmaf(wsm[k * C + cg * 8 + e], dl[pl * kHeadMaxCls + k], s);
-          o[e] = s * ks[e];
+            if (k < n_cls) sum = fmaf(wq[k][e], dk[k], sum);
+          o[e] = sum * ks[e];
         }
         if (accumulate) {
           float old[8];
-          unpack8(reinterpret_cast<const u32x4*>(dx)[p * CG + cg], old);
+          unpack8(reinterpret_cast<const u32x4*>(dx)[oct], old);
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] += old[e];
         }
@@ -324,7 +347,7 @@ __global__ __launch_bounds__(kThreads) void head_bwd_bf16_kernel(const float* __
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (raw[e] > 0.f) ? o[e] : 0.f;
         }
-        reinterpret_cast<u32x4*>(dx)[p * CG + cg] = pack8(o);
+        reinterpret_cast<u32x4*>(dx)[oct] = pack8(o);
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) xs[pl * XS + cg * 8 + e] = f[e];
@@ -332,18 +355,17 @@ __global__ __launch_bounds__(kThreads) void head_bwd_bf16_kernel(const float* __
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {  // dW[k, c] += sum_p dlogit[p, k] * xs[p, c]
-      const int idx = tid + q * kThreads;
-      if (idx < n_cls * C) {
-        const int k = idx / C, c = idx - k * C;
-        float s = 0.f;
-        for (int pl = 0; pl < 64; ++pl) s = fmaf(dl[pl * kHeadMaxCls + k], xs[pl * XS + c], s);
-        wacc[q] += s;
+      if (tid + q * kThreads < n_cls * C) {
+        const int k = pair_k[q], c = pair_c[q];
+        float sum = 0.f;
+        for (int pl = 0; pl < 64; ++pl) sum = fmaf(dl[pl * kHeadMaxCls + k], xs[pl * XS + c], sum);
+        wacc[q] += sum;
       }
     }
     if (tid < n_cls) {
-      float s = 0.f;
-      for (int pl = 0; pl < 64; ++pl) s += dl[pl * kHeadMaxCls + tid];
-      bacc += s;
+      float sum = 0.f;
+      for (int pl = 0; pl < 64; ++pl) sum += dl[pl * kHeadMaxCls + tid];
+      bacc += sum;
     }
   }
   float* dst = partial + static_cast<long>(blockIdx.x) * (n_cls * C + n_cls);
@@ -475,11 +497,31 @@ extern "C" int unetpp_head_bwd_bf16(const float* d_out_nchw, const float* out_nc
       !head_bf16_ok(N, H, W, C, n_cls, p_drop))
     return UNETPP_EINVAL;
   const long pixels = static_cast<long>(N) * H * W;
+  if (pixels >= 0x7fffffffL) return UNETPP_EINVAL;
   const long tiles = (pixels + 63) / 64;
-  const size_t lds = (64 * (C + 1) + 64 * kHeadMaxCls + kHeadMaxCls * C) * sizeof(float);
-  hipLaunchKernelGGL(head_bwd_bf16_kernel, dim3(static_cast<unsigned>(tiles < 4096 ? tiles : 4096)), dim3(kThreads), lds,
-                     ST(stream), d_out_nchw, out_nchw, static_cast<const bf16_t*>(x), weight, pixels, H * W, C, n_cls,
-                     1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, p_drop > 0.f ? 1 : 0,
-                     static_cast<bf16_t*>(dx), accumulate, gate_x, partial);
+  const size_t lds = (64 * (C + 1) + 64 * kHeadMaxCls) * sizeof(float);
+  const dim3 grid(static_cast<unsigned>(tiles < 4096 ? tiles : 4096));
+  const int drop = p_drop > 0.f ? (mask == nullptr ? 1 : 2) : 0;
+  if (drop == 2 && (reinterpret_cast<uintptr_t>(mask) & 7) != 0) return UNETPP_EINVAL;  // mask octets are read as 8 bytes
+#define UNETPP_HEAD_BWD_BF(L, D)                                                                                       \
+  hipLaunchKernelGGL((head_bwd_bf16_kernel<L, D>), grid, dim3(kThreads), lds, ST(stream), d_out_nchw, out_nchw,         \
+                     static_cast<const bf16_t*>(x), weight, static_cast<unsigned>(pixels), static_cast<unsigned>(H * W), \
+                     n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, static_cast<bf16_t*>(dx),       \
+                     accumulate, gate_x, partial)
+#define UNETPP_HEAD_BWD_BF_L(L)              \
+  do {                                       \
+    if (drop == 0) UNETPP_HEAD_BWD_BF(L, 0); \
+    else if (drop == 1) UNETPP_HEAD_BWD_BF(L, 1); \
+    else UNETPP_HEAD_BWD_BF(L, 2);           \
+  } while (0)
+  switch (C >> 3) {
+    case 1: UNETPP_HEAD_BWD_BF_L(0); break;
+    case 2: UNETPP_HEAD_BWD_BF_L(1); break;
+    case 4: UNETPP_HEAD_BWD_BF_L(2); break;
+    case 8: UNETPP_HEAD_BWD_BF_L(3); break;
+    default: UNETPP_HEAD_BWD_BF_L(4); break;
+  }
+#undef UNETPP_HEAD_BWD_BF_L
+#undef UNETPP_HEAD_BWD_BF
   return launch_status();
 }
