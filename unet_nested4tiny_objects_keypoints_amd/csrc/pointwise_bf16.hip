@@ -197,15 +197,15 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_bf16_kernel(const bf16_
 // DPP / ds_swizzle moves (xor_lane: the ds_bpermute shuffles of __shfl_xor made this kernel, like its fp32 twin,
 // instruction bound at a third of the HBM rate).  DROP: 0 = none, 1 = counter hash, 2 = mask tensor -- separate
 // instantiations keep the loop body straight-line.
-template <int LOG2CG, int DROP>
+template <int LOG2CG, int DROP, int PCLS>  // PCLS = classes padded to 4 or 8: the class loops carry no n_cls branches
 __global__ __launch_bounds__(kThreads) void head_fwd_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ weight,
                                                                  const float* __restrict__ bias, long pixels, int HW,
                                                                  int n_cls, float keep_scale, uint32_t thr16,
                                                                  uint64_t seed, const uint8_t* __restrict__ mask,
                                                                  float* __restrict__ out) {
   constexpr int CG = 1 << LOG2CG, C = 8 * CG;
-  __shared__ float wsm[kHeadMaxCls * kHeadMaxC];  // (the class weights in registers, 64 VGPRs, ran 1.27x slower)
-  for (int i = threadIdx.x; i < n_cls * C; i += kThreads) wsm[i] = weight[i];
+  __shared__ float wsm[PCLS * C];  // zero rows past n_cls (the class weights in registers ran 1.2x slower, twice measured)
+  for (int i = threadIdx.x; i < PCLS * C; i += kThreads) wsm[i] = i < n_cls * C ? weight[i] : 0.f;
   __syncthreads();
   constexpr int ppb = kThreads >> LOG2CG;  // pixels per workgroup pass
   const int cg = threadIdx.x & (CG - 1), pl = threadIdx.x >> LOG2CG;
@@ -236,15 +236,13 @@ __global__ __launch_bounds__(kThreads) void head_fwd_bf16_kernel(const bf16_t* _
     const unsigned n = p / uhw, hw = p - n * uhw;  // one 32-bit division per pixel
     float* obase = out + static_cast<long>(n) * n_cls * uhw + hw;
 #pragma unroll
-    for (int k = 0; k < kHeadMaxCls; ++k) {
-      if (k < n_cls) {
-        float s = 0.f;
+    for (int k = 0; k < PCLS; ++k) {
+      float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s = fmaf(f[e], wsm[k * C + cg * 8 + e], s);
-        static_for<LOG2CG>([&](auto mc) { s += xor_lane<(1 << decltype(mc)::v)>(s); });  // every lane of the pixel holds the logit
-        if (live && (k & (CG - 1)) == cg)                           // classes are dealt to the pixel's lanes round robin
-          obase[static_cast<long>(k) * uhw] = 1.0f / (1.0f + __expf(-(s + bias[k])));
-      }
+      for (int e = 0; e < 8; ++e) s = fmaf(f[e], wsm[k * C + cg * 8 + e], s);
+      static_for<LOG2CG>([&](auto mc) { s += xor_lane<(1 << decltype(mc)::v)>(s); });  // every lane of the pixel holds the logit
+      if (live && k < n_cls && (k & (CG - 1)) == cg)                // classes are dealt to the pixel's lanes round robin
+        obase[static_cast<long>(k) * uhw] = 1.0f / (1.0f + __expf(-(s + bias[k])));
     }
   }
 }
@@ -253,7 +251,7 @@ __global__ __launch_bounds__(kThreads) void head_fwd_bf16_kernel(const bf16_t* _
 // shifts and 32 bits; a thread's octet position is the same for all its pieces, so its class weights stay in registers
 // (the first version read 32 weights from LDS per octet); the (class, channel) pairs of the weight-gradient pass are
 // decoded once; DROP (0 none, 1 counter hash, 2 mask tensor) keeps the piece loop free of per-element branches.
-template <int LOG2CG, int DROP>
+template <int LOG2CG, int DROP, int PCLS>
 __global__ __launch_bounds__(kThreads) void head_bwd_bf16_kernel(const float* __restrict__ d_out, const float* __restrict__ outp,
                                                                  const bf16_t* __restrict__ x, const float* __restrict__ weight,
                                                                  unsigned pixels, unsigned HW, int n_cls, float keep_scale,
@@ -267,9 +265,9 @@ __global__ __launch_bounds__(kThreads) void head_bwd_bf16_kernel(const float* __
   float* dl = xs + 64 * XS;  // [64][8]
   const int tid = threadIdx.x;
   const int cg = tid & (CG - 1);
-  float wq[kHeadMaxCls][8];  // class weights of this thread's octet
+  float wq[PCLS][8];  // class weights of this thread's octet (zero rows past n_cls)
 #pragma unroll
-  for (int k = 0; k < kHeadMaxCls; ++k)
+  for (int k = 0; k < PCLS; ++k)
 #pragma unroll
     for (int e = 0; e < 8; ++e) wq[k][e] = (k < n_cls) ? weight[k * C + cg * 8 + e] : 0.f;
   float wacc[4] = {0.f, 0.f, 0.f, 0.f};  // dW entries tid, tid+256, ... (n_cls*C <= 1024)
@@ -281,6 +279,7 @@ __global__ __launch_bounds__(kThreads) void head_bwd_bf16_kernel(const float* __
     pair_c[q] = idx & (C - 1);
   }
   float bacc = 0.f;
+  for (int i = tid; i < 64 * kHeadMaxCls; i += kThreads) dl[i] = 0.f;  // classes past n_cls are never written again
   const unsigned n_tiles = (pixels + 63) / 64;
   for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const unsigned p0 = tile * 64;
@@ -324,17 +323,16 @@ __global__ __launch_bounds__(kThreads) void head_bwd_bf16_kernel(const float* __
 #pragma unroll
           for (int e = 0; e < 8; ++e) ks[e] = (((e < 4 ? m8.x : m8.y) >> (8 * (e & 3))) & 0xffu) != 0 ? keep_scale : 0.f;
         }
-        float dk[kHeadMaxCls];
+        float dk[PCLS];  // (rows past n_cls of dl are zero: written by the dlogit pass below n_cls only, cleared once)
 #pragma unroll
-        for (int k = 0; k < kHeadMaxCls; ++k) dk[k] = (k < n_cls) ? dl[pl * kHeadMaxCls + k] : 0.f;
+        for (int k = 0; k < PCLS; ++k) dk[k] = dl[pl * kHeadMaxCls + k];
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           f[e] = raw[e] * ks[e];
           float sum = 0.f;
 #pragma unroll
-          for (int k = 0; k < kHeadMaxCls; ++k)
-            if (k < n_cls) sum = fmaf(wq[k][e], dk[k], sum);
+          for (int k = 0; k < PCLS; ++k) sum = fmaf(wq[k][e], dk[k], sum);
           o[e] = sum * ks[e];
         }
         if (accumulate) {
@@ -467,15 +465,20 @@ extern "C" int unetpp_head_fwd_bf16(const void* x, const float* weight, const fl
   const dim3 grid(static_cast<unsigned>(passes < 256 * 16 ? passes : 256 * 16));
   const int drop = p_drop > 0.f ? (mask == nullptr ? 1 : 2) : 0;
   if (drop == 2 && (reinterpret_cast<uintptr_t>(mask) & 7) != 0) return UNETPP_EINVAL;  // mask octets are read as 8 bytes
-#define UNETPP_HEAD_BF(L, D)                                                                                          \
-  hipLaunchKernelGGL((head_fwd_bf16_kernel<L, D>), grid, dim3(kThreads), 0, ST(stream), static_cast<const bf16_t*>(x), \
-                     weight, bias, pixels, H * W, n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask,   \
+#define UNETPP_HEAD_BF(L, D, PC)                                                                                          \
+  hipLaunchKernelGGL((head_fwd_bf16_kernel<L, D, PC>), grid, dim3(kThreads), 0, ST(stream), static_cast<const bf16_t*>(x), \
+                     weight, bias, pixels, H * W, n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask,       \
                      out_nchw)
+#define UNETPP_HEAD_BF_D(L, D)            \
+  do {                                    \
+    if (n_cls <= 4) UNETPP_HEAD_BF(L, D, 4); \
+    else UNETPP_HEAD_BF(L, D, 8);         \
+  } while (0)
 #define UNETPP_HEAD_BF_L(L)              \
   do {                                   \
-    if (drop == 0) UNETPP_HEAD_BF(L, 0); \
-    else if (drop == 1) UNETPP_HEAD_BF(L, 1); \
-    else UNETPP_HEAD_BF(L, 2);           \
+    if (drop == 0) UNETPP_HEAD_BF_D(L, 0); \
+    else if (drop == 1) UNETPP_HEAD_BF_D(L, 1); \
+    else UNETPP_HEAD_BF_D(L, 2);         \
   } while (0)
   switch (CG) {
     case 1: UNETPP_HEAD_BF_L(0); break;
@@ -485,6 +488,7 @@ extern "C" int unetpp_head_fwd_bf16(const void* x, const float* weight, const fl
     default: UNETPP_HEAD_BF_L(4); break;
   }
 #undef UNETPP_HEAD_BF_L
+#undef UNETPP_HEAD_BF_D
 #undef UNETPP_HEAD_BF
   return launch_status();
 }
@@ -503,8 +507,13 @@ extern "C" int unetpp_head_bwd_bf16(const float* d_out_nchw, const float* out_nc
   const dim3 grid(static_cast<unsigned>(tiles < 4096 ? tiles : 4096));
   const int drop = p_drop > 0.f ? (mask == nullptr ? 1 : 2) : 0;
   if (drop == 2 && (reinterpret_cast<uintptr_t>(mask) & 7) != 0) return UNETPP_EINVAL;  // mask octets are read as 8 bytes
-#define UNETPP_HEAD_BWD_BF(L, D)                                                                                       \
-  hipLaunchKernelGGL((head_bwd_bf16_kernel<L, D>), grid, dim3(kThreads), lds, ST(stream), d_out_nchw, out_nchw,         \
+#define UNETPP_HEAD_BWD_BF(L, D)                                    \
+  do {                                                              \
+    if (n_cls <= 4) UNETPP_HEAD_BWD_BF_P(L, D, 4);                  \
+    else UNETPP_HEAD_BWD_BF_P(L, D, 8);                             \
+  } while (0)
+#define UNETPP_HEAD_BWD_BF_P(L, D, PC)                                                                                 \
+  hipLaunchKernelGGL((head_bwd_bf16_kernel<L, D, PC>), grid, dim3(kThreads), lds, ST(stream), d_out_nchw, out_nchw,     \
                      static_cast<const bf16_t*>(x), weight, static_cast<unsigned>(pixels), static_cast<unsigned>(H * W), \
                      n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, static_cast<bf16_t*>(dx),       \
                      accumulate, gate_x, partial)
@@ -523,5 +532,6 @@ extern "C" int unetpp_head_bwd_bf16(const float* d_out_nchw, const float* out_nc
   }
 #undef UNETPP_HEAD_BWD_BF_L
 #undef UNETPP_HEAD_BWD_BF
+#undef UNETPP_HEAD_BWD_BF_P
   return launch_status();
 }
