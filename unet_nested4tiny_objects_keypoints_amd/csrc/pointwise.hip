@@ -885,7 +885,7 @@ __global__ __launch_bounds__(kThreads, 4) void head_bwd_vec_kernel(const float* 
 // live in registers (the general kernel re-reads them from LDS per piece: 16 + 4 LDS reads per 16 bytes of x), the
 // (class, channel) pairs of the weight-gradient pass are decoded once instead of once per tile, and the dropout mode is
 // a template parameter (0 none, 1 counter hash, 2 mask tensor) so that the piece loop is straight-line code.
-template <int LOG2G, int DROP>
+template <int LOG2G, int DROP, int PCLS>  // PCLS = classes padded to 4 or 8 (zero weights past n_cls: no class branches)
 __global__ __launch_bounds__(kThreads, 4) void head_bwd_pow2_kernel(const float* __restrict__ d_out,
                                                                  const float* __restrict__ outp,
                                                                  const float* __restrict__ x,
@@ -903,11 +903,11 @@ __global__ __launch_bounds__(kThreads, 4) void head_bwd_pow2_kernel(const float*
   float* scratch = dl + 64 * kHeadMaxCls;
   const int tid = threadIdx.x;
   const int gq = tid & (G - 1);  // channel quad of every piece of this thread (kThreads is a multiple of G)
-  f32x4 wq[kHeadMaxCls];
+  f32x4 wq[PCLS];
 #pragma unroll
-  for (int k = 0; k < kHeadMaxCls; ++k)
+  for (int k = 0; k < PCLS; ++k)
     wq[k] = (k < n_cls) ? *reinterpret_cast<const f32x4*>(weight + k * C + 4 * gq) : f32x4{0.f, 0.f, 0.f, 0.f};
-  constexpr int kMaxPairs = (kHeadMaxCls * C + 127) / 128;  // (k, c) pairs per thread
+  constexpr int kMaxPairs = (PCLS * C + 127) / 128;  // (k, c) pairs per thread
   float wacc[kMaxPairs];
   int pair_k[kMaxPairs], pair_c[kMaxPairs];
   const int pair0 = tid & 127, half = tid >> 7;
@@ -919,6 +919,7 @@ __global__ __launch_bounds__(kThreads, 4) void head_bwd_pow2_kernel(const float*
     pair_c[q] = idx & (C - 1);
   }
   float bacc = 0.f;
+  for (int i = tid; i < 64 * kHeadMaxCls; i += kThreads) dl[i] = 0.f;  // classes past n_cls are never written again
   const unsigned n_tiles = (pixels + 63) / 64;
   for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const unsigned p0 = tile * 64;
@@ -958,12 +959,10 @@ __global__ __launch_bounds__(kThreads, 4) void head_bwd_pow2_kernel(const float*
         }
         f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < kHeadMaxCls; ++k) {
-          if (k < n_cls) {
-            const float dk = dl[pl * kHeadMaxCls + k];
+        for (int k = 0; k < PCLS; ++k) {
+          const float dk = dl[pl * kHeadMaxCls + k];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) sacc[q] += wq[k][q] * dk;
-          }
+          for (int q = 0; q < 4; ++q) sacc[q] += wq[k][q] * dk;
         }
         f32x4 old = {0.f, 0.f, 0.f, 0.f};
         if (accumulate) old = *reinterpret_cast<const f32x4*>(dx + off);
@@ -1455,8 +1454,13 @@ extern "C" int unetpp_head_bwd(const float* d_out_nchw, const float* out_nchw, c
     const size_t lds = (64 * (C + 1) + 64 * kHeadMaxCls + 2 * n_cls * C) * sizeof(float);
     const dim3 grid(static_cast<unsigned>(unetpp_head_bwd_blocks(pixels)));
     const int drop = !use_drop ? 0 : (mask == nullptr ? 1 : 2);
-#define UNETPP_HEAD_BWD(L, D)                                                                                       \
-  hipLaunchKernelGGL((head_bwd_pow2_kernel<L, D>), grid, dim3(kThreads), lds, ST(stream), d_out_nchw, out_nchw, x,   \
+#define UNETPP_HEAD_BWD(L, D)                    \
+  do {                                           \
+    if (n_cls <= 4) UNETPP_HEAD_BWD_P(L, D, 4);  \
+    else UNETPP_HEAD_BWD_P(L, D, 8);             \
+  } while (0)
+#define UNETPP_HEAD_BWD_P(L, D, PC)                                                                                 \
+  hipLaunchKernelGGL((head_bwd_pow2_kernel<L, D, PC>), grid, dim3(kThreads), lds, ST(stream), d_out_nchw, out_nchw, x, \
                      weight, static_cast<unsigned>(pixels), static_cast<unsigned>(H * W), n_cls, 1.0f / (1.0f - p_drop), \
                      keep_threshold(p_drop), seed, mask, dx, accumulate, gate_x, partial)
 #define UNETPP_HEAD_BWD_L(L)              \
@@ -1474,6 +1478,7 @@ extern "C" int unetpp_head_bwd(const float* d_out_nchw, const float* out_nchw, c
     }
 #undef UNETPP_HEAD_BWD_L
 #undef UNETPP_HEAD_BWD
+#undef UNETPP_HEAD_BWD_P
     return launch_status();
   }
   if ((C & 3) == 0 && aligned16(x) && aligned16(dx)) {
