@@ -45,6 +45,9 @@ __device__ __forceinline__ void lds_wait8x2(f32x2_t (&d)[8]) {
   asm volatile("s_waitcnt lgkmcnt(0)"
                : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]));
 }
+__device__ __forceinline__ void lds_wait4x2(f32x2_t (&d)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+}
 // Packed fp32 adds on register pairs (v_pk_add_f32, one issue slot for two adds; tools/probes/pk_add_probe.hip checks
 // the operand-select / negate modifiers on the device).  Results are bit-identical to the scalar expressions.
 __device__ __forceinline__ f32x2_t pk_add(f32x2_t a, f32x2_t b) {  // (a.x + b.x, a.y + b.y)
@@ -65,6 +68,11 @@ __device__ __forceinline__ f32x2_t pk_sub_add_x(f32x2_t a, f32x2_t b) {  // (a.x
 __device__ __forceinline__ f32x2_t pk_cross_sub(f32x2_t a, f32x2_t b) {  // (b.x - a.y, a.y - b.y)
   f32x2_t r;
   asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(b), "v"(a));
+  return r;
+}
+__device__ __forceinline__ f32x2_t pk_sum_diff(f32x2_t a) {  // (a.x + a.y, a.x - a.y)
+  f32x2_t r;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(a));
   return r;
 }
 __device__ __forceinline__ void lds_wait(f32x4& a, f32x4& b) {

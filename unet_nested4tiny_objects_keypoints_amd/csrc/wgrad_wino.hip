@@ -62,6 +62,8 @@ struct WWinoArgs {
   long n_pix_tiles;
 };
 
+constexpr int x_slot(int U) { return (U >> 3) * GX + (U & 7) * 32; }  // float offset of pixel slot U of the x patch
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -140,6 +142,13 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
   }
   // Edge patches take two passes: zero fills of out-of-image pixels first (plain ds_writes), then the DMAs -- a
   // ds_write into an array with a DMA in flight makes hipcc drain vmcnt first (see wgrad_dma.hip).
+  // in_block: hipcc hoists the zero extension of a 32-bit offset out of the loop and then keeps ten 64-bit pairs (and
+  // adds them to the base with v_lshl_add_u64); an offset that is "produced" next to its use stays one register and
+  // selects the DMA's scalar-base + 32-bit-offset addressing.
+  auto in_block = [](unsigned v) {
+    asm volatile("" : "+v"(v));
+    return v;
+  };
   auto issue_tile = [&](unsigned tile, float* buf) {  // tile < 2^31 (launcher); uniform: the decode runs on the SALU
     __builtin_amdgcn_s_setprio(3);
     unsigned b = __builtin_amdgcn_readfirstlane(tile);
@@ -159,45 +168,49 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
           float* lbase = buf + (q * 8 + wave) * GX;  // wave-uniform; the DMA adds lane * 16 bytes
           const int hp = (tid >> 3) + q * (kWThreads >> 3);
           if (hp < kNPix && hp % kXRow < kHWp)
-            __builtin_amdgcn_global_load_lds((gptr_t)(xb + xdelta[q]), (lptr_t)lbase, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(xb + in_block(xdelta[q])), (lptr_t)lbase, 16, 0, 0);
         }
       }
       if (nx_ok) {
 #pragma unroll
         for (int q = 0; q < DY_ITEMS; ++q) {
           float* lbase = buf + X_FLOATS + (q * 8 + wave) * GY;
-          __builtin_amdgcn_global_load_lds((gptr_t)(yb + ydelta[q]), (lptr_t)lbase, 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gptr_t)(yb + in_block(ydelta[q])), (lptr_t)lbase, 16, 0, 0);
         }
       }
     } else {
       unsigned xin = 0, yin = 0;  // bit q: item q of this thread lies inside the image
+      // everything below derives from te: "produced" here, so that hipcc cannot hoist two dozen per-thread
+      // invariants of this (border-only) path out of the tile loop into registers the MFMA phase needs
+      const int te = static_cast<int>(in_block(static_cast<unsigned>(tid)));
+      const int we = te >> 6, lqe = (te & 63) * 4;
 #pragma unroll
       for (int q = 0; q < X_ITEMS; ++q) {
-        const int it = tid + q * kWThreads;
+        const int it = te + q * kWThreads;
         const int hp = it >> 3;
         const int hy = hp / kXRow, hx = hp - hy * kXRow;
         const int y = ty0 + hy - 1, x = tx0 + hx - 1;
         const bool valid = hp < kNPix && hx < kHWp && kx_ok;
         const bool inimg = y >= 0 && y < d.H && x >= 0 && x < d.W;
         if (valid && inimg) xin |= 1u << q;
-        if (valid && !inimg) *reinterpret_cast<f32x4*>(buf + (q * 8 + wave) * GX + lq) = f32x4{x_pad, x_pad, x_pad, x_pad};
+        if (valid && !inimg) *reinterpret_cast<f32x4*>(buf + (q * 8 + we) * GX + lqe) = f32x4{x_pad, x_pad, x_pad, x_pad};
       }
 #pragma unroll
       for (int q = 0; q < DY_ITEMS; ++q) {
-        const int p = (tid + q * kWThreads) >> 3;
+        const int p = (te + q * kWThreads) >> 3;
         const bool inimg = ty0 + (p >> 5) < d.H && tx0 + (p & 31) < d.W;
         if (nx_ok && inimg) yin |= 1u << q;
-        if (nx_ok && !inimg) *reinterpret_cast<f32x4*>(buf + X_FLOATS + (q * 8 + wave) * GY + lq) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (nx_ok && !inimg) *reinterpret_cast<f32x4*>(buf + X_FLOATS + (q * 8 + we) * GY + lqe) = f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int q = 0; q < X_ITEMS; ++q) {
         float* lbase = buf + (q * 8 + wave) * GX;
-        if ((xin >> q) & 1u) __builtin_amdgcn_global_load_lds((gptr_t)(xb + xdelta[q]), (lptr_t)lbase, 16, 0, 0);
+        if ((xin >> q) & 1u) __builtin_amdgcn_global_load_lds((gptr_t)(xb + in_block(xdelta[q])), (lptr_t)lbase, 16, 0, 0);
       }
 #pragma unroll
       for (int q = 0; q < DY_ITEMS; ++q) {
         float* lbase = buf + X_FLOATS + (q * 8 + wave) * GY;
-        if ((yin >> q) & 1u) __builtin_amdgcn_global_load_lds((gptr_t)(yb + ydelta[q]), (lptr_t)lbase, 16, 0, 0);
+        if ((yin >> q) & 1u) __builtin_amdgcn_global_load_lds((gptr_t)(yb + in_block(ydelta[q])), (lptr_t)lbase, 16, 0, 0);
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -214,91 +227,91 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
   // window element = 72 g + 8 tg + (36 i + j + 2 r): whole groups for g and tg, a compile-time rest.
   const int lane_x = (9 * g + tg) * GX + 16 * ch + t16;
   const int lane_y = X_FLOATS + (8 * g + tg) * GY + t16;
-  auto compute = [&](const float* buf, int half) {
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int r = 2 * half + rr;
-      float t[4][4], V[16];
-      // all LDS operands of the k-step (x window, 2x2 dy values of both column halves) by hand-placed reads with ONE
-      // wait (lds_asm.h): left to hipcc, each of the three groups is read directly in front of its first use
-      float dyv[2][4];
-      {
-        float xa[4][4];
-        const unsigned xb = lds_offset(buf) + lane_x * 4, yb = lds_offset(buf) + lane_y * 4;
-        float xl[16];
+  // Adjacent windows of a tile row share two columns, and the column pass of B^T d B works on whole columns: k-step r
+  // reads only the window's last column pair (ds_read2_b32: the two pixels are 128 bytes apart in their group), runs
+  // the column pass on it and keeps the result for k-step r + 1 (tc).  All adds are packed (v_pk_add_f32 on the
+  // register pairs the reads deliver); every value is the same expression of the same operands as in the 16-read form.
+  f32x2_t tc[4];
+  auto compute = [&](const float* buf, auto hc) {
+    const unsigned xb = lds_offset(buf) + lane_x * 4, yb = lds_offset(buf) + lane_y * 4;
+    static_for<2>([&](auto rrc) {
+      constexpr int r = 2 * decltype(hc)::v + decltype(rrc)::v;
+      // all LDS operands of the k-step by hand-placed reads with ONE wait (lds_asm.h): left to hipcc, each group is
+      // read directly in front of its first use.  x: single reads with 16-bit immediates off one address (rows are
+      // 4.5 groups apart, out of ds_read2's 8-bit range); dy: the two pixels of a tile row in one ds_read2_b32.
+      f32x2_t in[8], first[4];  // in[i]: columns 2r+2, 2r+3 of window row i; in[4 + 2 nh + ap]: dy row ap, column half nh
+      static_for<4>([&](auto ic) {
+        constexpr int i = decltype(ic)::v, U = kXRow * i + 2 * r + 2;
+        float lo, hi;
+        lds_read_b32<x_slot(U) * 4>(lo, xb);
+        lds_read_b32<x_slot(U + 1) * 4>(hi, xb);
+        in[i] = f32x2_t{lo, hi};
         if (r == 0) {
-          static_for<16>([&](auto ic) { constexpr int e = decltype(ic)::v, U = kXRow * (e / 4) + (e % 4) + 0; lds_read_b32<((U >> 3) * GX + (U & 7) * 32) * 4>(xl[e], xb); });
-          static_for<8>([&](auto ic) { constexpr int e = decltype(ic)::v, P = kTW * ((e & 3) / 2) + (e & 1) + 0; lds_read_b32<(16 * (e >> 2) + (P >> 3) * GY + (P & 7) * 32) * 4>(dyv[e >> 2][e & 3], yb); });
-        } else if (r == 1) {
-          static_for<16>([&](auto ic) { constexpr int e = decltype(ic)::v, U = kXRow * (e / 4) + (e % 4) + 2; lds_read_b32<((U >> 3) * GX + (U & 7) * 32) * 4>(xl[e], xb); });
-          static_for<8>([&](auto ic) { constexpr int e = decltype(ic)::v, P = kTW * ((e & 3) / 2) + (e & 1) + 2; lds_read_b32<(16 * (e >> 2) + (P >> 3) * GY + (P & 7) * 32) * 4>(dyv[e >> 2][e & 3], yb); });
-        } else if (r == 2) {
-          static_for<16>([&](auto ic) { constexpr int e = decltype(ic)::v, U = kXRow * (e / 4) + (e % 4) + 4; lds_read_b32<((U >> 3) * GX + (U & 7) * 32) * 4>(xl[e], xb); });
-          static_for<8>([&](auto ic) { constexpr int e = decltype(ic)::v, P = kTW * ((e & 3) / 2) + (e & 1) + 4; lds_read_b32<(16 * (e >> 2) + (P >> 3) * GY + (P & 7) * 32) * 4>(dyv[e >> 2][e & 3], yb); });
-        } else {
-          static_for<16>([&](auto ic) { constexpr int e = decltype(ic)::v, U = kXRow * (e / 4) + (e % 4) + 6; lds_read_b32<((U >> 3) * GX + (U & 7) * 32) * 4>(xl[e], xb); });
-          static_for<8>([&](auto ic) { constexpr int e = decltype(ic)::v, P = kTW * ((e & 3) / 2) + (e & 1) + 6; lds_read_b32<(16 * (e >> 2) + (P >> 3) * GY + (P & 7) * 32) * 4>(dyv[e >> 2][e & 3], yb); });
+          lds_read_b32<x_slot(kXRow * i) * 4>(lo, xb);
+          lds_read_b32<x_slot(kXRow * i + 1) * 4>(hi, xb);
+          first[i] = f32x2_t{lo, hi};
         }
-        lds_wait16(xl);
-        lds_wait4(dyv[0]);
-        lds_wait4(dyv[1]);
+      });
+      const unsigned yb1 = in_block(yb) + 4 * GY * 4;  // dy row 1: four groups up (kept out of the long-lived registers)
+      static_for<4>([&](auto ic) {
+        constexpr int nh = decltype(ic)::v >> 1, ap = decltype(ic)::v & 1;
+        lds_read2_b32<16 * nh + 2 * r * 32, 16 * nh + (2 * r + 1) * 32>(in[4 + 2 * nh + ap], ap ? yb1 : yb);
+      });
+      if (r == 0) lds_wait4x2(first);
+      lds_wait8x2(in);
+      auto fold = [&](f32x2_t& v) {  // BatchNorm apply + ReLU of the producer, folded into the operand read;
+        v.x = fmaxf(fmaf(v.x, x_sc, x_sh), 0.f);  // max(NaN, 0) = 0 (padding)
+        v.y = fmaxf(fmaf(v.y, x_sc, x_sh), 0.f);
+      };
+      auto column_pass = [&](f32x2_t* x, f32x2_t* t) {
+        if (XFORM) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) xa[i][j] = xl[4 * i + j];
-        if (XFORM) {  // BatchNorm apply + ReLU of the producer, folded into the operand read; max(NaN, 0) = 0 (padding)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xa[i][j] = fmaxf(fmaf(xa[i][j], x_sc, x_sh), 0.f);
+          for (int i = 0; i < 4; ++i) fold(x[i]);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          t[0][j] = xa[0][j] - xa[2][j];
-          t[1][j] = xa[1][j] + xa[2][j];
-          t[2][j] = xa[2][j] - xa[1][j];
-          t[3][j] = xa[1][j] - xa[3][j];
-        }
-      }
+        t[0] = pk_sub(x[0], x[2]);
+        t[1] = pk_add(x[1], x[2]);
+        t[2] = pk_sub(x[2], x[1]);
+        t[3] = pk_sub(x[1], x[3]);
+      };
+      if (r == 0) column_pass(first, tc);
+      f32x2_t tn[4], V[8];
+      column_pass(in, tn);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        V[4 * i + 0] = t[i][0] - t[i][2];
-        V[4 * i + 1] = t[i][1] + t[i][2];
-        V[4 * i + 2] = t[i][2] - t[i][1];
-        V[4 * i + 3] = t[i][1] - t[i][3];
+        V[2 * i] = pk_sub_add_x(tc[i], tn[i]);      // t0 - t2, t1 + t2
+        V[2 * i + 1] = pk_cross_sub(tc[i], tn[i]);  // t2 - t1, t1 - t3
+        tc[i] = tn[i];
       }
+      // The packed adds are inline asm, which hipcc's hazard recogniser does not treat as VALU writes: one of them
+      // placed among or right behind the MFMAs may overwrite a register that an MFMA in flight still reads as its C
+      // operand (the accumulators are renamed freely; 7 wait states are required).  All of them depend on the k-step's
+      // LDS reads (a round trip behind the previous MFMA batch); the second column half's additionally on an s_nop 7
+      // that "produces" their inputs, and fences keep them out of the MFMA batches.
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh) {
-        float dy[2][2];
-#pragma unroll
-        for (int ap = 0; ap < 2; ++ap)
-#pragma unroll
-          for (int bp = 0; bp < 2; ++bp) dy[ap][bp] = dyv[nh][2 * ap + bp];
         // A dY A^T with A's last row taken as (0, +1): rows (d0, d0 + d1, d0 - d1, d1); the finish kernel applies the
         // sign (-1)^[a == 3] (-1)^[b == 3]
-        float rw[4][2];
+        if (nh == 1) asm volatile("s_nop 7" : "+v"(in[6]), "+v"(in[7]));
+        const f32x2_t rw[4] = {in[4 + 2 * nh], pk_add(in[4 + 2 * nh], in[5 + 2 * nh]),
+                               pk_sub(in[4 + 2 * nh], in[5 + 2 * nh]), in[5 + 2 * nh]};
+        f32x2_t sd[4];  // (left + right, left - right) of each row
 #pragma unroll
-        for (int bp = 0; bp < 2; ++bp) {
-          rw[0][bp] = dy[0][bp];
-          rw[1][bp] = dy[0][bp] + dy[1][bp];
-          rw[2][bp] = dy[0][bp] - dy[1][bp];
-          rw[3][bp] = dy[1][bp];
-        }
-        float M[16];
+        for (int aa = 0; aa < 4; ++aa) sd[aa] = pk_sum_diff(rw[aa]);
+        dbsum[nh] += sd[1].x;  // (1,1): the plain sum of the 2x2 tile
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int aa = 0; aa < 4; ++aa) {
-          M[4 * aa + 0] = rw[aa][0];
-          M[4 * aa + 1] = rw[aa][0] + rw[aa][1];
-          M[4 * aa + 2] = rw[aa][0] - rw[aa][1];
-          M[4 * aa + 3] = rw[aa][1];
-        }
-        dbsum[nh] += M[5];  // (1,1): the plain sum of the 2x2 tile
+          const float M[4] = {rw[aa].x, sd[aa].x, sd[aa].y, rw[aa].y};
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi)
-          acc[xi][nh] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi], M[xi], acc[xi][nh], 0, 0, 0);
+          for (int bb = 0; bb < 4; ++bb) {
+            const int xi = 4 * aa + bb;
+            const float v = (xi & 1) ? V[xi >> 1].y : V[xi >> 1].x;
+            acc[xi][nh] = __builtin_amdgcn_mfma_f32_16x16x4f32(v, M[bb], acc[xi][nh], 0, 0, 0);
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);  // 128 accumulator registers: keep the next batch's operands from being hoisted
       }
-    }
+    });
   };
 
   // tiles of this workgroup: blockIdx.x, +gridDim.x, ...   (buffer A holds even, buffer B odd local tiles)
@@ -319,11 +332,11 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
   for (int i = 0; i < n_my; i += 2) {
     if (!late && i + 1 < n_my) issue_tile(t0 + (i + 1) * stride, buf_b);
     WW_STAMP(1);  // 1: DMA issue (early waves)
-    compute(buf_a, 0);
+    compute(buf_a, IC<0>{});
     WW_STAMP(2);  // 2: MFMA half 0
     if (late && i + 1 < n_my) issue_tile(t0 + (i + 1) * stride, buf_b);
     WW_STAMP(3);  // 3: DMA issue (late waves)
-    compute(buf_a, 1);
+    compute(buf_a, IC<1>{});
     WW_STAMP(4);  // 4: MFMA half 1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     WW_STAMP(5);  // 5: wait for the DMAs
@@ -332,11 +345,11 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
     if (i + 1 < n_my) {
       if (!late && i + 2 < n_my) issue_tile(t0 + (i + 2) * stride, buf_a);
       WW_STAMP(1);
-      compute(buf_b, 0);
+      compute(buf_b, IC<0>{});
       WW_STAMP(2);
       if (late && i + 2 < n_my) issue_tile(t0 + (i + 2) * stride, buf_a);
       WW_STAMP(3);
-      compute(buf_b, 1);
+      compute(buf_b, IC<1>{});
       WW_STAMP(4);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       WW_STAMP(5);
