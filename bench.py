@@ -254,8 +254,13 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        # launches on steps 0, 4, 8, ...; named regions (the X_0,0 block) on the odd steps WITHOUT per-launch events
+        # inside them (two event pairs inside the block would add ~12 us to its ~420)
         sample = timer is not None and i % sample_every == 0
-        ops.set_timer(timer if sample else None)
+        sample_regions = timer is not None and i % 2 == 1
+        if timer is not None:
+            timer.want_launches, timer.want_regions = sample, sample_regions
+        ops.set_timer(timer if (sample or sample_regions) else None)
         sampled_steps += int(sample)
         train_step(model, opt, crit, x, target)
     ops.set_timer(None)

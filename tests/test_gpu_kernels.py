@@ -675,3 +675,4 @@ def test_conv3x3_view_larger_than_2gb_takes_the_general_kernel(dev):
         ref = F.conv2d(F.pad(crop, pad), wt.double())
         got = out[n, y0:y0 + 40, x0:x0 + 48].permute(2, 0, 1).unsqueeze(0).cpu()
         assert rel_err(got, ref.float()) < TOL
+

@@ -9,6 +9,7 @@
 //             grid-stride loop of patches; fixed-order LDS reduction; one slab per workgroup (wgrad_finish sums them)
 #include "bf16_common.h"
 #include "common.h"
+#include "lds_asm.h"
 
 namespace unetpp {
 namespace {
@@ -42,81 +43,154 @@ __device__ __forceinline__ void stage_patch(const SmallArgs& a, float* xs, int n
 }
 
 // BF: the output (forward) / the output gradient (wgrad) is bf16 storage (UNETPP_GEMM_BF16); the input stays fp32
+//
+// Forward: persistent workgroups over the patches (grid-stride).  The geometry of a thread's halo items is the same
+// for every patch, so it is decoded once; the next patch's input is requested into registers before the current one
+// is computed (two LDS buffers, one barrier per patch for the input); a thread keeps its four output channels' weights
+// in registers when there is one input channel; the BatchNorm partial sums are reduced with lane shuffles inside a
+// wave and in fixed order across the four waves.
 template <int CIN, bool BF = false>
 __global__ __launch_bounds__(kThreads) void small_cin_fwd_kernel(const SmallArgs a) {
-  __shared__ float xs[kMaxHaloPixels * CIN];
-  __shared__ __attribute__((aligned(16))) float ws[9 * CIN * kMaxCout];
-  __shared__ float red[kThreads][8];
+  constexpr int ITEMS = (kMaxHaloPixels * CIN + kThreads - 1) / kThreads;
+  constexpr bool WREG = CIN == 1;
+  __shared__ float xs2[2][kMaxHaloPixels * CIN];
+  __shared__ __attribute__((aligned(16))) float ws[WREG ? 4 : 9 * CIN * kMaxCout];
+  __shared__ float red[4][kMaxCout * 2];  // [wave][quad][s1 x 4, s2 x 4]
   const int tid = threadIdx.x;
   const int TW = 1 << a.log2tw, TH = kBlockPixels >> a.log2tw, HWp = TW + 2;
-  long b = blockIdx.x;
-  const int txi = static_cast<int>(b % a.tiles_x);
-  b /= a.tiles_x;
-  const int tyi = static_cast<int>(b % a.tiles_y);
-  const int n = static_cast<int>(b / a.tiles_y);
-  const int ty0 = tyi * TH, tx0 = txi * TW;
-  stage_patch<CIN>(a, xs, n, ty0, tx0, TW, TH);
-  for (int i = tid; i < 9 * CIN * a.COUT; i += kThreads) ws[i] = a.w[i];
-  __syncthreads();
-
+  const int npix = HWp * (TH + 2);
   const int QN = a.COUT >> 2;             // 4-channel groups; the launcher guarantees 256 % QN == 0
   const int quad = tid % QN, psub = tid / QN, pstep = kThreads / QN;
+
+  // halo items of this thread: offset from the patch's first pixel and position inside the halo
+  int rel[ITEMS], pos[ITEMS];  // pos = hy << 16 | hx, or -1 for no item
+#pragma unroll
+  for (int q = 0; q < ITEMS; ++q) {
+    const int it = tid + q * kThreads;
+    const int hp = it / CIN, ci = it - hp * CIN;
+    const int hy = hp / HWp, hx = hp - hy * HWp;
+    rel[q] = ((hy - 1) * a.W + (hx - 1)) * CIN + ci;
+    pos[q] = hp < npix ? (hy << 16 | hx) : -1;
+  }
+  float pre[ITEMS];
+  auto request = [&](unsigned patch) {
+    unsigned b = patch;
+    const int txi = static_cast<int>(b % static_cast<unsigned>(a.tiles_x));
+    b /= static_cast<unsigned>(a.tiles_x);
+    const int tyi = static_cast<int>(b % static_cast<unsigned>(a.tiles_y));
+    const int n = static_cast<int>(b / static_cast<unsigned>(a.tiles_y));
+    const int ty0 = tyi * TH, tx0 = txi * TW;
+    const float* origin = a.x + ((static_cast<long>(n) * a.H + ty0) * a.W + tx0) * CIN;
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) {
+      const int y = ty0 + (pos[q] >> 16) - 1, x = tx0 + (pos[q] & 0xffff) - 1;
+      pre[q] = (pos[q] >= 0 && y >= 0 && y < a.H && x >= 0 && x < a.W) ? origin[rel[q]] : 0.f;
+    }
+  };
+
+  f32x4 wr[WREG ? 9 : 1];
+  if (WREG) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) wr[tap] = *reinterpret_cast<const f32x4*>(a.w + tap * a.COUT + 4 * quad);
+  } else {
+    for (int i = tid; i < 9 * CIN * a.COUT; i += kThreads) ws[i] = a.w[i];
+  }
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
   if (a.bias != nullptr) bias4 = *reinterpret_cast<const f32x4*>(a.bias + 4 * quad);
-  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-  for (int p = psub; p < kBlockPixels; p += pstep) {
-    const int py = p >> a.log2tw, px = p & (TW - 1);
-    const int y = ty0 + py, x = tx0 + px;
-    if (y < a.H && x < a.W) {
-      f32x4 acc = bias4;
+
+  const unsigned n_patches = static_cast<unsigned>(a.n_patches);
+  unsigned patch = blockIdx.x;
+  if (patch < n_patches) request(patch);
+  for (int k = 0; patch < n_patches; patch += gridDim.x, ++k) {
+    float* xs = xs2[k & 1];
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const float* xp = &xs[((py + tap / 3) * HWp + px + tap % 3) * CIN];
+    for (int q = 0; q < ITEMS; ++q)
+      if (pos[q] >= 0) xs[tid + q * kThreads] = pre[q];
+    __syncthreads();  // the patch is staged; everybody is done with the other buffer and with red[]
+    if (patch + gridDim.x < n_patches) request(patch + gridDim.x);
+
+    unsigned b = patch;
+    const int txi = static_cast<int>(b % static_cast<unsigned>(a.tiles_x));
+    b /= static_cast<unsigned>(a.tiles_x);
+    const int tyi = static_cast<int>(b % static_cast<unsigned>(a.tiles_y));
+    const int n = static_cast<int>(b / static_cast<unsigned>(a.tiles_y));
+    const int ty0 = tyi * TH, tx0 = txi * TW;
+    float* y_patch = BF ? reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(a.y) + ((static_cast<long>(n) * a.H + ty0) * a.W + tx0) * a.yC)
+                        : a.y + ((static_cast<long>(n) * a.H + ty0) * a.W + tx0) * a.yC;
+    // two-channel register pairs: hipcc selects v_pk_fma_f32 / v_pk_add_f32 for the vector arithmetic (18 + 4 issue
+    // slots per pixel instead of 36 + 8; the kernel is as much VALU- as HBM-bound)
+    f32x2_t s1a = {0.f, 0.f}, s1b = {0.f, 0.f}, s2a = {0.f, 0.f}, s2b = {0.f, 0.f};
+    for (int p = psub; p < kBlockPixels; p += pstep) {
+      const int py = p >> a.log2tw, px = p & (TW - 1);
+      const int y = ty0 + py, x = tx0 + px;
+      if (y < a.H && x < a.W) {
+        f32x2_t acc_a = {bias4[0], bias4[1]}, acc_b = {bias4[2], bias4[3]};
 #pragma unroll
-        for (int ci = 0; ci < CIN; ++ci) {
-          const float xv = xp[ci];
-          const f32x4 w4 = *reinterpret_cast<const f32x4*>(&ws[(tap * CIN + ci) * a.COUT + 4 * quad]);
+        for (int tap = 0; tap < 9; ++tap) {
+          const float* xp = &xs[((py + tap / 3) * HWp + px + tap % 3) * CIN];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] = fmaf(xv, w4[e], acc[e]);
+          for (int ci = 0; ci < CIN; ++ci) {
+            const f32x2_t xv = {xp[ci], xp[ci]};
+            const f32x4 w4 = WREG ? wr[WREG ? tap : 0]
+                                  : *reinterpret_cast<const f32x4*>(&ws[WREG ? 0 : (tap * CIN + ci) * a.COUT + 4 * quad]);
+            acc_a = __builtin_elementwise_fma(xv, f32x2_t{w4[0], w4[1]}, acc_a);
+            acc_b = __builtin_elementwise_fma(xv, f32x2_t{w4[2], w4[3]}, acc_b);
+          }
+        }
+        f32x4 acc = {acc_a.x, acc_a.y, acc_b.x, acc_b.y};
+        if (a.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
+        }
+        if (BF) {  // the statistics describe the stored (rounded) tensor
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = bf_round(acc[e]);
+        }
+        const f32x2_t va = {acc[0], acc[1]}, vb = {acc[2], acc[3]};
+        s1a += va;
+        s1b += vb;
+        s2a = __builtin_elementwise_fma(va, va, s2a);
+        s2b = __builtin_elementwise_fma(vb, vb, s2b);
+        // scalar patch origin + 32-bit offset inside the patch (8 rows of the image at most: the launcher checks)
+        const unsigned o = static_cast<unsigned>((py * a.W + px) * a.yC + 4 * quad);
+#ifndef UNETPP_FIRST_NO_NT  // streaming stores: the tensor is far larger than the L2, and lines left dirty there delay the next launch (X_0,0 block 428 -> 417 us)
+        if (BF)
+          __builtin_nontemporal_store(u32x2{pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])}, reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(y_patch) + o));
+        else
+          __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(y_patch + o));
+#else
+        if (BF)
+          *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(y_patch) + o) = u32x2{pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])};
+        else
+          *reinterpret_cast<f32x4*>(y_patch + o) = acc;
+#endif
+      }
+    }
+    f32x4 s1 = {s1a.x, s1a.y, s1b.x, s1b.y}, s2 = {s2a.x, s2a.y, s2b.x, s2b.y};
+    if (a.stats != nullptr) {  // uniform
+      // lanes quad, quad + QN, ... of a wave hold the same channels: butterfly over them, then the four waves in order
+      for (int off = QN; off < 64; off <<= 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s1[e] += __shfl_xor(s1[e], off);
+          s2[e] += __shfl_xor(s2[e], off);
         }
       }
-      if (a.relu) {
+      const int lane = tid & 63, wave = tid >> 6;
+      if (lane < QN) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
+        for (int e = 0; e < 4; ++e) {
+          red[wave][lane * 8 + e] = s1[e];
+          red[wave][lane * 8 + 4 + e] = s2[e];
+        }
       }
-      if (BF) {  // the statistics describe the stored (rounded) tensor
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = bf_round(acc[e]);
+      __syncthreads();
+      if (tid < a.COUT) {
+        const int i1 = (tid >> 2) * 8 + (tid & 3);
+        float* dst = a.stats + (static_cast<long>(patch) * a.COUT + tid) * 2;
+        dst[0] = (red[0][i1] + red[1][i1]) + (red[2][i1] + red[3][i1]);
+        dst[1] = (red[0][i1 + 4] + red[1][i1 + 4]) + (red[2][i1 + 4] + red[3][i1 + 4]);
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        s1[e] += acc[e];
-        s2[e] += acc[e] * acc[e];
-      }
-      const long o = ((static_cast<long>(n) * a.H + y) * a.W + x) * a.yC + 4 * quad;
-      if (BF)
-        *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(a.y) + o) = u32x2{pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])};
-      else
-        *reinterpret_cast<f32x4*>(a.y + o) = acc;
-    }
-  }
-  if (a.stats != nullptr) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      red[tid][e] = s1[e];
-      red[tid][4 + e] = s2[e];
-    }
-    __syncthreads();
-    for (int c = tid; c < a.COUT; c += kThreads) {
-      const int q = c >> 2, e = c & 3;
-      float t1 = 0.f, t2 = 0.f;
-      for (int t = q; t < kThreads; t += QN) {  // fixed order
-        t1 += red[t][e];
-        t2 += red[t][4 + e];
-      }
-      float* dst = a.stats + (static_cast<long>(blockIdx.x) * a.COUT + c) * 2;
-      dst[0] = t1;
-      dst[1] = t2;
     }
   }
 }
@@ -224,6 +298,7 @@ int launch_small_cin_fwd(const unetpp_gemm_desc* d, hipStream_t st) {
   SmallArgs a = {};
   fill_geom(a, d->N, d->H, d->W);
   if (a.n_patches > 0x7fffffffL) return 1;
+  if ((16L * d->W + 64) * Y.C * 4 > 0x7fffffffL) return 1;  // 32-bit offsets inside a patch (at most 16 rows)
   const bool bf = (d->flags & UNETPP_GEMM_BF16) != 0;
   if (d->weight == nullptr) return 1;
   a.x = X.ptr;
@@ -234,7 +309,14 @@ int launch_small_cin_fwd(const unetpp_gemm_desc* d, hipStream_t st) {
   a.COUT = Y.c_len;
   a.yC = Y.C;
   a.relu = Y.relu;
-  const dim3 grid(static_cast<unsigned>(a.n_patches)), block(kThreads);
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return UNETPP_ELAUNCH;
+  // persistent grid: as many workgroups as are resident at once (<= 128 registers up to three input channels, 156
+  // with four: four / three one-wave-per-SIMD workgroups per CU)
+  const long workers = static_cast<long>(cus) * (X.C == 4 ? 3 : 4);
+  const dim3 grid(static_cast<unsigned>(a.n_patches < workers ? a.n_patches : workers)), block(kThreads);
 #define UNETPP_SMALL_FWD(B)                                                                          \
   switch (X.C) {                                                                                     \
     case 1: hipLaunchKernelGGL((small_cin_fwd_kernel<1, B>), grid, block, 0, st, a); break;          \

@@ -24,11 +24,15 @@ def _stream():
 class LaunchTimer:
     """Optional per-launch timing with HIP events on the launching stream (used by bench.py for the
     roofline line).  Records (kind, flops, bytes, start_event, end_event) for every MFMA-kernel launch
-    and (name, start, end) for named regions; read the times after a device synchronise."""
+    and (name, start, end) for named regions; read the times after a device synchronise.  An event pair costs the
+    stream about 6 us, so a caller that wants honest region times samples launches and regions on DIFFERENT steps
+    (want_launches / want_regions)."""
 
     def __init__(self):
         self.launches = []
         self.regions = []
+        self.want_launches = True
+        self.want_regions = True
 
     def _pair(self):
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -64,13 +68,14 @@ class region:
         self.name = name
 
     def __enter__(self):
-        if _TIMER is not None:
+        self.on = _TIMER is not None and _TIMER.want_regions
+        if self.on:
             self.s, self.e = _TIMER._pair()
             self.s.record()
         return self
 
     def __exit__(self, *exc):
-        if _TIMER is not None:
+        if self.on and _TIMER is not None:
             self.e.record()
             _TIMER.regions.append((self.name, self.s, self.e))
         return False
@@ -79,7 +84,7 @@ class region:
 def _timed_call(kind, flops, fn, nbytes=0.0):
     """kind = label of the launch, or None to ask the library which kernel it picked (unetpp_last_kernel_name).
     flops / nbytes: ALGORITHMIC work of the launch (every operand element read or written once)."""
-    if _TIMER is None:
+    if _TIMER is None or not _TIMER.want_launches:
         return fn()
     s, e = _TIMER._pair()
     s.record()
