@@ -331,7 +331,8 @@ def main():
                     "traffic_over_algorithmic": None if traffic is None else round(traffic / traffic_alg, 3),
                     "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes "
                                     "of this command; profiles/pmc_hbm_traffic_latest.json, null when that file is "
-                                    "from another build); traffic_algorithmic = 4 B x (Cin + Cout) x pixels",
+                                    "from another build); traffic_algorithmic = 4 B x (Cin + Cout) x pixels, plus the accumulated outputs and ReLU "
+                                    "gates an input-gradient launch has to read",
                     "launches_per_step": dom[1]["launches"] / sampled_steps,
                     "timed_steps_with_launch_events": sampled_steps,
                     "avg_launch_ms": round(dom[1]["ms"] / dom[1]["launches"], 4),

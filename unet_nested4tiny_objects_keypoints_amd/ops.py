@@ -356,7 +356,8 @@ def gemm_fwd(n: int, h: int, w: int, taps: int, ins: Sequence[V], outs: Sequence
     if d.weight_image is None and from_src:  # generic kernel: it reads the packed operand
         packed = weight.packed()
         d.weight = packed.data_ptr()
-    acc = sum(v.c_len for v in d.out[:d.n_out] if v.accumulate)  # accumulated outputs are read as well
+    # operands the launch has to read besides its inputs: accumulated outputs and ReLU gates of the output views
+    acc = sum(v.c_len for v in d.out[:d.n_out] if v.accumulate) + sum(v.c_len for v in d.out[:d.n_out] if v.gate)
     _timed_call(None, 2.0 * n * h * w * taps * k * nc,
                 lambda: check(_lib.lib().unetpp_gemm_fwd(C.byref(d), _stream()), "unetpp_gemm_fwd"),
                 (2.0 if d.flags & _lib.GEMM_BF16 else 4.0) * n * h * w * (k + nc + acc))
