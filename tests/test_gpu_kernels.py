@@ -51,6 +51,9 @@ def conv_algo(request):
     (2, 32, 64, [1], 32),         # first-layer VALU kernel (1 -> 32 channels)
     (1, 24, 40, [3], 8),          # first-layer VALU kernel, rgb, ragged patches
     (1, 16, 16, [4], 64),
+    (5, 256, 256, [1], 32),       # first layer, more patches than persistent workgroups: prefetch + both LDS buffers
+    (5, 250, 250, [3], 16),       # the same with ragged border patches, three input channels
+    (5, 256, 256, [4], 64),       # four input channels (three workgroups per CU), sixteen channel quads
 ])
 def test_conv3x3_fwd_multiview(dev, shape, conv_algo):
     from unet_nested4tiny_objects_keypoints_amd import engine, ops
