@@ -185,8 +185,8 @@ def test_first_layer_bf16(dev):
     from unet_nested4tiny_objects_keypoints_amd import engine, ops
     from unet_nested4tiny_objects_keypoints_amd.ops import V
     g = torch.Generator().manual_seed(6)
-    for cin in (1, 3):
-        b, h, w, co = 2, 24, 40, 32
+    for cin, (b, h, w, co) in ((1, (2, 24, 40, 32)), (3, (2, 24, 40, 32)), (1, (5, 256, 256, 32))):
+        # the last shape has more patches (1280) than persistent workgroups: prefetched patches, both LDS buffers
         x = torch.randn(b, cin, h, w, generator=g)
         wt = torch.randn(co, cin, 3, 3, generator=g) * 0.3
         bias = torch.randn(co, generator=g) * 0.1
