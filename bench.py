@@ -64,6 +64,10 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps (BASELINE.md section 4: >= 3)")
     ap.add_argument("--prewarm", type=int, default=10, help="untimed steps before the W warm-up steps (see main)")
     ap.add_argument("--no-launch-timing", action="store_true", help="skip per-launch HIP events (roofline = null)")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="multi-process plumbing only, on the CPU over gloo, with synthetic gradients and NO kernels: "
+                         "self-spawn, rendezvous, broadcast, bucketed all-reduce, optimizer, max-over-ranks timing, "
+                         "replica check (tests/test_dp_gloo.py); the line it prints is labelled a rehearsal")
     return ap.parse_args()
 
 
@@ -181,10 +185,79 @@ def spawn_ranks(args):
         raise SystemExit(1)
 
 
+def replicas_bit_identical(model, dist):
+    """every rank must hold bit-identical parameters after the run (DataParallel keeps ONE copy): MAX == MIN over ranks
+    of the parameter bits"""
+    import torch
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).view(torch.int32)
+    hi, lo = flat.clone(), flat.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return bool(torch.equal(hi, lo))
+
+
+def rehearse_cpu(args):
+    """`--rehearse-cpu`: the N-rank protocol of this benchmark without a GPU and without a single kernel -- every rank
+    plays the engine's role with per-rank pseudo-gradients written into the averager's flat buffer node by node (the
+    order and granularity of engine.backward_impl), then steps Adam.  What it proves: N processes rendezvous, start
+    identical, exchange exactly the buckets the real run would, stay bit-identical, and rank 0's line reaches stdout."""
+    import torch
+    import torch.distributed as dist
+
+    from unet_nested4tiny_objects_keypoints_amd import UNet_Nested, dp
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fs = int(args.feature_scale) if float(args.feature_scale).is_integer() else args.feature_scale
+    torch.manual_seed(rank)  # ranks start different: the broadcast has to fix that
+    model = UNet_Nested(in_channels=args.in_channels, n_classes=args.n_classes, feature_scale=fs, depth=args.depth)
+    averager = dp.make_data_parallel(model)
+    groups = dp.ready_groups(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    gen = torch.Generator().manual_seed(1000 + rank)
+
+    def step():
+        opt.zero_grad()
+        for grp in groups:  # the engine reports a convolution's (and its BatchNorm's) gradients together
+            fresh = []
+            for p in grp:
+                slot = model._grad_alloc(p)
+                slot.copy_(torch.randn(p.shape, generator=gen))
+                fresh.append((p, slot))
+            model._grad_sink(fresh)
+        assert model._grad_done() is True
+        opt.step()
+
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    same = replicas_bit_identical(model, dist)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "REHEARSAL of the multi-process protocol (no kernels, CPU, gloo) -- not a measurement",
+            "value": None, "unit": None, "n_gpus": 0, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * float(t.item()) / max(1, args.steps), 3), "data": "synthetic gradients",
+            "config": {"world_size": world, "backend": dist.get_backend(), "gradient_bytes": 4 * averager.flat.numel(),
+                       "bucket_bytes": averager.bucket_bytes, "grad_allreduce_buckets": len(averager.buckets_last_step),
+                       "replicas_bit_identical": same}}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args)
+    if args.rehearse_cpu:
+        return rehearse_cpu(args)
     import torch
     import torch.distributed as dist
 
@@ -276,13 +349,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    replicas_identical = None
-    if distributed:  # every rank must hold bit-identical parameters after the run (DataParallel keeps ONE copy)
-        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).view(torch.int32)
-        hi, lo = flat.clone(), flat.clone()
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        replicas_identical = bool(torch.equal(hi, lo))
+    replicas_identical = replicas_bit_identical(model, dist) if distributed else None
 
     # eval-mode forward latency (the reference's "high-speed inference" claim; BASELINE metric part 2)
     model.eval()
@@ -392,6 +459,8 @@ def main():
                    "world_size": dist.get_world_size() if distributed else 1,
                    "backend": dist.get_backend() if distributed else None,
                    "grad_allreduce_buckets": None if averager is None else len(averager.buckets_last_step),
+                   "grad_bucket_bytes": None if averager is None else averager.bucket_bytes,
+                   "gradient_bytes": None if averager is None else 4 * averager.flat.numel(),
                    "replicas_bit_identical": replicas_identical},
         "fwd_ms_per_img": round(fwd_ms_per_img, 4),
         "roofline": roofline,

@@ -136,3 +136,86 @@ def test_ready_order_covers_every_parameter_once(kw):
     last = names[id(order[-1])]
     assert first.startswith("final_%d" % (m.depth - 1))       # heads finish first ...
     assert last.startswith("conv00.conv1")                    # ... the first encoder conv last
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.py's own multi-process protocol with more than two ranks (the first 8-GPU run must not be the
+# first N > 2 run): `python bench.py --gpus 4 --rehearse-cpu` spawns its four ranks itself -- rendezvous on 127.0.0.1,
+# broadcast, bucketed all-reduce in the engine's ready order, Adam, max-over-ranks timing, replicas_bit_identical,
+# rank 0's JSON line relayed by the parent.  No kernels run (there is no GPU here); the line says so.
+def _run_bench(*extra, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rehearse-cpu", "--steps", "3", "--warmup", "1",
+                        *extra], capture_output=True, text=True, timeout=600, env=e)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
+
+
+@pytest.mark.parametrize("world,extra,grad_bytes", [
+    (4, ["--feature-scale", "1"], 8828976),                                                     # configs[2]'s network
+    (3, ["--feature-scale", "4", "--depth", "5", "--in-channels", "3", "--n-classes", "5"], None),  # odd world, depth 5
+])
+def test_bench_self_spawn_and_replica_check(world, extra, grad_bytes):
+    code, line, err = _run_bench("--gpus", str(world), *extra)
+    assert code == 0, err
+    cfg = line["config"]
+    assert cfg["world_size"] == world and cfg["backend"] == "gloo"
+    assert cfg["replicas_bit_identical"] is True
+    assert line["value"] is None and "REHEARSAL" in line["metric"]      # cannot be mistaken for a measurement
+    if grad_bytes is not None:
+        assert cfg["gradient_bytes"] == grad_bytes                        # 2 207 244 parameters x 4 B
+        assert 6 <= cfg["grad_allreduce_buckets"] <= 16, cfg              # auto bucket size: about a dozen per step
+
+
+def test_bench_self_spawn_reports_a_failing_rank():
+    """a rank that dies must turn into a non-zero exit of the parent, not into a hang or a silent success"""
+    code, line, err = _run_bench("--gpus", "2", "--depth", "9")          # the model constructor refuses depth 9 on every rank
+    assert code != 0 and line is None
+    assert "rank exit codes" in err
+
+
+def test_auto_bucket_bytes_targets_a_dozen_buckets():
+    assert dp.auto_bucket_bytes(8828976) == -(-8828976 // 12)                 # configs[1]/[2]: 8.8 MB -> 0.74 MB
+    assert 11 << 20 < dp.auto_bucket_bytes(36167124 * 4) < 13 << 20           # configs[4]: 145 MB -> 12 MB
+    assert dp.auto_bucket_bytes(1000) == 256 << 10 and dp.auto_bucket_bytes(1 << 40) == 64 << 20
+
+
+def test_frozen_parameters_get_no_gradient_and_hooks_are_refused():
+    """delivery must leave p.grad None for requires_grad=False parameters (an optimizer built over
+    model.parameters() would otherwise update them) and must not silently skip registered tensor hooks."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        model = UNet_Nested(**CTOR)
+        frozen = [model.final_1.weight, model.conv00.conv1[0].weight] if hasattr(model.conv00.conv1, "__getitem__") else \
+            [model.final_1.weight, getattr(model.conv00.conv1, "0").weight]
+        for p in frozen:
+            p.requires_grad_(False)
+        dp.make_data_parallel(model)
+        order = dp.ready_order(model)
+
+        def backward():
+            for p in order:
+                model._grad_alloc(p).fill_(1.0)
+                model._grad_sink([(p, None)])
+            model._grad_done()
+
+        backward()
+        assert all(p.grad is None for p in frozen)
+        assert all(p.grad is not None and float(p.grad.min()) == 1.0 for p in order if p.requires_grad)
+        backward()   # accumulation with frozen parameters present
+        assert all(p.grad is None for p in frozen)
+        assert all(float(p.grad.min()) == 2.0 for p in order if p.requires_grad)
+        order[5].register_hook(lambda g: g)
+        with pytest.raises(RuntimeError, match="hook"):
+            backward()
+    finally:
+        dist.destroy_process_group()

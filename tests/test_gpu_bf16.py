@@ -389,7 +389,11 @@ def _bf16_vs_oracle(dev, ctor, b, h, w, seed, probe=False):
     (dict(in_channels=1, n_classes=4, feature_scale=1), 2, 64, 64),               # configs[3] widths (base 32)
     (dict(in_channels=3, n_classes=5, feature_scale=0.5, depth=5), 1, 64, 64),    # configs[4] topology and widths
     (dict(in_channels=1, n_classes=4, feature_scale=4), 4, 64, 64),               # base 8: partial tiles everywhere
-], ids=["base32", "d5-base64-rgb5", "base8"])
+    # BASELINE configs[3] / configs[4] at their REAL geometry (batch 1): > 10^4 units per launch, the slab split of the
+    # bf16 weight gradient and the swapped-operand epilogue at scale, 2.6e5 / 1.5e5 values per BatchNorm channel
+    (dict(in_channels=1, n_classes=4, feature_scale=1), 1, 512, 512),
+    (dict(in_channels=3, n_classes=5, feature_scale=0.5, depth=5), 1, 384, 384),
+], ids=["base32", "d5-base64-rgb5", "base8", "configs3-512x512", "configs4-d5-base64-384x384"])
 def test_bf16_train_step_vs_oracles(dev, ctor, b, h, w):
     """The separately stated bf16 tolerance (north_star's 1e-4 is the fp32 bar).
 
@@ -450,6 +454,32 @@ def test_bf16_training_tracks_fp32(dev):
     with torch.no_grad():
         e1, e2 = bmod(x), bmod(x)
     assert all(torch.equal(p, q) for p, q in zip(e1, e2))
+
+
+def test_bf16_long_trajectory_tracks_fp32_at_base32(dev):
+    """The end-to-end bound on what bf16 storage does to TRAINING (the per-parameter gradient gap to the fp32 oracle is
+    recorded, not bounded: see test_bf16_train_step_vs_oracles): forty SGD steps at configs[3]'s widths (base 32) on
+    128 x 128 images from the same state on the same data, bf16 storage against the fp32 HIP path -- the loss stays
+    within 2 % of the fp32 curve at EVERY step and both fall by more than a quarter."""
+    import copy
+
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, UNet_Nested, train_step
+    torch.manual_seed(67)
+    a = UNet_Nested(in_channels=1, n_classes=4, feature_scale=1).to(dev).train()
+    a.drop_out.p = 0.0
+    bmod = copy.deepcopy(a).set_activation_dtype(BF)
+    x = torch.randn(4, 1, 128, 128, device=dev)
+    t = torch.rand(4, 4, 128, 128, device=dev)
+    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+    oa, ob = torch.optim.SGD(a.parameters(), lr=5e-4, momentum=0.9), torch.optim.SGD(bmod.parameters(), lr=5e-4, momentum=0.9)
+    la, lb = [], []
+    for _ in range(40):
+        la.append(float(train_step(a, oa, crit, x, t)[1]))
+        lb.append(float(train_step(bmod, ob, crit, x, t)[1]))
+    print("bf16 vs fp32 trajectory (base 32, 128x128, 40 steps): fp32", ["%.4f" % v for v in la], "bf16", ["%.4f" % v for v in lb])
+    worst = max(abs(p - q) / abs(p) for p, q in zip(la, lb))
+    assert worst <= 0.02, (worst, la, lb)
+    assert la[-1] < 0.75 * la[0] and lb[-1] < 0.75 * lb[0], (la, lb)
 
 
 def test_bf16_unsupported_configurations_raise(dev):

@@ -102,32 +102,60 @@ def test_golden_train_step(dev, name):
 
 @pytest.mark.parametrize("opt_name", ["adam", "sgd"])
 def test_golden_optimizer_step(dev, opt_name):
-    """the reference's step body (trainer/trainer.py:114-136) end to end: parameters after one update."""
+    """the reference's step body (trainer/trainer.py:114-136) end to end: parameters after one update.
+
+    STRICT when no ReLU gate / pool winner of the HIP forward differs from the oracle's (true for every golden case,
+    profiles/r2/relu_gate_flips.jsonl): the SGD update lr * grad within 1e-4 of the reference's; Adam's first update
+    is lr * g / (|g| + eps), i.e. +-lr wherever the gradient is resolved, so every element whose reference gradient is
+    larger than the gradient tolerance itself (2e-4 of the tensor's largest) must match to fp32 rounding of the
+    parameter, and the unresolved rest may at most land on the other sign (2 * lr)."""
+    from oracle.unet_nested_oracle import UNetNestedOracle
+    from tests.helpers import check_flips, install_hip_gates
     from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, train_step
     z, ctor = load_golden("c1_fs4_64x64_b4_seed0")
     m = _hip_model(ctor, sub(z, "state0"), dev).train()
     m.drop_out.eval()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3) if opt_name == "adam" else \
-        torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
+    m._debug_keep_saved = True
+    lr = 1e-3 if opt_name == "adam" else 0.01
+    opt = torch.optim.Adam(m.parameters(), lr=lr) if opt_name == "adam" else \
+        torch.optim.SGD(m.parameters(), lr=lr, momentum=0.9)
     train_step(m, opt, FocalLoss_BCE_2d(gamma=3, size_average=False),
                torch.from_numpy(z["x"]).to(dev), torch.from_numpy(z["target"]).to(dev))
-    after, before = sub(z, "after_" + opt_name), sub(z, "state0")
-    # Strict gradient parity is test_golden_train_step's job (gate-aware).  Here the update itself is
-    # compared, tolerant to the ReLU gate flips described in tests/helpers.py: SGD's update is lr*grad
-    # (L2-relative bound); Adam's first update is ~lr*sign(grad), so a near-zero gradient element may land
-    # on the other side by 2*lr -- bound the FRACTION of such elements instead of the maximum.
-    n_off, n_all = 0, 0
+    ref = UNetNestedOracle(**ctor)
+    ref.load_state_dict(sub(z, "state0"))
+    ref.train().drop_out.eval()
+    gated = install_hip_gates(ref, m._debug_saved)
+    with torch.no_grad():
+        ref(torch.from_numpy(z["x"]))
+    flips = check_flips(gated, "golden-optimizer:" + opt_name)
+    after, before, grads = sub(z, "after_" + opt_name), sub(z, "state0"), sub(z, "grad")
+    n_off, n_all, n_unresolved = 0, 0, 0
     for k, p in m.named_parameters():
         if is_pre_bn_bias(k, ctor):
             continue  # analytically zero gradient: pure rounding noise on both sides
         got_u = p.detach().cpu().double() - before[k].double()
         want_u = after[k].double() - before[k].double()
-        if opt_name == "sgd":
+        if flips == 0 and opt_name == "sgd":
+            assert rel_err(got_u, want_u) < TOL, (k, rel_err(got_u, want_u))
+        elif flips == 0:
+            g = grads[k].double().abs()
+            resolved = g > 2 * TOL * float(g.max())
+            err = (got_u - want_u).abs()
+            delta = TOL * float(g.max())                            # what the gradient itself may be off by
+            bound = TOL * lr + 2.4e-7 * before[k].double().abs()    # 1e-4 of the step + 2 ulp of the fp32 parameter
+            bound = bound + lr * 1e-8 * delta / ((g - delta).clamp_min(delta) + 1e-8) ** 2   # d u / d g = lr eps / (|g| + eps)^2
+            assert bool((err[resolved] <= bound[resolved]).all()), (k, float((err - bound)[resolved].max()))
+            assert float(err.max()) <= 2.001 * lr, (k, float(err.max()))
+            n_unresolved += int((~resolved).sum())
+            n_all += g.numel()
+        elif opt_name == "sgd":   # with flips (not observed on the golden cases) only a loose bound is meaningful
             assert float((got_u - want_u).norm() / want_u.norm()) < 0.1, k
         else:
             n_off += int(((got_u - want_u).abs() > 1e-5).sum())
             n_all += got_u.numel()
-    assert opt_name == "sgd" or n_off / n_all < 0.02, (n_off, n_all)
+    assert flips == 0, "golden cases are expected to run the strict branch"
+    assert n_unresolved <= 0.02 * max(1, n_all), (n_unresolved, n_all)
+    assert n_off <= 0.02 * max(1, n_all), (n_off, n_all)
 
 
 ORACLE_CASES = [
@@ -537,3 +565,29 @@ def test_graphed_eval_forward_matches_eager_and_tracks_parameters(dev):
     with pytest.raises(RuntimeError):
         g(x0)
     m.eval()
+
+
+def test_graphed_forward_survives_plan_churn(dev):
+    """the captured graph holds raw pointers into the model's weight-image plan.  Eager passes with another
+    activation type (new signatures -> a new job table) and more passes than the plan's eviction horizon must neither
+    free nor recycle what the graph reads: the replay still equals a fresh eager forward bit for bit."""
+    from unet_nested4tiny_objects_keypoints_amd import GraphedForward, UNet_Nested
+    torch.manual_seed(6)
+    m = UNet_Nested(in_channels=1, n_classes=4, feature_scale=4).to(dev).eval()
+    x0 = torch.randn(1, 1, 64, 64, device=dev)
+    g = GraphedForward(m, x0)
+    plan = m.__dict__["_pack_plan"]
+    assert plan.pinned == 1
+    with torch.no_grad():
+        want = [o.clone() for o in m(x0)]
+        m.set_activation_dtype(torch.bfloat16)
+        for _ in range(20):                       # other signatures, beyond the 16-pass eviction horizon
+            m(x0)
+        junk = [torch.randn(1 << 20, device=dev) for _ in range(8)]   # recycle whatever the allocator got back
+        m.set_activation_dtype(torch.float32)
+    got = g(x0)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    del junk, g
+    import gc
+    gc.collect()
+    assert plan.pinned == 0

@@ -24,3 +24,27 @@ def test_inline_asm_valu_writes_keep_clear_of_mfma_c_operands(tmp_path, src):
            *_lib.EXTRA_FLAGS.get(src, ()), "--offload-device-only", "-S", os.path.join(_lib.CSRC, src), "-o", out]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     assert check_asm_mfma_hazard.main(out, "_kernel") == 0
+
+
+def test_checker_sees_a_hazard_across_a_loop_back_edge(tmp_path):
+    """The checker's own known-answer test: an inline-asm packed add at the TOP of a loop that overwrites the C operand
+    of the MFMA at the BOTTOM of the previous iteration is only visible when the back edge is followed; an s_waitcnt
+    between them does not hide it (it may issue in one cycle); eight wait states of s_nop do."""
+    import check_asm_mfma_hazard
+    body = """_Z6kernelv:                            ; @_Z6kernelv
+.LBB0_1:                                ; =>This Inner Loop Header: Depth=1
+	;;#ASMSTART
+	v_pk_add_f32 v[10:11], v[2:3], v[4:5]
+	;;#ASMEND
+	%s
+	s_waitcnt lgkmcnt(0)
+	v_mfma_f32_16x16x4_f32 v[20:23], v0, v1, v[8:11]
+	s_cbranch_scc1 .LBB0_1
+	s_endpgm
+.Lfunc_end0:
+"""
+    bad, good = tmp_path / "bad.s", tmp_path / "good.s"
+    bad.write_text(body % "s_nop 0")
+    good.write_text((body % "s_nop 0").replace("\ts_cbranch_scc1", "\ts_nop 7\n\ts_cbranch_scc1"))
+    assert check_asm_mfma_hazard.main(str(bad), "kernel") == 1
+    assert check_asm_mfma_hazard.main(str(good), "kernel") == 0

@@ -122,6 +122,40 @@ def test_extraction_hip_equals_oracle(dev, seed, h, w):
 
 
 @pytest.mark.gpu
+def test_extraction_has_no_region_limit(dev):
+    """A speckled map (what an untrained network's sigmoid outputs look like after thresholding) has far more regions
+    than the ranking buffer holds (max_regions = 4096).  The reference's extract_points_ has no such limit
+    (heatmap.py:148-200): the top `num` regions must still come out exactly, in order -- the selection then runs over
+    all roots.  Also: the blob maps with a ranking buffer of only `num` entries (every map takes the uncapped path)."""
+    from scipy import ndimage
+
+    from oracle.keypoints_oracle import region_mask
+    from unet_nested4tiny_objects_keypoints_amd import ops
+    rng = np.random.default_rng(9)
+    h, w, num, thr = 512, 512, 7, 0.7
+    heat = rng.uniform(0, 1, (2, h, w)).astype(np.float32)
+    points, counts = ops.keypoints_extract(torch.from_numpy(heat).to(dev), num, thr)
+    points, counts = points.cpu().numpy(), counts.cpu().numpy()
+    for m in range(2):
+        labels, count = ndimage.label(region_mask(heat[m], thr), structure=np.ones((3, 3), dtype=int))
+        assert count > 4096, count   # the case this test is about
+        assert int(counts[m]) == count
+        hz = np.where(heat[m] < thr, 0, heat[m])
+        peaks = ndimage.maximum(hz, labels, index=np.arange(1, count + 1))
+        order = sorted(range(count), key=lambda k: (-float(peaks[k]), k))[:num]
+        for rank, k in enumerate(order):
+            ys, xs = np.where((labels == k + 1) & (hz == peaks[k]))
+            want = [0, 0] if peaks[k] == 0 else [int(xs[0]), int(ys[0])]
+            assert [int(points[m, rank, 0]), int(points[m, rank, 1])] == want, (m, rank)
+    maps = _random_blob_maps(5, 2, 3, 64, 64)
+    flat = torch.from_numpy(maps.reshape(-1, 64, 64)).to(dev)
+    a_pts, a_cnt = ops.keypoints_extract(flat, 2, 0.5)
+    b_pts, b_cnt = ops.keypoints_extract(flat, 2, 0.5, max_regions=2)
+    assert int(a_cnt.max()) > 2
+    assert torch.equal(a_pts, b_pts) and torch.equal(a_cnt, b_cnt)
+
+
+@pytest.mark.gpu
 def test_heads_to_points_end_to_end(dev):
     """eval forward of the HIP network -> its three head outputs -> key points, all on the device (the reference moves
     every output to the CPU and runs OpenCV per map, trainer/trainer.py:213-221)"""

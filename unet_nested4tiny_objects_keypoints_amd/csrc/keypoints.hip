@@ -150,12 +150,28 @@ __global__ __launch_bounds__(kKpThreads) void kp_peak_kernel(const float* __rest
   atomicMax(&best[static_cast<long>(blockIdx.y) * hw + l], key);
 }
 
-// one workgroup per map: gather the roots, rank them by (peak descending, root index ascending), write the first `num`
+__device__ __forceinline__ void kp_write_point(float* out, int rank, unsigned long long best_key, int W) {
+  // (a region whose thresholded values are all zero: the reference's np.where(map == 0) then finds the first zero
+  // of the WHOLE map, pixel 0 -- heatmap.py:168-170)
+  const unsigned peak = static_cast<unsigned>(best_key >> 32);
+  const unsigned idx = peak == 0u ? 0u : 0xFFFFFFFFu - static_cast<unsigned>(best_key & 0xFFFFFFFFull);
+  out[2 * rank] = static_cast<float>(idx % static_cast<unsigned>(W));      // x
+  out[2 * rank + 1] = static_cast<float>(idx / static_cast<unsigned>(W));  // y
+}
+
+// one workgroup per map: rank the roots by (peak descending, root index ascending), write the first `num`.
+// Up to max_regions roots are gathered into `cand` and ranked against each other; a map with MORE regions (a speckled
+// map of an untrained net can have tens of thousands) takes the exact selection over all roots instead: `num` rounds
+// of a workgroup-wide arg-max of the 64-bit key (peak bits, ~root) below the key selected in the round before --
+// the same order, no cap, no dependence on the order the atomics arrived in (the reference's extract_points_ has no
+// region limit either, heatmap.py:148-200).
 __global__ __launch_bounds__(1024) void kp_select_kernel(int H, int W, const int* __restrict__ label,
                                                          const unsigned long long* __restrict__ best, int num,
                                                          int max_regions, unsigned long long* __restrict__ cand,
                                                          float* __restrict__ points, int* __restrict__ counts) {
   __shared__ int n_cand;
+  __shared__ unsigned long long red[1024 / 64];
+  __shared__ unsigned long long chosen;
   const long hw = static_cast<long>(H) * W;
   const int* lab = label + static_cast<long>(blockIdx.x) * hw;
   const unsigned long long* bst = best + static_cast<long>(blockIdx.x) * hw;
@@ -173,27 +189,49 @@ __global__ __launch_bounds__(1024) void kp_select_kernel(int H, int W, const int
   }
   __syncthreads();
   const int total = n_cand;
-  const int n = min(total, max_regions);
   float* out = points + static_cast<long>(blockIdx.x) * num * 2;
   for (int k = threadIdx.x; k < num * 2; k += blockDim.x) out[k] = -1.f;
   __syncthreads();
-  for (int c = threadIdx.x; c < n; c += blockDim.x) {
-    const unsigned peak = static_cast<unsigned>(cd[2 * c] >> 32);
-    const unsigned long long root = cd[2 * c + 1];
-    int rank = 0;
-    for (int o = 0; o < n; ++o) {
-      const unsigned po = static_cast<unsigned>(cd[2 * o] >> 32);
-      if (po > peak || (po == peak && cd[2 * o + 1] < root)) ++rank;
+  if (threadIdx.x == 0) counts[blockIdx.x] = total;  // regions found
+  if (total <= max_regions) {
+    for (int c = threadIdx.x; c < total; c += blockDim.x) {
+      const unsigned peak = static_cast<unsigned>(cd[2 * c] >> 32);
+      const unsigned long long root = cd[2 * c + 1];
+      int rank = 0;
+      for (int o = 0; o < total; ++o) {
+        const unsigned po = static_cast<unsigned>(cd[2 * o] >> 32);
+        if (po > peak || (po == peak && cd[2 * o + 1] < root)) ++rank;
+      }
+      if (rank < num) kp_write_point(out, rank, cd[2 * c], W);
     }
-    if (rank < num) {
-      // (a region whose thresholded values are all zero: the reference's np.where(map == 0) then finds the first zero
-      // of the WHOLE map, pixel 0 -- heatmap.py:168-170)
-      const unsigned idx = peak == 0u ? 0u : 0xFFFFFFFFu - static_cast<unsigned>(cd[2 * c] & 0xFFFFFFFFull);
-      out[2 * rank] = static_cast<float>(idx % static_cast<unsigned>(W));      // x
-      out[2 * rank + 1] = static_cast<float>(idx / static_cast<unsigned>(W));  // y
-    }
+    return;
   }
-  if (threadIdx.x == 0) counts[blockIdx.x] = total;  // regions found (may exceed max_regions: the caller checks)
+  // more roots than the candidate buffer holds: exact top-`num` over ALL roots (uniform branch: `total` is shared)
+  unsigned long long below = ~0ull;  // keys are < 2^64 - 1: a root index is < 2^31
+  for (int r = 0; r < num; ++r) {
+    unsigned long long mine = 0ull;  // 0 = nothing (a real key has non-zero low half: ~root with root < 2^31)
+    for (long i = threadIdx.x; i < hw; i += blockDim.x) {
+      if (lab[i] != static_cast<int>(i)) continue;
+      const unsigned long long key = (bst[i] & 0xFFFFFFFF00000000ull) | (0xFFFFFFFFull - static_cast<unsigned long long>(i));
+      if (key < below && key > mine) mine = key;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned long long o = __shfl_xor(mine, off);
+      mine = o > mine ? o : mine;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long m = 0ull;
+      for (int k = 0; k < 1024 / 64; ++k) m = red[k] > m ? red[k] : m;
+      chosen = m;
+      if (m != 0ull) kp_write_point(out, r, bst[0xFFFFFFFFull - (m & 0xFFFFFFFFull)], W);
+    }
+    __syncthreads();
+    below = chosen;
+    if (below == 0ull) break;  // fewer than num regions (cannot happen on this branch; keeps the loop bounded)
+  }
 }
 
 }  // namespace

@@ -22,6 +22,8 @@
 // (An LDS-DMA ring of three buffers was tried for plain views: same speed, the DMA instructions issue slowly.)
 // Fixed-order tree sum of the 4 waves; one slab per workgroup in the format of wgrad.hip ([taps*K + 1][Ncols] fp32,
 // last row = db).
+#include <atomic>
+
 #include "bf16_common.h"
 #include "common.h"
 #include "lds_asm.h"
@@ -348,14 +350,18 @@ int launch_one(const WBfArgs& a, dim3 grid, hipStream_t st) {
   constexpr int TREE = 2 * TAPS * 4096;
   constexpr size_t lds = ((2 * BUF > TREE) ? 2 * BUF : TREE) + 256;
   static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");
-  // > 64 KB of dynamic LDS needs the per-function opt-in: once per process and kernel (the call costs tens of
-  // microseconds of host time, more than a short launch runs on the device)
-  static bool opted_in = false;
-  if (!opted_in) {
+  // > 64 KB of dynamic LDS needs the per-function opt-in; the attribute is PER DEVICE, so it is remembered per device
+  // (bit mask, atomically updated: host threads may launch concurrently) -- the call costs tens of microseconds of
+  // host time, more than a short launch runs on the device, hence not on every launch
+  static std::atomic<unsigned long long> opted_in[4] = {};  // devices 0..255
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device > 255) return UNETPP_ELAUNCH;
+  const unsigned long long bit = 1ull << (device & 63);
+  if (!(opted_in[device >> 6].load(std::memory_order_acquire) & bit)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_kernel<TAPS, LOG2TW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
       return UNETPP_ELAUNCH;
-    opted_in = true;
+    opted_in[device >> 6].fetch_or(bit, std::memory_order_release);
   }
   hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS, LOG2TW>), grid, dim3(kWThreads), lds, st, a);
   note_kernel(TAPS == 9 ? "wgrad_bf16_kernel<9>" : "wgrad_bf16_kernel<1>");

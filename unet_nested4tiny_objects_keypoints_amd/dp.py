@@ -17,52 +17,81 @@ and the only exchange per step is the gradient average:
     live ``p.grad``), and is ADDED to when it already exists (gradient accumulation, ``zero_grad(set_to_none=False)``),
     exactly as autograd's AccumulateGrad would.  The engine returns no parameter gradients to autograd in this mode.
 
-xGMI is point-to-point (7 links x ~153 GB/s per GPU): 8.8 MB of gradients (BASELINE configs[1]/[2]) is
-latency-bound, so the default is few, large buckets (2 MiB) rather than many small ones.
+xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a ring all-reduce is bound by one link and a small one by
+latency: the default bucket size follows the gradient volume (``auto_bucket_bytes``: about a dozen buckets per step --
+0.7 MiB at the 8.8 MB of BASELINE configs[1]/[2], 12 MiB at the 145 MB of configs[4]), few enough that per-collective
+latency (tens of microseconds) stays hidden behind the backward kernels, many enough that all but the last bucket
+overlap with them.
+
+Contract of the delivered gradients: parameters with ``requires_grad=False`` get none (``p.grad`` stays None, exactly as
+autograd would leave them); a handed-out ``p.grad`` is a view into one of two alternating homes and keeps its contents
+until the backward AFTER the next one (clone it to keep it longer); tensor hooks / post-accumulate hooks on parameters
+never fire on this path (delivery does not go through AccumulateGrad), so registering them is refused, and
+``torch.autograd.grad(loss, params)`` is not supported with an attached averager (use ``loss.backward()``).
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 
-def ready_order(model) -> List[torch.nn.Parameter]:
-    """Parameters in the order engine.backward_impl finishes their gradients."""
+def ready_groups(model) -> List[List[torch.nn.Parameter]]:
+    """Parameters in the order engine.backward_impl finishes their gradients, grouped as it REPORTS them (one group per
+    engine flush: all heads, then per convolution of a node -- conv2 (+BN2) before conv1 (+BN1) -- and per up-path)."""
     d = model.depth
-    out: List[torch.nn.Parameter] = []
+    out: List[List[torch.nn.Parameter]] = []
 
     def pair(blk):
         # backward runs conv2 (+BN2) before conv1 (+BN1)
         for name in ("conv2", "conv1"):
             seq = getattr(blk, name)
+            grp = []
             if blk.is_batchnorm:
                 bn = getattr(seq, "1")
-                out.extend([bn.weight, bn.bias])
+                grp.extend([bn.weight, bn.bias])
             conv = getattr(seq, "0")
-            out.extend([conv.weight, conv.bias])
+            grp.extend([conv.weight, conv.bias])
+            out.append(grp)
 
+    heads = []
     for j in range(d - 1, 0, -1):
         head = getattr(model, "final_%d" % j)
-        out.extend([head.weight, head.bias])
+        heads.extend([head.weight, head.bias])
+    out.append(heads)
     for j in range(d - 1, 0, -1):
         for i in range(d - 1 - j, -1, -1):
             mod = getattr(model, "up_concat%d%d" % (i, j))
             pair(mod.conv)
             up = mod.up if model.is_deconv else getattr(mod.up, "1")
-            out.extend([up.weight, up.bias])
+            out.append([up.weight, up.bias])
     for i in range(d - 1, -1, -1):
         pair(getattr(model, "conv%d0" % i))
+    return out
+
+
+def ready_order(model) -> List[torch.nn.Parameter]:
+    """Parameters in the order engine.backward_impl finishes their gradients."""
+    out = [p for grp in ready_groups(model) for p in grp]
     assert len(out) == len(list(model.parameters())) and len({id(p) for p in out}) == len(out)
     return out
+
+
+TARGET_BUCKETS = 12
+
+
+def auto_bucket_bytes(total_bytes: int) -> int:
+    """Bucket size for a gradient vector of `total_bytes`: ~TARGET_BUCKETS all-reduces per step (the node-granular
+    ready order makes it 8..16 in practice), never below 256 KiB (latency-bound collectives) nor above 64 MiB."""
+    return int(min(64 << 20, max(256 << 10, -(-total_bytes // TARGET_BUCKETS))))
 
 
 class GradientAverager:
     """Flat gradient buffer + bucketed, overlapped all-reduce.  Works on any backend (nccl = RCCL on ROCm;
     gloo on CPU for tests, where the 'side stream' degenerates to in-order execution)."""
 
-    def __init__(self, params: Sequence[torch.nn.Parameter], process_group=None, bucket_bytes: int = 2 << 20,
+    def __init__(self, params: Sequence[torch.nn.Parameter], process_group=None, bucket_bytes: Optional[int] = None,
                  always_reduce: bool = False):
         self.params = list(params)
         self.always_reduce = always_reduce  # issue the collectives even in a world of one (backend smoke tests)
@@ -84,7 +113,10 @@ class GradientAverager:
         for p in self.params:
             self.offset[id(p)] = off
             off += p.numel()
-        self.bucket_elems = max(1, bucket_bytes // 4)
+        if bucket_bytes is None:
+            bucket_bytes = auto_bucket_bytes(4 * total)
+        self.bucket_bytes = int(bucket_bytes)
+        self.bucket_elems = max(1, self.bucket_bytes // 4)
         self.stream = torch.cuda.Stream(device=dev) if self.cuda else None
         self._ready_upto = 0     # elements of `flat` whose gradients are final
         self._sent_upto = 0      # elements already handed to an all-reduce
@@ -128,10 +160,18 @@ class GradientAverager:
         self._deliver()
         return True
 
+    def _check_hooks(self):
+        for p in self.params:
+            if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+                raise RuntimeError("data-parallel gradient delivery does not run tensor hooks: a parameter of the model has "
+                                   "a (post-accumulate-)grad hook registered; remove it or do the work after backward()")
+
     def _deliver(self):
-        held = [p.grad for p in self.params]
+        self._check_hooks()
+        live = [p for p in self.params if p.requires_grad]   # frozen parameters get no gradient (autograd's contract)
+        held = [p.grad for p in live]
         if all(g is None for g in held):
-            for p in self.params:
+            for p in live:
                 p.grad = self.alloc(p)
             self._cur ^= 1  # the slices are live now: the next backward works in the other home
             if self._homes[self._cur] is None:
@@ -139,11 +179,12 @@ class GradientAverager:
             self.flat = self._homes[self._cur]
             return
         other = self._homes[self._cur ^ 1]
-        if other is not None and all(g is not None and g.data_ptr() == other.data_ptr() + 4 * self.offset[id(p)]
-                                     for p, g in zip(self.params, held)):
+        if (other is not None and len(live) == len(self.params)
+                and all(g is not None and g.data_ptr() == other.data_ptr() + 4 * self.offset[id(p)]
+                        for p, g in zip(live, held))):
             other.add_(self.flat)  # every p.grad is its slice of the other home: one add for all of them
             return
-        for p, g in zip(self.params, held):
+        for p, g in zip(live, held):
             if g is None:
                 p.grad = self.alloc(p).clone()
             else:
@@ -193,7 +234,7 @@ def broadcast_parameters(model, src: int = 0, process_group=None) -> None:
         dist.broadcast(t.data, src=src, group=process_group)
 
 
-def make_data_parallel(model, process_group=None, bucket_bytes: int = 2 << 20,
+def make_data_parallel(model, process_group=None, bucket_bytes: Optional[int] = None,
                        always_reduce: bool = False) -> GradientAverager:
     """Broadcast rank 0's parameters/buffers, then hook the gradient averager into the model's backward."""
     broadcast_parameters(model, 0, process_group)

@@ -342,11 +342,14 @@ def _conv_wgrad(conv, xs, dys, b, h, w, grads):
     grads[conv.bias] = db
 
 
-def _pair_bwd(blk, r: _PairRec, d_out, in_targets: Optional[List[V]], b, grads, pre_gated=False, pool_grad=None):
+def _pair_bwd(blk, r: _PairRec, d_out, in_targets: Optional[List[V]], b, grads, pre_gated=False, pool_grad=None,
+              flush=None):
     """Backward of models/unet.py:150-156.  d_out (gradient of r.out) is consumed.  in_targets: output views
     for the gradient of every entry of r.ins (None = the inputs need no gradient).  pre_gated: the last
     contributor already multiplied d_out by (r.out > 0).  pool_grad = (d_pooled, pool_idx): gradient of the max-pooled
-    copy of r.out that has NOT been added to d_out yet (BatchNorm nodes only: routed inside BatchNorm backward)."""
+    copy of r.out that has NOT been added to d_out yet (BatchNorm nodes only: routed inside BatchNorm backward).
+    flush(): reports the parameter gradients finished so far to the data-parallel averager -- called after each
+    convolution's weight gradient, so the deepest node's 3.5 MB (configs[1]) are two buckets rather than one."""
     conv1, conv2 = getattr(blk.conv1, "0"), getattr(blk.conv2, "0")
     h, w = r.h, r.w
     if blk.is_batchnorm:
@@ -358,6 +361,8 @@ def _pair_bwd(blk, r: _PairRec, d_out, in_targets: Optional[List[V]], b, grads, 
         dy2 = V(d_out)
         mean, invstd, scale, shift = r.bn1
         _conv_wgrad(conv2, [V(r.y1, scale=scale, shift=shift, relu=True)], [dy2], b, h, w, grads)  # a1 on the fly
+        if flush is not None:
+            flush()
         d_a1 = torch.empty_like(r.y1)
         ops.gemm_fwd(b, h, w, 9, [dy2], [V(d_a1)], pack_conv_dgrad(conv2.weight.detach()))
         dg, dbt = ops.bn_backward(d_a1, r.y1, scale, shift, mean, invstd, bn1.weight.detach(), d_a1,
@@ -368,10 +373,14 @@ def _pair_bwd(blk, r: _PairRec, d_out, in_targets: Optional[List[V]], b, grads, 
         # ReLU backward: already applied by the last contributor's epilogue, else folded into the operand load
         dy2 = V(d_out) if pre_gated else V(d_out, gate=r.out)
         _conv_wgrad(conv2, [V(r.a1)], [dy2], b, h, w, grads)
+        if flush is not None:
+            flush()
         d_a1 = torch.empty_like(r.a1)
         ops.gemm_fwd(b, h, w, 9, [dy2], [V(d_a1, gate=r.a1)], pack_conv_dgrad(conv2.weight.detach()))
         dy1 = V(d_a1)
     _conv_wgrad(conv1, r.ins, [dy1], b, h, w, grads)
+    if flush is not None:
+        flush()
     if in_targets is not None:
         ops.gemm_fwd(b, h, w, 9, [dy1], in_targets, pack_conv_dgrad(conv1.weight.detach()))
 
@@ -419,7 +428,7 @@ def _backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=No
     seen = set()
 
     def flush():
-        if grad_sink is not None:
+        if grad_sink is not None and len(grads) > len(seen):
             fresh = [(p, g) for p, g in grads.items() if id(p) not in seen]
             seen.update(id(p) for p, _ in fresh)
             if fresh:
@@ -452,7 +461,7 @@ def _backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=No
             for jj in range(j):
                 t, acc, gate = book.target((i, jj), can_gate=True)
                 targets.append(V(t, accumulate=acc, gate=gate, gate_sum=True))
-            _pair_bwd(mod.conv, r, d_out, targets, b, grads, pre_gated)
+            _pair_bwd(mod.conv, r, d_out, targets, b, grads, pre_gated, flush=flush)
             t, acc, gate = book.target((i + 1, j - 1), can_gate=model.is_deconv)
             _up_bwd(mod.up, model.is_deconv, u, d_up, t, acc, gate, b, grads)
             flush()
@@ -468,7 +477,7 @@ def _backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=No
         mine, pool_grad = pool_grad, None
         if i > 0:
             d_pooled = torch.empty_like(s.pairs[(i - 1, 0)].pooled)
-            _pair_bwd(blk, r, d_out, [V(d_pooled)], b, grads, pre_gated, pool_grad=mine)
+            _pair_bwd(blk, r, d_out, [V(d_pooled)], b, grads, pre_gated, pool_grad=mine, flush=flush)
             # the pool gradient is the last contribution to the node above: with BatchNorm it is routed to the argmax
             # inside that node's BatchNorm backward, which reads the gradient anyway
             t, acc, _ = book.target((i - 1, 0))  # counts as the node's last contribution (no gate here)
@@ -479,9 +488,9 @@ def _backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=No
             if s.X[(0, 0)].dtype != torch.float32:
                 raise NotImplementedError("the input gradient is not available with bf16 activation storage")
             dx_in = torch.empty_like(s.x_nhwc)
-            _pair_bwd(blk, r, d_out, [V(dx_in)], b, grads, pre_gated, pool_grad=mine)
+            _pair_bwd(blk, r, d_out, [V(dx_in)], b, grads, pre_gated, pool_grad=mine, flush=flush)
         else:
-            _pair_bwd(blk, r, d_out, None, b, grads, pre_gated, pool_grad=mine)
+            _pair_bwd(blk, r, d_out, None, b, grads, pre_gated, pool_grad=mine, flush=flush)
         flush()
     return grads, dx_in
 

@@ -236,6 +236,18 @@ class PackPlan:
         self.phase = None
         self.pass_id = 0
         self.launches = 0     # batched pack launches issued (tests)
+        self.pinned = 0       # > 0 while a captured HIP graph holds raw pointers into this plan (serving.GraphedForward)
+        self._retired = []    # job tables replaced while pinned: a captured pack launch may still read them
+
+    def pin(self) -> None:
+        """A captured graph bakes in the addresses of the weight images and of the device job table of its pack launch:
+        while pinned, entries are not evicted and a replaced job table is kept alive instead of freed."""
+        self.pinned += 1
+
+    def unpin(self) -> None:
+        self.pinned = max(0, self.pinned - 1)
+        if not self.pinned:
+            self._retired.clear()
 
     def invalidate(self) -> None:
         """The parameters may have changed: the next pass of every phase rebuilds its images."""
@@ -250,9 +262,10 @@ class PackPlan:
     def begin(self, phase: str) -> None:
         self.phase = phase
         self.pass_id += 1
-        stale = [k for k, e in self.entries.items() if self.pass_id - e.used > 16]
-        for k in stale:
-            del self.entries[k]
+        if not self.pinned:
+            stale = [k for k, e in self.entries.items() if self.pass_id - e.used > 16]
+            for k in stale:
+                del self.entries[k]
         sigs = tuple(k for k, e in self.entries.items() if e.phase == phase)
         if not sigs:
             return
@@ -261,6 +274,8 @@ class PackPlan:
         if tab is None or tab[2] != sigs:
             arr = (PackJob * len(ents))(*[e.job for e in ents])
             dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(ents[0].image.device)
+            if self.pinned and phase in self._tables:
+                self._retired.append(self._tables[phase])
             tab = (dev, arr, sigs, max(e.n_img for e in ents))
             self._tables[phase] = tab
             self._packed.discard(phase)
@@ -614,7 +629,8 @@ def heatmap_pattern(points: torch.Tensor, pattern, height: int, width: int, radi
 def keypoints_extract(heat: torch.Tensor, num: int, threshold: float = 0.5, max_regions: int = 4096):
     """heat [maps, H, W] fp32 on the GPU -> (points [maps, num, 2] as (x, y), -1 padded; counts [maps] regions found).
     tools/misc/heatmap.py:148-200 with connected components as the region step; a map without any region is retried
-    once at 0.9 * threshold (heatmap.py:176-198)."""
+    once at 0.9 * threshold (heatmap.py:176-198).  max_regions sizes the fast ranking buffer only: maps with more
+    regions are selected exactly over all of them (no failure mode the reference does not have)."""
     lib = _lib.lib()
     _need(heat, "heat")
     if heat.dim() != 3:
@@ -642,15 +658,14 @@ def keypoints_extract(heat: torch.Tensor, num: int, threshold: float = 0.5, max_
         check(lib.unetpp_keypoints_extract(2, *args, 1, _ptr(ws), _ptr(changed), _ptr(points), _ptr(counts), st), "keypoints select")
 
     run()
-    host_counts = counts.cpu()
-    if int((host_counts == 0).sum()) > 0:  # retry the empty maps at 0.9 * threshold; the others keep their result
+    # one small read-back per call: are there maps without any region?  (the sweeps above already read a flag back
+    # every few iterations; everything else -- mask, labels, peaks, the exact top-`num` selection over ALL regions --
+    # stays on the device, and there is no limit on the number of regions: kp_select_kernel)
+    if bool((counts == 0).any()):  # retry the empty maps at 0.9 * threshold; the others keep their result
         keep_points, keep_counts = points.clone(), counts.clone()
         empty = (counts == 0)
         thr = torch.where(empty, thr * 0.9, thr)
         run()
         points = torch.where(empty.view(-1, 1, 1), points, keep_points)
         counts = torch.where(empty, counts, keep_counts)
-        host_counts = counts.cpu()
-    if int(host_counts.max()) > max_regions:
-        raise RuntimeError("keypoints_extract: more than max_regions=%d regions in a map" % max_regions)
     return points, counts

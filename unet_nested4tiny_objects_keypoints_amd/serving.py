@@ -34,9 +34,20 @@ class GraphedForward:
             for _ in range(max(1, warmup)):  # first passes record the weight-image jobs and size the allocator pools
                 model(self._x)
         torch.cuda.current_stream(example.device).wait_stream(side)
+        # The captured launches carry raw pointers into the model's weight-image plan (the images and the device job
+        # table of the in-graph pack launch): pin the plan so that neither is evicted / freed while this graph lives,
+        # and remember what was captured -- a replay after the plan changed shape (set_activation_dtype, a differently
+        # structured eager call) still finds its own table and images alive.
+        self._plan = model.__dict__.get("_pack_plan")
+        if self._plan is not None:
+            self._plan.pin()
         self._graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self._graph):
             outs = model(self._x)
+        self._held = None
+        if self._plan is not None:
+            self._held = (self._plan._tables.get("fwd"), [e.image for e in self._plan.entries.values()])
+        self._param_ptrs = [p.data_ptr() for p in model.parameters()]
         self._outs: Tuple[torch.Tensor, ...] = tuple(outs) if isinstance(outs, (tuple, list)) else (outs,)
         self._single = not isinstance(outs, (tuple, list))
 
@@ -46,6 +57,15 @@ class GraphedForward:
                 tuple(self._x.shape), self._x.dtype, self._x.device, tuple(x.shape), x.dtype, x.device))
         if self.model.training:
             raise RuntimeError("the captured graph is the eval forward; the model is in training mode")
+        if [p.data_ptr() for p in self.model.parameters()] != self._param_ptrs:
+            raise RuntimeError("the model's parameters moved (.to() / load with assign) since the graph was captured: "
+                               "build a new GraphedForward")
         self._x.copy_(x)
         self._graph.replay()
         return self._outs[0] if self._single else self._outs
+
+    def __del__(self):
+        plan = getattr(self, "_plan", None)
+        if plan is not None:
+            plan.unpin()
+            self._plan = None
