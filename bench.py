@@ -97,25 +97,36 @@ def usable_cores():
     return min(n, int(os.environ.get("UNETPP_CPU_THREADS", "16")))
 
 
-def pmc_traffic(kernel_label, build_hash):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (counters cannot be read from
-    inside the process: tools/pmc_traffic.py makes the file from two rocprofv3 --pmc passes of this workload).
-    A summary stamped with another build's hash is refused (None): it describes other kernels."""
+def config_key(args):
+    """names a benchmark configuration in profiles/pmc_hbm_traffic_latest.json (tools/pmc_traffic.py)"""
+    fs = int(args.feature_scale) if float(args.feature_scale).is_integer() else args.feature_scale
+    return "%s_d%d_fs%s_s%d_b%d_i%d_c%d" % (args.dtype, args.depth, fs, args.size, args.batch, args.in_channels, args.n_classes)
+
+
+def pmc_counters(kernel_label, build_hash, cfg_key):
+    """(HBM bytes per launch, matrix-pipe occupancy) of the dominant kernel from the committed PMC summary of THIS
+    configuration (counters cannot be read from inside the process: tools/pmc_traffic.py makes the file from separate
+    rocprofv3 --pmc passes of this command).  A summary stamped with another build's hash is refused (None, None): it
+    describes other kernels."""
     path = os.path.join(ROOT, "profiles", "pmc_hbm_traffic_latest.json")
     try:
         with open(path) as f:
-            doc = json.load(f)
+            doc = json.load(f)["configs"][cfg_key]
         rows = doc["kernels"]
     except (OSError, ValueError, KeyError):
-        return None
+        return None, None
     if doc.get("build_hash") != build_hash:
-        return None
+        return None, None
     stem = kernel_label.rstrip(">")  # "gemm_fast_kernel<9" matches "gemm_fast_kernel<9, 5, 1>"
     hits = [r for r in rows if r["kernel"].startswith(stem)]
     n = sum(r["launches"] for r in hits)
     if n == 0:
-        return None
-    return round(sum((r["fetch_bytes_x2_per_launch"] + r["write_bytes_per_launch"]) * r["launches"] for r in hits) / n)
+        return None, None
+    traffic = round(sum((r["fetch_bytes_x2_per_launch"] + r["write_bytes_per_launch"]) * r["launches"] for r in hits) / n)
+    busy = [(r["sq"]["mfma_busy"] * r["sq"]["avg_us"] * r["sq"]["dispatches"], r["sq"]["avg_us"] * r["sq"]["dispatches"])
+            for r in hits if "sq" in r and "mfma_busy" in r["sq"]]
+    mfma_busy = round(sum(b for b, _ in busy) / sum(t for _, t in busy), 4) if busy else None   # time-weighted
+    return traffic, mfma_busy
 
 
 def cpu_baseline(args, n_cls):
@@ -384,9 +395,8 @@ def main():
         # what the matrix pipe executes: Winograd F(2x2,3x3) runs 16 multiply-adds per 36 algorithmic ones
         wino = dom[0].startswith("gemm_wino") or dom[0].startswith("wgrad_wino")
         executed = alg / 2.25 if wino else alg
-        c2 = args.size == 256 and fs == 1 and args.batch == 32 and args.depth == 4 and args.dtype == "f32"
         from unet_nested4tiny_objects_keypoints_amd import _lib as _l
-        traffic = pmc_traffic(dom[0], _l.source_hash()) if c2 else None
+        traffic, mfma_busy = pmc_counters(dom[0], _l.source_hash(), config_key(args))
         traffic_alg = dom[1]["bytes"] / dom[1]["launches"]
         roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
@@ -397,10 +407,12 @@ def main():
                     "traffic": traffic,
                     "traffic_algorithmic": round(traffic_alg),
                     "traffic_over_algorithmic": None if traffic is None else round(traffic / traffic_alg, 3),
+                    "mfma_busy_pmc": mfma_busy,
                     "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes "
                                     "of this command; profiles/pmc_hbm_traffic_latest.json, null when that file is "
-                                    "from another build); traffic_algorithmic = 4 B x (Cin + Cout) x pixels, plus the accumulated outputs and ReLU "
-                                    "gates an input-gradient launch has to read",
+                                    "from another build); traffic_algorithmic = 4 B (bf16 storage: 2 B) x (Cin + Cout) x pixels, plus the "
+                                    "accumulated outputs and ReLU gates an input-gradient launch has to read; mfma_busy_pmc = "
+                                    "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) from a third pass",
                     "launches_per_step": dom[1]["launches"] / sampled_steps,
                     "timed_steps_with_launch_events": sampled_steps,
                     "avg_launch_ms": round(dom[1]["ms"] / dom[1]["launches"], 4),
