@@ -105,7 +105,8 @@ def test_golden_optimizer_step(dev, opt_name):
     """the reference's step body (trainer/trainer.py:114-136) end to end: parameters after one update.
 
     STRICT when no ReLU gate / pool winner of the HIP forward differs from the oracle's (true for every golden case,
-    profiles/r2/relu_gate_flips.jsonl): the SGD update lr * grad within 1e-4 of the reference's; Adam's first update
+    profiles/r2/relu_gate_flips.jsonl): the SGD update lr * grad within 1e-4 of the reference's (plus two ulp of the
+    fp32 parameter it is added to); Adam's first update
     is lr * g / (|g| + eps), i.e. +-lr wherever the gradient is resolved, so every element whose reference gradient is
     larger than the gradient tolerance itself (2e-4 of the tensor's largest) must match to fp32 rounding of the
     parameter, and the unresolved rest may at most land on the other sign (2 * lr)."""
@@ -136,7 +137,11 @@ def test_golden_optimizer_step(dev, opt_name):
         got_u = p.detach().cpu().double() - before[k].double()
         want_u = after[k].double() - before[k].double()
         if flips == 0 and opt_name == "sgd":
-            assert rel_err(got_u, want_u) < TOL, (k, rel_err(got_u, want_u))
+            # lr * grad within 1e-4 of the largest update of the tensor, plus the fp32 rounding of the parameter itself
+            # (2 ulp: BatchNorm gammas are ~1.0 and move by ~1e-4, so an ulp of the PARAMETER is 2e-4 of the update)
+            err = (got_u - want_u).abs()
+            bound = TOL * float(want_u.abs().max()) + 2.4e-7 * before[k].double().abs()
+            assert bool((err <= bound).all()), (k, float((err - bound).max()), rel_err(got_u, want_u))
         elif flips == 0:
             g = grads[k].double().abs()
             resolved = g > 2 * TOL * float(g.max())
