@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNETPP_ABI_VERSION 5
+#define UNETPP_ABI_VERSION 6
 #define UNETPP_MAX_VIEWS 8
 
 #define UNETPP_OK 0
@@ -68,6 +68,28 @@ typedef struct unetpp_view {
                               * shift, stats_partial and slabs stay fp32; the arithmetic is v_mfma_f32_32x32x16_bf16
                               * with fp32 accumulation (BASELINE configs[3]/[4]).  There is no generic bf16 kernel:
                               * a descriptor the MFMA kernels cannot take returns UNETPP_EINVAL. */
+/* BatchNorm2d training-mode finalize (models/unet.py:133) FUSED into the convolution launch that takes the statistics:
+ * the launch leaves mean, invstd, scale = gamma * invstd, shift = beta - mean * scale ([Ncols] each) and the updated
+ * running statistics behind, exactly as unetpp_bn_finalize would, without a second launch.  Inside the persistent
+ * kernels every workgroup publishes ONE row of sums over all its units, takes a ticket, and the workgroup that
+ * arrives last adds the rows in fixed order (fp64) and writes the coefficients (agent-scope hand-off: write-through
+ * rows, device-scope ticket, acquire in the last arriver).  Kernels without that epilogue (generic shapes, more than
+ * 256 columns) write per-block rows and the library enqueues unetpp_bn_finalize itself: the result of the call is the
+ * same either way.  scale == NULL: not fused (the caller finishes stats_partial with unetpp_bn_finalize). */
+typedef struct unetpp_bn_fused {
+  const float* gamma;
+  const float* beta;
+  float* running_mean; /* both NULL or both set */
+  float* running_var;
+  float* mean;
+  float* invstd;
+  float* scale;
+  float* shift;
+  int64_t count;     /* N*H*W */
+  float eps, momentum;
+  uint32_t* ticket;  /* one 32-bit word of device memory, zero before the launch; the launch leaves it zero */
+} unetpp_bn_fused;
+
 typedef struct unetpp_gemm_desc {
   int32_t N, H, W;
   int32_t taps;
@@ -80,11 +102,13 @@ typedef struct unetpp_gemm_desc {
   const float* weight; /* packed [taps][K][Ncols] (see unetpp_pack_weight); may be NULL when weight_image is set */
   const float* bias;   /* [Ncols] or NULL */
   /* optional BatchNorm statistics epilogue: per pixel-block partial (sum, sum of squares) of the
-   * stored values, [unetpp_gemm_pixel_blocks()][Ncols][2]; requires n_out == 1. */
+   * stored values, [unetpp_gemm_pixel_blocks()][Ncols][2]; requires n_out == 1.  With `bn` set the buffer is
+   * workspace of [unetpp_gemm_stats_rows()][Ncols][2] floats whose row structure is the kernel's own. */
   float* stats_partial;
   /* optional fast path: `weight` re-laid as the kernel's LDS image by unetpp_gemm_pack_weight_image
    * (unetpp_gemm_weight_image_floats() floats).  NULL selects the generic kernel. */
   const float* weight_image;
+  unetpp_bn_fused bn; /* bn.scale != NULL: finalize the statistics inside this call (needs stats_partial) */
 } unetpp_gemm_desc;
 
 /* weight gradient:  dW[tap][k][n] = sum_p x[p (+) tap, k] * dy[p, n]  (+ db[n] = sum_p dy[p, n]).
@@ -113,6 +137,8 @@ const char* unetpp_last_kernel_name(void);
 
 /* ---- multi-view pixel GEMM on MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32) ------ */
 int64_t unetpp_gemm_pixel_blocks(int32_t N, int32_t H, int32_t W);
+/* rows of [Ncols][2] floats stats_partial must hold when the finalize is fused (d->bn.scale != NULL) */
+int64_t unetpp_gemm_stats_rows(int32_t N, int32_t H, int32_t W);
 int unetpp_gemm_fwd(const unetpp_gemm_desc* d, void* stream);
 /* Fast path (register-prefetched LDS-image kernels; Winograd F(2x2,3x3) for taps = 9 unless UNETPP_GEMM_DIRECT):
  * applies when every input view is a 16-byte aligned slice without a ReLU gate on load (C, c_off and c_len

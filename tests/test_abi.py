@@ -41,7 +41,7 @@ def test_exported_symbols_are_plain_c(built_lib):
     out = subprocess.run(["nm", "-D", "--defined-only", built_lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
     assert set(_declared_functions()) <= exported
-    assert built_lib.lib().unetpp_abi_version() == built_lib.ABI_VERSION == 5
+    assert built_lib.lib().unetpp_abi_version() == built_lib.ABI_VERSION == 6
     assert built_lib.lib().unetpp_build_arch() == b"gfx950"
 
 
@@ -49,11 +49,13 @@ def test_struct_layout_matches_header(built_lib, tmp_path):
     """sizeof/offsetof from a C compile of the header vs the ctypes mirrors."""
     src = tmp_path / "layout.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "unetpp_hip.h"\nint main(void){'
-                   'printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(unetpp_view), offsetof(unetpp_view, gate),'
+                   'printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(unetpp_view), offsetof(unetpp_view, gate),'
                    'offsetof(unetpp_view, gate_sum), sizeof(unetpp_gemm_desc), offsetof(unetpp_gemm_desc, out),'
                    'offsetof(unetpp_gemm_desc, weight_image), sizeof(unetpp_wgrad_desc), offsetof(unetpp_wgrad_desc, dy),'
                    'offsetof(unetpp_wgrad_desc, slabs), sizeof(unetpp_weight_src), offsetof(unetpp_weight_src, k_inner),'
-                   'sizeof(unetpp_pack_job), offsetof(unetpp_pack_job, image), offsetof(unetpp_pack_job, out_len));return 0;}')
+                   'sizeof(unetpp_pack_job), offsetof(unetpp_pack_job, image), offsetof(unetpp_pack_job, out_len),'
+                   'sizeof(unetpp_bn_fused), offsetof(unetpp_bn_fused, count), offsetof(unetpp_bn_fused, ticket),'
+                   'offsetof(unetpp_gemm_desc, bn));return 0;}')
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
@@ -61,7 +63,8 @@ def test_struct_layout_matches_header(built_lib, tmp_path):
     want = [ctypes.sizeof(L.View), L.View.gate.offset, L.View.gate_sum.offset, ctypes.sizeof(L.GemmDesc),
             L.GemmDesc.out.offset, L.GemmDesc.weight_image.offset, ctypes.sizeof(L.WgradDesc), L.WgradDesc.dy.offset,
             L.WgradDesc.slabs.offset, ctypes.sizeof(L.WeightSrc), L.WeightSrc.k_inner.offset, ctypes.sizeof(L.PackJob),
-            L.PackJob.image.offset, L.PackJob.out_len.offset]
+            L.PackJob.image.offset, L.PackJob.out_len.offset, ctypes.sizeof(L.BnFused), L.BnFused.count.offset,
+            L.BnFused.ticket.offset, L.GemmDesc.bn.offset]
     assert got == want
 
 
@@ -70,6 +73,7 @@ def test_argument_validation_without_gpu(built_lib):
     lib = built_lib.lib()
     assert lib.unetpp_gemm_pixel_blocks(32, 256, 256) == 32 * 32 * 8
     assert lib.unetpp_gemm_pixel_blocks(0, 256, 256) == 0
+    assert lib.unetpp_gemm_stats_rows(32, 256, 256) == 32 * 32 * 8 and lib.unetpp_gemm_stats_rows(1, 64, 64) == 2048
     assert lib.unetpp_wgrad_max_split(1, 8, 8) == 1
     assert lib.unetpp_head_bwd_blocks(100) == 2
     assert lib.unetpp_bn_bwd_blocks(32 * 256 * 256, 32) % 8 == 0

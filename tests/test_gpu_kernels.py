@@ -77,6 +77,69 @@ def test_conv3x3_fwd_multiview(dev, shape, conv_algo):
     assert rel_err(sums[:, 1], (ref.double() ** 2).sum((0, 2, 3))) < TOL
 
 
+@pytest.mark.parametrize("shape", [
+    # (B, H, W, [cin per source], cout): which kernel takes the statistics, and who finalizes
+    (32, 64, 64, [32], 32),           # Winograd lean kernel, 512 persistent workgroups with 1 unit each: last arriver
+    (8, 128, 128, [32, 32], 64),      # Winograd, two column groups per patch, several units per workgroup
+    (3, 40, 24, [16], 24),            # ragged patches, partial column tile
+    (16, 256, 256, [1], 32),          # first-layer VALU kernel, 1024 persistent workgroups, 8 patches each
+    (2, 24, 40, [3], 8),              # first layer, rgb, fewer patches than workgroups
+    (1, 16, 16, [64], 288),           # more columns than the in-kernel finalize takes: trailing bn_finalize launch
+    (2, 8, 8, [5, 3], 7),             # generic kernel: trailing bn_finalize launch
+])
+@pytest.mark.parametrize("fold", [False, True])
+def test_fused_batchnorm_finalize_matches_separate_launch(dev, shape, fold, conv_algo):
+    """unetpp_bn_fused: the convolution launch that takes the statistics also leaves mean / invstd / scale / shift and
+    the running statistics behind (last-arriving workgroup, or a finalize launch enqueued by the library).  Against
+    the float64 statistics of the stored tensor, against the two-launch path, three times in a row on one ticket word
+    (it must come back to zero), with other work in flight before it (uneven load)."""
+    from unet_nested4tiny_objects_keypoints_amd import engine, ops
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    b, h, w, cins, co = shape
+    g = torch.Generator().manual_seed(3)
+    srcs = [nhwc(torch.randn(b, c, h, w, generator=g)) for c in cins]
+    wt = (torch.randn(co, sum(cins), 3, 3, generator=g) * 0.2).cuda()
+    bias = torch.randn(co, generator=g).cuda()
+    gamma, beta = (1 + 0.1 * torch.randn(co, generator=g)).cuda(), (0.1 * torch.randn(co, generator=g)).cuda()
+    kw = {}
+    if fold and cins[0] >= 8 and len(cins) == 1:   # a folded BatchNorm + ReLU on the input view (encoder conv2)
+        kw = dict(scale=(1 + 0.1 * torch.randn(cins[0], generator=g)).cuda(), shift=(0.1 * torch.randn(cins[0], generator=g)).cuda(), relu=True)
+    ins = [V(s, **kw) for s in srcs]
+    wp = engine.pack_conv_fwd(wt)
+    count = b * h * w
+    # two-launch reference
+    y_ref = torch.empty(b, h, w, co, device=dev)
+    blocks = ops.gemm_pixel_blocks(b, h, w)
+    part = torch.empty(blocks * co * 2, device=dev)
+    ops.gemm_fwd(b, h, w, 9, ins, [V(y_ref)], wp, bias, part)
+    rm_ref, rv_ref = torch.zeros(co, device=dev), torch.ones(co, device=dev)
+    ref = ops.bn_finalize(part, blocks, co, count, gamma, beta, 1e-5, 0.1, rm_ref, rv_ref)
+    # fused
+    ticket = torch.zeros(4, dtype=torch.int32, device=dev)
+    rm, rv = torch.zeros(co, device=dev), torch.ones(co, device=dev)
+    rows = ops.gemm_stats_rows(b, h, w)
+    busy = torch.randn(1 << 22, device=dev)
+    for rep in range(3):
+        y = torch.full((b, h, w, co), float("nan"), device=dev)
+        workspace = torch.full((rows * co * 2,), float("nan"), device=dev)   # stale rows must not matter
+        fin = ops.BatchNormFinish(gamma, beta, rm, rv, 1e-5, 0.1, count, ticket)
+        for _ in range(4):
+            busy = busy * 1.0001 + 0.5      # other kernels in front of the launch: its workgroups start unevenly
+        ops.gemm_fwd(b, h, w, 9, ins, [V(y)], wp, bias, workspace, bn=fin)
+        assert int(ticket[0]) == 0, rep
+        assert torch.equal(y, y_ref)
+        yd = y.double().view(-1, co)
+        mean, var = yd.mean(0), yd.var(0, unbiased=False)
+        assert float((fin.mean.cpu().double() - mean.cpu()).abs().max()) < 1e-5 * max(1.0, float(mean.abs().max()))
+        assert rel_err(fin.invstd.cpu(), (1 / (var + 1e-5).sqrt()).cpu()) < 1e-5
+        for got, want in zip((fin.mean, fin.invstd, fin.scale, fin.shift), ref):
+            assert rel_err(got.cpu(), want.cpu()) < 1e-5
+    # three updates of the running statistics with momentum 0.1 == three two-launch updates
+    for _ in range(2):
+        ops.bn_finalize(part, blocks, co, count, gamma, beta, 1e-5, 0.1, rm_ref, rv_ref)
+    assert rel_err(rm.cpu(), rm_ref.cpu()) < 1e-5 and rel_err(rv.cpu(), rv_ref.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("ck", [12, 16])  # 12: partial 8-channel chunk (general kernel); 16: the lean fold kernel
 def test_conv3x3_load_transform_and_slices(dev, conv_algo, ck):
     """affine + ReLU applied on load (zero padding AFTER the transform), channel-sliced views, store gate/accumulate."""

@@ -6,11 +6,13 @@ Why at this size: a BatchNorm channel sums 2.1 M values here (262 k at the batch
 gradient runs its full <= 4096-slab split, and the fp32 CPU library itself loses up to 7e-4 on such sums
 (profiles/r2/grad_error_fp32_vs_fp64_c2.txt) -- the comparison has to be against float64.  GPU only.
 """
+import copy
+
 import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.helpers import rel_err
+from tests.helpers import GatedReLU, RoutedMaxPool, check_flips, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -46,28 +48,40 @@ def test_x00_block_forward_backward_at_benchmark_batch_vs_float64(dev, b, h, w):
     d_out = torch.randn(b, 32, h, w, generator=g)            # gradient reaching X_0,0 through the dense skips
     d_pool = torch.randn(b, 32, h // 2, w // 2, generator=g)  # gradient reaching it through the max-pool
 
-    # ---- float64 statement on the CPU (batch statistics, biased variance in the normalisation: SURVEY appendix B)
+    # ---- the HIP path: the engine's own schedule of the pair (what the network's forward / backward run)
+    blk_d = copy.deepcopy(blk).to(dev)
+    x_nhwc = x.to(dev).view(b, h, w, 1)
+    r = engine._pair_fwd(blk_d, [V(x_nhwc)], b, h, w, True, pool=True)
+    engine.flush_batch_counters()
+
+    # ---- float64 statement on the CPU (batch statistics, biased variance in the normalisation: SURVEY appendix B).
+    # Its BACKWARD uses the ReLU gates and pool winners of the HIP forward (tests/helpers.py: among 1.3e8 gated values a
+    # handful sit within fp32 rounding of zero, and with a random upstream gradient every such gate moves a
+    # 2-million-term random-walk sum by 1e-3 of its size although both sides are right); the differing gates are
+    # counted and must be few and only where the float64 pre-activation itself is rounding noise around zero.
+    a1_hip = (r.y1.double() * r.bn1[2].double() + r.bn1[3].double()).float()   # only the sign is used
+    relu1 = GatedReLU((a1_hip.permute(0, 3, 1, 2) > 0).cpu())
+    del a1_hip
+    relu2 = GatedReLU((r.out.permute(0, 3, 1, 2) > 0).cpu())
+    pool = RoutedMaxPool([r.pool_idx.cpu()])
     p64 = {k: v.detach().double().requires_grad_(True) for k, v in blk.named_parameters()}
     rm = [torch.zeros(32, dtype=torch.float64) for _ in range(2)]
     rv = [torch.ones(32, dtype=torch.float64) for _ in range(2)]
     y1 = F.conv2d(x.double(), p64["conv1.0.weight"], p64["conv1.0.bias"], padding=1)
-    a1 = F.relu(F.batch_norm(y1, rm[0], rv[0], p64["conv1.1.weight"], p64["conv1.1.bias"], True, 0.1, 1e-5))
+    a1 = relu1(F.batch_norm(y1, rm[0], rv[0], p64["conv1.1.weight"], p64["conv1.1.bias"], True, 0.1, 1e-5))
     y2 = F.conv2d(a1, p64["conv2.0.weight"], p64["conv2.0.bias"], padding=1)
-    out = F.relu(F.batch_norm(y2, rm[1], rv[1], p64["conv2.1.weight"], p64["conv2.1.bias"], True, 0.1, 1e-5))
-    pooled = F.max_pool2d(out, 2)
+    out = relu2(F.batch_norm(y2, rm[1], rv[1], p64["conv2.1.weight"], p64["conv2.1.bias"], True, 0.1, 1e-5))
+    pooled = pool(out)
     ((out * d_out.double()).sum() + (pooled * d_pool.double()).sum()).backward()
     want = {k: v.grad for k, v in p64.items()}
     out, pooled, y2 = out.detach(), pooled.detach(), y2.detach()
     del y1, a1
+    check_flips([relu1, relu2, pool], "x00-block b%d %dx%d" % (b, h, w))
 
-    # ---- the HIP path: the engine's own schedule of the pair (what the network's forward / backward run)
-    blk = blk.to(dev)
-    x_nhwc = x.to(dev).view(b, h, w, 1)
-    r = engine._pair_fwd(blk, [V(x_nhwc)], b, h, w, True, pool=True)
-    engine.flush_batch_counters()
     assert rel_err(_nchw(r.y2), y2) < TOL
     assert rel_err(_nchw(r.out), out) < TOL
     assert rel_err(_nchw(r.pooled), pooled) < TOL
+    blk = blk_d
     for bn, m, v in ((getattr(blk.conv1, "1"), rm[0], rv[0]), (getattr(blk.conv2, "1"), rm[1], rv[1])):
         assert rel_err(bn.running_mean.cpu(), m) < TOL and rel_err(bn.running_var.cpu(), v) < TOL
         assert int(bn.num_batches_tracked) == 1

@@ -16,9 +16,9 @@ LIB_PATH = os.environ.get("UNETPP_LIB", os.path.join(_PKG_DIR, "libunetpp_hip.so
 CSRC = os.path.join(_PKG_DIR, "csrc")
 INCLUDE = os.path.join(_REPO, "include")
 SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_wino.hip", "gemm_bf16.hip", "wgrad_bf16.hip", "pointwise_bf16.hip", "keypoints.hip", "weight_image.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "wgrad_wino.hip", "first_layer.hip", "pointwise.hip", "caller.hip")
-HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h", "lds_asm.h", "bf16_common.h", "dropout.h")
+HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h", "lds_asm.h", "bf16_common.h", "dropout.h", "bn_fused.h")
 MAX_VIEWS = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 # packed-f32 VALU (SLP-vectorised add pairs) costs issue slots beside MFMAs: keep the Winograd transforms scalar
 EXTRA_FLAGS = {"gemm_wino.hip": ("-fno-slp-vectorize",), "wgrad_wino.hip": ("-fno-slp-vectorize",)}
 GEMM_DIRECT = 1  # unetpp_gemm_desc.flags: direct summation only (no Winograd)
@@ -37,6 +37,15 @@ class View(C.Structure):
     ]
 
 
+class BnFused(C.Structure):
+    """mirror of struct unetpp_bn_fused"""
+    _fields_ = [
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+        ("mean", C.c_void_p), ("invstd", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+        ("count", C.c_int64), ("eps", C.c_float), ("momentum", C.c_float), ("ticket", C.c_void_p),
+    ]
+
+
 class GemmDesc(C.Structure):
     """mirror of struct unetpp_gemm_desc"""
     _fields_ = [
@@ -46,6 +55,7 @@ class GemmDesc(C.Structure):
         ("inp", View * MAX_VIEWS), ("out", View * MAX_VIEWS),
         ("weight", C.c_void_p), ("bias", C.c_void_p), ("stats_partial", C.c_void_p),
         ("weight_image", C.c_void_p),
+        ("bn", BnFused),
     ]
 
 
@@ -87,6 +97,7 @@ SIGNATURES = {
     "unetpp_build_arch": (C.c_char_p, []),
     "unetpp_last_kernel_name": (C.c_char_p, []),
     "unetpp_gemm_pixel_blocks": (_I64, [_I32, _I32, _I32]),
+    "unetpp_gemm_stats_rows": (_I64, [_I32, _I32, _I32]),
     "unetpp_gemm_fwd": (C.c_int, [C.POINTER(GemmDesc), _P]),
     "unetpp_gemm_weight_image_floats": (_I64, [C.POINTER(GemmDesc)]),
     "unetpp_gemm_pack_weight_image": (C.c_int, [C.POINTER(GemmDesc), _P, _P]),

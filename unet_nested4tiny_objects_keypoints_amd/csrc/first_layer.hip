@@ -8,6 +8,7 @@
 //   wgrad   : thread = (pixel stripe, 4 output channels) keeps 9*Cin float4 accumulators in registers over a
 //             grid-stride loop of patches; fixed-order LDS reduction; one slab per workgroup (wgrad_finish sums them)
 #include "bf16_common.h"
+#include "bn_fused.h"
 #include "common.h"
 #include "lds_asm.h"
 
@@ -27,6 +28,8 @@ struct SmallArgs {
   int N, H, W, COUT, yC, relu;
   int log2tw, tiles_x, tiles_y;
   long n_patches;
+  int bn_in_kernel;    // forward: rows are per workgroup and the last arriver finalizes the BatchNorm (bn_fused.h)
+  unetpp_bn_fused bn;
 };
 
 template <int CIN>
@@ -56,7 +59,10 @@ __global__ __launch_bounds__(kThreads) void small_cin_fwd_kernel(const SmallArgs
   __shared__ float xs2[2][kMaxHaloPixels * CIN];
   __shared__ __attribute__((aligned(16))) float ws[WREG ? 4 : 9 * CIN * kMaxCout];
   __shared__ float red[4][kMaxCout * 2];  // [wave][quad][s1 x 4, s2 x 4]
+  __shared__ double fin_scratch[(kThreads / 32) * 32 * 2 + 1];  // fused BatchNorm finalize: slice sums + the flag word
   const int tid = threadIdx.x;
+  const bool bn_fused = a.bn_in_kernel != 0;  // uniform
+  float run1 = 0.f, run2 = 0.f;               // this thread's column (tid < COUT) over all patches of the workgroup
   const int TW = 1 << a.log2tw, TH = kBlockPixels >> a.log2tw, HWp = TW + 2;
   const int npix = HWp * (TH + 2);
   const int QN = a.COUT >> 2;             // 4-channel groups; the launcher guarantees 256 % QN == 0
@@ -187,11 +193,29 @@ __global__ __launch_bounds__(kThreads) void small_cin_fwd_kernel(const SmallArgs
       __syncthreads();
       if (tid < a.COUT) {
         const int i1 = (tid >> 2) * 8 + (tid & 3);
-        float* dst = a.stats + (static_cast<long>(patch) * a.COUT + tid) * 2;
-        dst[0] = (red[0][i1] + red[1][i1]) + (red[2][i1] + red[3][i1]);
-        dst[1] = (red[0][i1 + 4] + red[1][i1 + 4]) + (red[2][i1 + 4] + red[3][i1 + 4]);
+        const float t1 = (red[0][i1] + red[1][i1]) + (red[2][i1] + red[3][i1]);
+        const float t2 = (red[0][i1 + 4] + red[1][i1 + 4]) + (red[2][i1 + 4] + red[3][i1 + 4]);
+        if (bn_fused) {
+          run1 += t1;
+          run2 += t2;
+        } else {
+          float* dst = a.stats + (static_cast<long>(patch) * a.COUT + tid) * 2;
+          dst[0] = t1;
+          dst[1] = t2;
+        }
       }
     }
+  }
+  if (bn_fused) {
+    __syncthreads();  // everybody is done with red[]: it becomes the workgroup's row
+    float* run = &red[0][0];
+    if (tid < a.COUT) {
+      run[2 * tid] = run1;
+      run[2 * tid + 1] = run2;
+    }
+    __syncthreads();
+    bn_fused_finish<kThreads>(a.bn, a.stats, a.COUT, run, fin_scratch,
+                              reinterpret_cast<unsigned*>(&fin_scratch[(kThreads / 32) * 32 * 2]));
   }
 }
 
@@ -315,8 +339,11 @@ int launch_small_cin_fwd(const unetpp_gemm_desc* d, hipStream_t st) {
     return UNETPP_ELAUNCH;
   // persistent grid: as many workgroups as are resident at once (<= 128 registers up to three input channels, 156
   // with four: four / three one-wave-per-SIMD workgroups per CU)
-  const long workers = static_cast<long>(cus) * (X.C == 4 ? 3 : 4);
+  long workers = static_cast<long>(cus) * (X.C == 4 ? 3 : 4);
+  if (workers > kBnFusedRows) workers = kBnFusedRows;
   const dim3 grid(static_cast<unsigned>(a.n_patches < workers ? a.n_patches : workers)), block(kThreads);
+  a.bn_in_kernel = bn_fused_in_kernel(d, a.COUT) ? 1 : 0;
+  a.bn = d->bn;
 #define UNETPP_SMALL_FWD(B)                                                                          \
   switch (X.C) {                                                                                     \
     case 1: hipLaunchKernelGGL((small_cin_fwd_kernel<1, B>), grid, block, 0, st, a); break;          \
@@ -331,6 +358,7 @@ int launch_small_cin_fwd(const unetpp_gemm_desc* d, hipStream_t st) {
   }
 #undef UNETPP_SMALL_FWD
   note_kernel("small_cin_fwd_kernel");
+  if (a.bn_in_kernel) note_bn_fused();
   return launch_status();
 }
 

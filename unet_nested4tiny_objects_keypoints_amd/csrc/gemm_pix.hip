@@ -15,6 +15,7 @@
 // MFMA operand maps (cdna guide section 3): A lane l = (row l&31, k l>>5), B lane l = (k l>>5, col l&31),
 // D reg r of lane l = row (r&3)+8*(r>>2)+4*(l>>5), col l&31.  Rows are pixels, columns are
 // output channels, so one stored register is 32 consecutive floats of one pixel (a full 128-B line).
+#include "bn_fused.h"
 #include "common.h"
 
 namespace unetpp {
@@ -187,7 +188,9 @@ namespace unetpp {
 namespace {
 thread_local const char* g_last_kernel = "";
 }
+thread_local bool g_bn_fused_done = false;
 void note_kernel(const char* name) { g_last_kernel = name; }
+void note_bn_fused() { g_bn_fused_done = true; }
 }  // namespace unetpp
 
 using namespace unetpp;
@@ -200,7 +203,35 @@ extern "C" int64_t unetpp_gemm_pixel_blocks(int32_t N, int32_t H, int32_t W) {
   return static_cast<int64_t>(N) * g.tiles_y * g.tiles_x;
 }
 
+extern "C" int64_t unetpp_gemm_stats_rows(int32_t N, int32_t H, int32_t W) {
+  const int64_t blocks = unetpp_gemm_pixel_blocks(N, H, W);
+  if (blocks <= 0) return 0;
+  return blocks > kBnFusedRows ? blocks : kBnFusedRows;
+}
+
+namespace {
+int gemm_fwd_dispatch(const unetpp_gemm_desc* d, void* stream);
+}
+
 extern "C" int unetpp_gemm_fwd(const unetpp_gemm_desc* d, void* stream) {
+  if (d == nullptr || d->N <= 0 || d->H <= 0 || d->W <= 0) return UNETPP_EINVAL;
+  const unetpp_bn_fused& bn = d->bn;
+  if (bn.scale == nullptr) return gemm_fwd_dispatch(d, stream);
+  // BatchNorm finalize fused into this call: in the kernel's last-arriving workgroup where the kernel can, else by a
+  // unetpp_bn_finalize launch behind it (per-block rows); same results up to the row partition of the fp32 sums
+  if (!d->stats_partial || !bn.gamma || !bn.beta || !bn.mean || !bn.invstd || !bn.shift || !bn.ticket || bn.count < 1 ||
+      (bn.running_mean == nullptr) != (bn.running_var == nullptr) || d->n_out != 1)
+    return UNETPP_EINVAL;
+  g_bn_fused_done = false;
+  const int rc = gemm_fwd_dispatch(d, stream);
+  if (rc != UNETPP_OK || g_bn_fused_done) return rc;
+  return unetpp_bn_finalize(d->stats_partial, unetpp_gemm_pixel_blocks(d->N, d->H, d->W), d->out[0].c_len, bn.count, bn.gamma,
+                            bn.beta, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.mean, bn.invstd, bn.scale,
+                            bn.shift, stream);
+}
+
+namespace {
+int gemm_fwd_dispatch(const unetpp_gemm_desc* d, void* stream) {
   if (d == nullptr || d->N <= 0 || d->H <= 0 || d->W <= 0) return UNETPP_EINVAL;
   if (d->taps != 9 && d->taps != 1) return UNETPP_EINVAL;
   if (d->n_in < 1 || d->n_in > UNETPP_MAX_VIEWS || d->n_out < 1 || d->n_out > UNETPP_MAX_VIEWS) return UNETPP_EINVAL;
@@ -247,3 +278,4 @@ extern "C" int unetpp_gemm_fwd(const unetpp_gemm_desc* d, void* stream) {
   note_kernel(d->taps == 9 ? "gemm_pix_kernel<9>" : "gemm_pix_kernel<1>");
   return launch_status();
 }
+}  // namespace

@@ -10,6 +10,7 @@ struct FastArgs {
   int Ktot, Ncols, n_tiles, n_chunks;
   int nt_unit, n_groups;  // column tiles per unit of work, units per pixel patch (n_tiles / nt_unit)
   long total_blocks;
+  int bn_in_kernel;  // the BatchNorm finalize runs in the last-arriving workgroup (bn_fused.h); rows are per workgroup
 };
 
 // 32-bit element offset of a view pixel (the fast kernels only take tensors below 2^31 elements)
@@ -81,6 +82,7 @@ inline bool fast_args(const unetpp_gemm_desc* d, FastArgs& a, int kc, int ncol =
   if (d->taps != 9 && d->taps != 1) return false;
   if (d->n_in < 1 || d->n_in > UNETPP_MAX_VIEWS || d->n_out < 1 || d->n_out > UNETPP_MAX_VIEWS) return false;
   a.d = *d;
+  a.bn_in_kernel = 0;
   a.Ktot = a.Ncols = a.n_tiles = a.n_chunks = 0;
   for (int i = 0; i < d->n_in; ++i) {
     const unetpp_view& v = d->in[i];

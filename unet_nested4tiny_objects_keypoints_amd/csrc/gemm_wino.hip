@@ -36,6 +36,7 @@
 #include <cstdlib>
 #include <utility>
 
+#include "bn_fused.h"
 #include "common.h"
 #include "gemm_units.h"
 #include "lds_asm.h"
@@ -138,14 +139,28 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
   float* in_tile = smem;             // buffers of the chunk being computed
   float* w_tile = smem + IN_FLOATS;
-  __shared__ float stat_lds[4 * WNC * 2];  // the four waves' BatchNorm partial sums of the unit just finished
+  // the four waves' BatchNorm partial sums of the unit just finished; then (fused finalize, bn_fused.h) the sums of ALL
+  // units of this workgroup per column, and the "I am the last arriver" word -- one object: see bn_fused.h on LDS objects
+  constexpr int RUN0 = 4 * WNC * 2, FLAG0 = RUN0 + kBnFusedMaxCols * 2;
+  __shared__ float stat_lds[FLAG0 + 4];
 
   const unetpp_gemm_desc& d = a.d;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, t16 = lane & 15, g = lane >> 4;
 
   const UnitRange ur = my_contiguous_unit_range(a.total_blocks);
-  if (ur.count == 0) return;
+  const bool bn_fused = a.bn_in_kernel != 0;  // uniform
+  if (bn_fused) {
+    for (int i = tid; i < kBnFusedMaxCols * 2; i += kThreads) stat_lds[RUN0 + i] = 0.f;  // (a barrier follows in the prologue)
+  }
+  if (ur.count == 0) {  // (cannot happen with the launcher's grids; every workgroup must take its ticket all the same)
+    if (bn_fused) {
+      __syncthreads();
+      bn_fused_finish<kThreads>(a.d.bn, a.d.stats_partial, a.Ncols, stat_lds + RUN0, reinterpret_cast<double*>(smem),
+                                reinterpret_cast<unsigned*>(stat_lds + FLAG0));
+    }
+    return;
+  }
   // Everything that steers the (unit, chunk) stream is wave uniform; readfirstlane moves it to scalar registers
   // (hipcc computes the range with vector divisions and would keep the whole cursor in VGPRs otherwise).
   const int n_units = __builtin_amdgcn_readfirstlane(static_cast<int>(ur.count));
@@ -569,6 +584,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       t1 += stat_lds[(w * WNC + tid) * 2 + 0];
       t2 += stat_lds[(w * WNC + tid) * 2 + 1];
     }
+    if (bn_fused) {  // column n0 + tid is always this thread's: a plain read-modify-write
+      stat_lds[RUN0 + (tc.n0 + tid) * 2 + 0] += t1;
+      stat_lds[RUN0 + (tc.n0 + tid) * 2 + 1] += t2;
+      return;
+    }
     float* dst = d.stats_partial + (ug.patch * a.Ncols + tc.n0 + tid) * 2;
     dst[0] = t1;
     dst[1] = t2;
@@ -760,6 +780,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     atomicAdd(&g_wino_stamps[8], 1ull);
   }
 #endif
+  if (bn_fused) {
+    __syncthreads();  // the last unit's sums are in; the staging buffers are free (scratch of the finalize)
+    bn_fused_finish<kThreads>(d.bn, d.stats_partial, a.Ncols, stat_lds + RUN0, reinterpret_cast<double*>(smem),
+                              reinterpret_cast<unsigned*>(stat_lds + FLAG0));
+  }
 }
 
 }  // namespace
@@ -784,6 +809,7 @@ int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
   FastArgs a;
   if (!wino_applies(d) || !fast_args(d, a, WKC, WNC) || d->weight_image == nullptr) return UNETPP_EINVAL;
   if (d->stats_partial != nullptr && d->n_out != 1) return UNETPP_EINVAL;
+  a.bn_in_kernel = bn_fused_in_kernel(d, a.Ncols) ? 1 : 0;
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
@@ -793,6 +819,7 @@ int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
   if (const char* e = getenv("UNETPP_WINO_ONE_PER_CU"); e != nullptr && e[0] == '1') workers = cus & ~7L;  // waves alone on their SIMD
 #endif
   if (workers < 8) workers = 8;
+  if (workers > kBnFusedRows) workers = kBnFusedRows;
   const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(kThreads);
   bool narrow = true;  // no output view wider than 16 channels: the second column half is never used
   for (int i = 0; i < d->n_out; ++i) narrow = narrow && d->out[i].c_len <= 16;
@@ -822,6 +849,7 @@ int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
 #undef UNETPP_LAUNCH_WINO
 #undef UNETPP_LAUNCH_WINO_M
   note_kernel("gemm_wino_kernel");
+  if (a.bn_in_kernel) note_bn_fused();
   return launch_status();
 }
 

@@ -320,10 +320,34 @@ def gemm_pixel_blocks(n: int, h: int, w: int) -> int:
     return int(_lib.lib().unetpp_gemm_pixel_blocks(n, h, w))
 
 
+@dataclass
+class BatchNormFinish:
+    """BatchNorm finalize fused into the convolution launch that takes the statistics (struct unetpp_bn_fused): the
+    launch leaves mean / invstd / scale / shift and the updated running statistics behind -- no bn_finalize launch."""
+    gamma: torch.Tensor
+    beta: torch.Tensor
+    running_mean: Optional[torch.Tensor]
+    running_var: Optional[torch.Tensor]
+    eps: float
+    momentum: float
+    count: int
+    ticket: torch.Tensor   # one zeroed int32 word on the device (the launch leaves it zero)
+
+    def outputs(self, c: int):
+        dev = self.gamma.device
+        self.mean, self.invstd, self.scale, self.shift = (torch.empty(c, dtype=torch.float32, device=dev) for _ in range(4))
+        return self.mean, self.invstd, self.scale, self.shift
+
+
+def gemm_stats_rows(n: int, h: int, w: int) -> int:
+    return int(_lib.lib().unetpp_gemm_stats_rows(n, h, w))
+
+
 def gemm_fwd(n: int, h: int, w: int, taps: int, ins: Sequence[V], outs: Sequence[V], weight: torch.Tensor,
              bias: Optional[torch.Tensor] = None, stats_partial: Optional[torch.Tensor] = None,
-             direct: bool = False) -> None:
-    """direct=True forbids the Winograd form of the 3x3 fast path (bit-exact direct summation)."""
+             direct: bool = False, bn: Optional[BatchNormFinish] = None) -> None:
+    """direct=True forbids the Winograd form of the 3x3 fast path (bit-exact direct summation).
+    bn: finalize the BatchNorm statistics inside this call (stats_partial then is workspace of gemm_stats_rows() rows)."""
     if len(ins) > MAX_VIEWS or len(outs) > MAX_VIEWS:
         raise ValueError("too many views")
     d = GemmDesc()
@@ -339,8 +363,24 @@ def gemm_fwd(n: int, h: int, w: int, taps: int, ins: Sequence[V], outs: Sequence
         raise ValueError("weight has %d elements, expected %d*%d*%d" % (weight.numel(), taps, k, nc))
     if bias is not None and _need(bias, "bias").numel() != nc:
         raise ValueError("bias length mismatch")
-    if stats_partial is not None and _need(stats_partial, "stats").numel() != gemm_pixel_blocks(n, h, w) * nc * 2:
+    rows = gemm_pixel_blocks(n, h, w) if bn is None else gemm_stats_rows(n, h, w)
+    if stats_partial is not None and _need(stats_partial, "stats").numel() != rows * nc * 2:
         raise ValueError("stats_partial size mismatch")
+    if bn is not None:
+        if stats_partial is None or len(outs) != 1:
+            raise ValueError("a fused BatchNorm finalize needs stats_partial and a single output view")
+        if bn.ticket.dtype != torch.int32 or bn.ticket.numel() < 1 or bn.ticket.device != stats_partial.device:
+            raise ValueError("bn.ticket must be a zeroed int32 word on the launch device")
+        mean, invstd, scale, shift = bn.outputs(nc)
+        for t, what in ((bn.gamma, "gamma"), (bn.beta, "beta")):
+            if _need(t, what).numel() != nc:
+                raise ValueError("BatchNorm %s length mismatch" % what)
+        d.bn.gamma, d.bn.beta = bn.gamma.data_ptr(), bn.beta.data_ptr()
+        d.bn.running_mean = None if bn.running_mean is None else _need(bn.running_mean, "running_mean").data_ptr()
+        d.bn.running_var = None if bn.running_var is None else _need(bn.running_var, "running_var").data_ptr()
+        d.bn.mean, d.bn.invstd, d.bn.scale, d.bn.shift = mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr()
+        d.bn.count, d.bn.eps, d.bn.momentum = int(bn.count), float(bn.eps), float(bn.momentum)
+        d.bn.ticket = bn.ticket.data_ptr()
     d.weight = None if from_src else weight.data_ptr()
     d.bias = None if bias is None else bias.data_ptr()
     d.stats_partial = None if stats_partial is None else stats_partial.data_ptr()
