@@ -71,11 +71,12 @@ typedef struct unetpp_view {
 /* BatchNorm2d training-mode finalize (models/unet.py:133) FUSED into the convolution launch that takes the statistics:
  * the launch leaves mean, invstd, scale = gamma * invstd, shift = beta - mean * scale ([Ncols] each) and the updated
  * running statistics behind, exactly as unetpp_bn_finalize would, without a second launch.  Inside the persistent
- * kernels every workgroup publishes ONE row of sums over all its units, takes a ticket, and the workgroup that
- * arrives last adds the rows in fixed order (fp64) and writes the coefficients (agent-scope hand-off: write-through
- * rows, device-scope ticket, acquire in the last arriver).  Kernels without that epilogue (generic shapes, more than
+ * kernels every workgroup publishes ONE row of sums over all its units and takes a ticket; the rows are added in fixed
+ * order (fp64) by the last arrivers of two levels (groups of 32 workgroups, then the groups) and the very last one
+ * writes the coefficients (agent-scope hand-off: write-through rows, device-scope tickets, acquire in the arriver).  Kernels without that epilogue (generic shapes, more than
  * 256 columns) write per-block rows and the library enqueues unetpp_bn_finalize itself: the result of the call is the
  * same either way.  scale == NULL: not fused (the caller finishes stats_partial with unetpp_bn_finalize). */
+#define UNETPP_BN_TICKET_WORDS 65
 typedef struct unetpp_bn_fused {
   const float* gamma;
   const float* beta;
@@ -87,7 +88,7 @@ typedef struct unetpp_bn_fused {
   float* shift;
   int64_t count;     /* N*H*W */
   float eps, momentum;
-  uint32_t* ticket;  /* one 32-bit word of device memory, zero before the launch; the launch leaves it zero */
+  uint32_t* ticket;  /* UNETPP_BN_TICKET_WORDS 32-bit words of device memory, zero before the launch; left zero */
 } unetpp_bn_fused;
 
 typedef struct unetpp_gemm_desc {

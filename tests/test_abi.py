@@ -73,7 +73,7 @@ def test_argument_validation_without_gpu(built_lib):
     lib = built_lib.lib()
     assert lib.unetpp_gemm_pixel_blocks(32, 256, 256) == 32 * 32 * 8
     assert lib.unetpp_gemm_pixel_blocks(0, 256, 256) == 0
-    assert lib.unetpp_gemm_stats_rows(32, 256, 256) == 32 * 32 * 8 and lib.unetpp_gemm_stats_rows(1, 64, 64) == 2048
+    assert lib.unetpp_gemm_stats_rows(32, 256, 256) == 32 * 32 * 8 and lib.unetpp_gemm_stats_rows(1, 64, 64) == 2048 + 128
     assert lib.unetpp_wgrad_max_split(1, 8, 8) == 1
     assert lib.unetpp_head_bwd_blocks(100) == 2
     assert lib.unetpp_bn_bwd_blocks(32 * 256 * 256, 32) % 8 == 0

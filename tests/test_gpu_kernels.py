@@ -115,7 +115,7 @@ def test_fused_batchnorm_finalize_matches_separate_launch(dev, shape, fold, conv
     rm_ref, rv_ref = torch.zeros(co, device=dev), torch.ones(co, device=dev)
     ref = ops.bn_finalize(part, blocks, co, count, gamma, beta, 1e-5, 0.1, rm_ref, rv_ref)
     # fused
-    ticket = torch.zeros(4, dtype=torch.int32, device=dev)
+    ticket = torch.zeros(ops.BN_TICKET_WORDS, dtype=torch.int32, device=dev)
     rm, rv = torch.zeros(co, device=dev), torch.ones(co, device=dev)
     rows = ops.gemm_stats_rows(b, h, w)
     busy = torch.randn(1 << 22, device=dev)
@@ -126,7 +126,7 @@ def test_fused_batchnorm_finalize_matches_separate_launch(dev, shape, fold, conv
         for _ in range(4):
             busy = busy * 1.0001 + 0.5      # other kernels in front of the launch: its workgroups start unevenly
         ops.gemm_fwd(b, h, w, 9, ins, [V(y)], wp, bias, workspace, bn=fin)
-        assert int(ticket[0]) == 0, rep
+        assert int(ticket.abs().sum()) == 0, rep
         assert torch.equal(y, y_ref)
         yd = y.double().view(-1, co)
         mean, var = yd.mean(0), yd.var(0, unbiased=False)

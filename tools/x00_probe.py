@@ -88,7 +88,7 @@ def block_two_launch_finalize():   # rounds 1-2: a bn_finalize launch behind eac
 
 rows_f = ops.gemm_stats_rows(B, HW, HW)
 partf1, partf2 = torch.empty(rows_f * C * 2, device=dev), torch.empty(rows_f * C * 2, device=dev)
-tick1, tick2 = torch.zeros(4, dtype=torch.int32, device=dev), torch.zeros(4, dtype=torch.int32, device=dev)
+tick1, tick2 = torch.zeros(ops.BN_TICKET_WORDS, dtype=torch.int32, device=dev), torch.zeros(ops.BN_TICKET_WORDS, dtype=torch.int32, device=dev)
 
 
 def finish(ticket):

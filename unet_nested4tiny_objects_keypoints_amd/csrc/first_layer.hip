@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kThreads) void small_cin_fwd_kernel(const SmallArgs
   __shared__ float xs2[2][kMaxHaloPixels * CIN];
   __shared__ __attribute__((aligned(16))) float ws[WREG ? 4 : 9 * CIN * kMaxCout];
   __shared__ float red[4][kMaxCout * 2];  // [wave][quad][s1 x 4, s2 x 4]
-  __shared__ double fin_scratch[(kThreads / 32) * 32 * 2 + 1];  // fused BatchNorm finalize: slice sums + the flag word
+  __shared__ unsigned fin_flag[2];  // fused BatchNorm finalize: the "last arriver" word
   const int tid = threadIdx.x;
   const bool bn_fused = a.bn_in_kernel != 0;  // uniform
   float run1 = 0.f, run2 = 0.f;               // this thread's column (tid < COUT) over all patches of the workgroup
@@ -214,8 +214,7 @@ __global__ __launch_bounds__(kThreads) void small_cin_fwd_kernel(const SmallArgs
       run[2 * tid + 1] = run2;
     }
     __syncthreads();
-    bn_fused_finish<kThreads>(a.bn, a.stats, a.COUT, run, fin_scratch,
-                              reinterpret_cast<unsigned*>(&fin_scratch[(kThreads / 32) * 32 * 2]));
+    bn_fused_finish<kThreads>(a.bn, a.stats, a.COUT, run, fin_flag);
   }
 }
 

@@ -206,7 +206,8 @@ extern "C" int64_t unetpp_gemm_pixel_blocks(int32_t N, int32_t H, int32_t W) {
 extern "C" int64_t unetpp_gemm_stats_rows(int32_t N, int32_t H, int32_t W) {
   const int64_t blocks = unetpp_gemm_pixel_blocks(N, H, W);
   if (blocks <= 0) return 0;
-  return blocks > kBnFusedRows ? blocks : kBnFusedRows;
+  const int64_t ws = kBnFusedRows + kBnFusedGroupRowsAsRows;  // per-workgroup rows + the fp64 group rows (bn_fused.h)
+  return blocks > ws ? blocks : ws;
 }
 
 namespace {

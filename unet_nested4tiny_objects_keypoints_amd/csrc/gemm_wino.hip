@@ -120,7 +120,9 @@ __device__ unsigned long long g_wino_stamps[16];
 
 // NH = 16-column halves of the tile that are computed: 2, or 1 when no output view is wider than 16 channels (narrow
 // networks, e.g. the reference's default base width 16) -- the second half would multiply zero weights.
-template <int LOG2TW, int NH, int MODE>
+// BNF: the BatchNorm finalize runs inside this launch (bn_fused.h); an instantiation of its own, so that the 30 launches
+// of a step without statistics keep their registers (the runtime switch cost 8 more scalar spills and 5 % of the kernel)
+template <int LOG2TW, int NH, int MODE, bool BNF = false>
 __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a) {
   constexpr bool LEAN = MODE != 0, FOLD = MODE == 2;
   constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;
@@ -142,21 +144,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   // the four waves' BatchNorm partial sums of the unit just finished; then (fused finalize, bn_fused.h) the sums of ALL
   // units of this workgroup per column, and the "I am the last arriver" word -- one object: see bn_fused.h on LDS objects
   constexpr int RUN0 = 4 * WNC * 2, FLAG0 = RUN0 + kBnFusedMaxCols * 2;
-  __shared__ float stat_lds[FLAG0 + 4];
+  __shared__ float stat_lds[BNF ? FLAG0 + 4 : RUN0];
 
   const unetpp_gemm_desc& d = a.d;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, t16 = lane & 15, g = lane >> 4;
 
   const UnitRange ur = my_contiguous_unit_range(a.total_blocks);
-  const bool bn_fused = a.bn_in_kernel != 0;  // uniform
-  if (bn_fused) {
+  constexpr bool bn_fused = BNF;
+  if constexpr (BNF) {
     for (int i = tid; i < kBnFusedMaxCols * 2; i += kThreads) stat_lds[RUN0 + i] = 0.f;  // (a barrier follows in the prologue)
   }
   if (ur.count == 0) {  // (cannot happen with the launcher's grids; every workgroup must take its ticket all the same)
-    if (bn_fused) {
+    if constexpr (BNF) {
       __syncthreads();
-      bn_fused_finish<kThreads>(a.d.bn, a.d.stats_partial, a.Ncols, stat_lds + RUN0, reinterpret_cast<double*>(smem),
+      bn_fused_finish<kThreads>(a.d.bn, a.d.stats_partial, a.Ncols, stat_lds + RUN0,
                                 reinterpret_cast<unsigned*>(stat_lds + FLAG0));
     }
     return;
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       t1 += stat_lds[(w * WNC + tid) * 2 + 0];
       t2 += stat_lds[(w * WNC + tid) * 2 + 1];
     }
-    if (bn_fused) {  // column n0 + tid is always this thread's: a plain read-modify-write
+    if constexpr (bn_fused) {  // column n0 + tid is always this thread's: a plain read-modify-write
       stat_lds[RUN0 + (tc.n0 + tid) * 2 + 0] += t1;
       stat_lds[RUN0 + (tc.n0 + tid) * 2 + 1] += t2;
       return;
@@ -780,10 +782,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     atomicAdd(&g_wino_stamps[8], 1ull);
   }
 #endif
-  if (bn_fused) {
-    __syncthreads();  // the last unit's sums are in; the staging buffers are free (scratch of the finalize)
-    bn_fused_finish<kThreads>(d.bn, d.stats_partial, a.Ncols, stat_lds + RUN0, reinterpret_cast<double*>(smem),
-                              reinterpret_cast<unsigned*>(stat_lds + FLAG0));
+  if constexpr (BNF) {
+    __syncthreads();  // the last unit's sums are in
+    bn_fused_finish<kThreads>(d.bn, d.stats_partial, a.Ncols, stat_lds + RUN0, reinterpret_cast<unsigned*>(stat_lds + FLAG0));
   }
 }
 
@@ -809,7 +810,6 @@ int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
   FastArgs a;
   if (!wino_applies(d) || !fast_args(d, a, WKC, WNC) || d->weight_image == nullptr) return UNETPP_EINVAL;
   if (d->stats_partial != nullptr && d->n_out != 1) return UNETPP_EINVAL;
-  a.bn_in_kernel = bn_fused_in_kernel(d, a.Ncols) ? 1 : 0;
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess ||
       hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
@@ -832,9 +832,12 @@ int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
     fold = fold || v.scale != nullptr || v.relu != 0;
   }
   const int mode = !lean ? 0 : (fold ? 2 : 1);
+  a.bn_in_kernel = (mode != 0 && bn_fused_in_kernel(d, a.Ncols)) ? 1 : 0;  // (the general kernel: trailing finalize launch)
 #define UNETPP_LAUNCH_WINO_M(L, NHV)                                                                    \
   do {                                                                                                  \
     if (mode == 0) hipLaunchKernelGGL((gemm_wino_kernel<L, NHV, 0>), grid, block, 0, st, a);            \
+    else if (a.bn_in_kernel && mode == 1) hipLaunchKernelGGL((gemm_wino_kernel<L, NHV, 1, true>), grid, block, 0, st, a); \
+    else if (a.bn_in_kernel) hipLaunchKernelGGL((gemm_wino_kernel<L, NHV, 2, true>), grid, block, 0, st, a);             \
     else if (mode == 1) hipLaunchKernelGGL((gemm_wino_kernel<L, NHV, 1>), grid, block, 0, st, a);       \
     else hipLaunchKernelGGL((gemm_wino_kernel<L, NHV, 2>), grid, block, 0, st, a);                      \
   } while (0)

@@ -115,7 +115,7 @@ def _ticket_of(bn, device):
     BatchNorm layer and device, kept outside the state dict."""
     t = bn.__dict__.get("_unetpp_ticket")
     if t is None or t.device != device:
-        t = torch.zeros(4, dtype=torch.int32, device=device)
+        t = torch.zeros(ops.BN_TICKET_WORDS, dtype=torch.int32, device=device)
         bn.__dict__["_unetpp_ticket"] = t
     return t
 

@@ -320,6 +320,9 @@ def gemm_pixel_blocks(n: int, h: int, w: int) -> int:
     return int(_lib.lib().unetpp_gemm_pixel_blocks(n, h, w))
 
 
+BN_TICKET_WORDS = 65  # UNETPP_BN_TICKET_WORDS
+
+
 @dataclass
 class BatchNormFinish:
     """BatchNorm finalize fused into the convolution launch that takes the statistics (struct unetpp_bn_fused): the
@@ -331,7 +334,7 @@ class BatchNormFinish:
     eps: float
     momentum: float
     count: int
-    ticket: torch.Tensor   # one zeroed int32 word on the device (the launch leaves it zero)
+    ticket: torch.Tensor   # BN_TICKET_WORDS zeroed int32 words on the device (the launch leaves them zero)
 
     def outputs(self, c: int):
         dev = self.gamma.device
@@ -369,8 +372,8 @@ def gemm_fwd(n: int, h: int, w: int, taps: int, ins: Sequence[V], outs: Sequence
     if bn is not None:
         if stats_partial is None or len(outs) != 1:
             raise ValueError("a fused BatchNorm finalize needs stats_partial and a single output view")
-        if bn.ticket.dtype != torch.int32 or bn.ticket.numel() < 1 or bn.ticket.device != stats_partial.device:
-            raise ValueError("bn.ticket must be a zeroed int32 word on the launch device")
+        if bn.ticket.dtype != torch.int32 or bn.ticket.numel() < BN_TICKET_WORDS or bn.ticket.device != stats_partial.device:
+            raise ValueError("bn.ticket must be %d zeroed int32 words on the launch device" % BN_TICKET_WORDS)
         mean, invstd, scale, shift = bn.outputs(nc)
         for t, what in ((bn.gamma, "gamma"), (bn.beta, "beta")):
             if _need(t, what).numel() != nc:
