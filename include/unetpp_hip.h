@@ -68,15 +68,13 @@ typedef struct unetpp_view {
                               * shift, stats_partial and slabs stay fp32; the arithmetic is v_mfma_f32_32x32x16_bf16
                               * with fp32 accumulation (BASELINE configs[3]/[4]).  There is no generic bf16 kernel:
                               * a descriptor the MFMA kernels cannot take returns UNETPP_EINVAL. */
-/* BatchNorm2d training-mode finalize (models/unet.py:133) FUSED into the convolution launch that takes the statistics:
- * the launch leaves mean, invstd, scale = gamma * invstd, shift = beta - mean * scale ([Ncols] each) and the updated
- * running statistics behind, exactly as unetpp_bn_finalize would, without a second launch.  Inside the persistent
- * kernels every workgroup publishes ONE row of sums over all its units and takes a ticket; the rows are added in fixed
- * order (fp64) by the last arrivers of two levels (groups of 32 workgroups, then the groups) and the very last one
- * writes the coefficients (agent-scope hand-off: write-through rows, device-scope tickets, acquire in the arriver).  Kernels without that epilogue (generic shapes, more than
- * 256 columns) write per-block rows and the library enqueues unetpp_bn_finalize itself: the result of the call is the
- * same either way.  scale == NULL: not fused (the caller finishes stats_partial with unetpp_bn_finalize). */
-#define UNETPP_BN_TICKET_WORDS 65
+/* BatchNorm2d training-mode finalize (models/unet.py:133) attached to the convolution call that takes the statistics:
+ * the call leaves mean, invstd, scale = gamma * invstd, shift = beta - mean * scale ([Ncols] each) and the updated
+ * running statistics behind, exactly as a unetpp_bn_finalize call of the caller would.  The persistent kernels then
+ * write ONE row of sums per workgroup (all its units; <= 2048 rows instead of one per 256-pixel block) and the library
+ * enqueues the finalize over those rows itself; kernels without that epilogue (generic shapes, more than 256
+ * columns) keep per-block rows.  Same result up to the row partition of the fp32 sums.
+ * scale == NULL: not attached (the caller finishes stats_partial with unetpp_bn_finalize). */
 typedef struct unetpp_bn_fused {
   const float* gamma;
   const float* beta;
@@ -88,7 +86,6 @@ typedef struct unetpp_bn_fused {
   float* shift;
   int64_t count;     /* N*H*W */
   float eps, momentum;
-  uint32_t* ticket;  /* UNETPP_BN_TICKET_WORDS 32-bit words of device memory, zero before the launch; left zero */
 } unetpp_bn_fused;
 
 typedef struct unetpp_gemm_desc {
@@ -109,7 +106,7 @@ typedef struct unetpp_gemm_desc {
   /* optional fast path: `weight` re-laid as the kernel's LDS image by unetpp_gemm_pack_weight_image
    * (unetpp_gemm_weight_image_floats() floats).  NULL selects the generic kernel. */
   const float* weight_image;
-  unetpp_bn_fused bn; /* bn.scale != NULL: finalize the statistics inside this call (needs stats_partial) */
+  unetpp_bn_fused bn; /* bn.scale != NULL: finish the statistics inside this call (needs stats_partial) */
 } unetpp_gemm_desc;
 
 /* weight gradient:  dW[tap][k][n] = sum_p x[p (+) tap, k] * dy[p, n]  (+ db[n] = sum_p dy[p, n]).

@@ -54,7 +54,7 @@ def test_struct_layout_matches_header(built_lib, tmp_path):
                    'offsetof(unetpp_gemm_desc, weight_image), sizeof(unetpp_wgrad_desc), offsetof(unetpp_wgrad_desc, dy),'
                    'offsetof(unetpp_wgrad_desc, slabs), sizeof(unetpp_weight_src), offsetof(unetpp_weight_src, k_inner),'
                    'sizeof(unetpp_pack_job), offsetof(unetpp_pack_job, image), offsetof(unetpp_pack_job, out_len),'
-                   'sizeof(unetpp_bn_fused), offsetof(unetpp_bn_fused, count), offsetof(unetpp_bn_fused, ticket),'
+                   'sizeof(unetpp_bn_fused), offsetof(unetpp_bn_fused, count), offsetof(unetpp_bn_fused, momentum),'
                    'offsetof(unetpp_gemm_desc, bn));return 0;}')
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
@@ -64,7 +64,7 @@ def test_struct_layout_matches_header(built_lib, tmp_path):
             L.GemmDesc.out.offset, L.GemmDesc.weight_image.offset, ctypes.sizeof(L.WgradDesc), L.WgradDesc.dy.offset,
             L.WgradDesc.slabs.offset, ctypes.sizeof(L.WeightSrc), L.WeightSrc.k_inner.offset, ctypes.sizeof(L.PackJob),
             L.PackJob.image.offset, L.PackJob.out_len.offset, ctypes.sizeof(L.BnFused), L.BnFused.count.offset,
-            L.BnFused.ticket.offset, L.GemmDesc.bn.offset]
+            L.BnFused.momentum.offset, L.GemmDesc.bn.offset]
     assert got == want
 
 
@@ -73,7 +73,7 @@ def test_argument_validation_without_gpu(built_lib):
     lib = built_lib.lib()
     assert lib.unetpp_gemm_pixel_blocks(32, 256, 256) == 32 * 32 * 8
     assert lib.unetpp_gemm_pixel_blocks(0, 256, 256) == 0
-    assert lib.unetpp_gemm_stats_rows(32, 256, 256) == 32 * 32 * 8 and lib.unetpp_gemm_stats_rows(1, 64, 64) == 2048 + 128
+    assert lib.unetpp_gemm_stats_rows(32, 256, 256) == 32 * 32 * 8 and lib.unetpp_gemm_stats_rows(1, 64, 64) == 2048
     assert lib.unetpp_wgrad_max_split(1, 8, 8) == 1
     assert lib.unetpp_head_bwd_blocks(100) == 2
     assert lib.unetpp_bn_bwd_blocks(32 * 256 * 256, 32) % 8 == 0

@@ -42,7 +42,7 @@ class BnFused(C.Structure):
     _fields_ = [
         ("gamma", C.c_void_p), ("beta", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
         ("mean", C.c_void_p), ("invstd", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
-        ("count", C.c_int64), ("eps", C.c_float), ("momentum", C.c_float), ("ticket", C.c_void_p),
+        ("count", C.c_int64), ("eps", C.c_float), ("momentum", C.c_float),
     ]
 
 

@@ -108,9 +108,9 @@ inline int launch_status() { return hipGetLastError() == hipSuccess ? UNETPP_OK 
 
 // remembers the kernel a dispatch chose (unetpp_last_kernel_name); defined in gemm_pix.hip
 void note_kernel(const char* name);
-// a launcher tells unetpp_gemm_fwd that its kernel finalizes the BatchNorm statistics itself (bn_fused.h); otherwise
-// the dispatcher enqueues unetpp_bn_finalize behind the launch.  Thread-local, like the kernel name.
-void note_bn_fused();
+// a launcher tells unetpp_gemm_fwd how many rows of BatchNorm partial sums its kernel wrote (bn_fused.h: one per
+// workgroup); without the note the dispatcher assumes one row per 256-pixel block.  Thread-local, like the kernel name.
+void note_bn_rows(long rows);
 
 // gemm_fast.hip: register-prefetched kernel for plain aligned views (needs d->weight_image)
 int launch_gemm_fast(const unetpp_gemm_desc* d, hipStream_t st);

@@ -28,8 +28,7 @@ struct SmallArgs {
   int N, H, W, COUT, yC, relu;
   int log2tw, tiles_x, tiles_y;
   long n_patches;
-  int bn_in_kernel;    // forward: rows are per workgroup and the last arriver finalizes the BatchNorm (bn_fused.h)
-  unetpp_bn_fused bn;
+  int bn_in_kernel;    // forward: the BatchNorm partial rows are per workgroup (bn_fused.h)
 };
 
 template <int CIN>
@@ -59,7 +58,6 @@ __global__ __launch_bounds__(kThreads) void small_cin_fwd_kernel(const SmallArgs
   __shared__ float xs2[2][kMaxHaloPixels * CIN];
   __shared__ __attribute__((aligned(16))) float ws[WREG ? 4 : 9 * CIN * kMaxCout];
   __shared__ float red[4][kMaxCout * 2];  // [wave][quad][s1 x 4, s2 x 4]
-  __shared__ unsigned fin_flag[2];  // fused BatchNorm finalize: the "last arriver" word
   const int tid = threadIdx.x;
   const bool bn_fused = a.bn_in_kernel != 0;  // uniform
   float run1 = 0.f, run2 = 0.f;               // this thread's column (tid < COUT) over all patches of the workgroup
@@ -214,7 +212,7 @@ __global__ __launch_bounds__(kThreads) void small_cin_fwd_kernel(const SmallArgs
       run[2 * tid + 1] = run2;
     }
     __syncthreads();
-    bn_fused_finish<kThreads>(a.bn, a.stats, a.COUT, run, fin_flag);
+    bn_rows_store<kThreads>(a.stats, a.COUT, run);
   }
 }
 
@@ -341,8 +339,7 @@ int launch_small_cin_fwd(const unetpp_gemm_desc* d, hipStream_t st) {
   long workers = static_cast<long>(cus) * (X.C == 4 ? 3 : 4);
   if (workers > kBnFusedRows) workers = kBnFusedRows;
   const dim3 grid(static_cast<unsigned>(a.n_patches < workers ? a.n_patches : workers)), block(kThreads);
-  a.bn_in_kernel = bn_fused_in_kernel(d, a.COUT) ? 1 : 0;
-  a.bn = d->bn;
+  a.bn_in_kernel = bn_rows_per_workgroup(d, a.COUT) ? 1 : 0;
 #define UNETPP_SMALL_FWD(B)                                                                          \
   switch (X.C) {                                                                                     \
     case 1: hipLaunchKernelGGL((small_cin_fwd_kernel<1, B>), grid, block, 0, st, a); break;          \
@@ -357,7 +354,7 @@ int launch_small_cin_fwd(const unetpp_gemm_desc* d, hipStream_t st) {
   }
 #undef UNETPP_SMALL_FWD
   note_kernel("small_cin_fwd_kernel");
-  if (a.bn_in_kernel) note_bn_fused();
+  if (a.bn_in_kernel) note_bn_rows(grid.x);
   return launch_status();
 }
 

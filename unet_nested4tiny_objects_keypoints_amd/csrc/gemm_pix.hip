@@ -188,9 +188,9 @@ namespace unetpp {
 namespace {
 thread_local const char* g_last_kernel = "";
 }
-thread_local bool g_bn_fused_done = false;
+thread_local long g_bn_rows = 0;
 void note_kernel(const char* name) { g_last_kernel = name; }
-void note_bn_fused() { g_bn_fused_done = true; }
+void note_bn_rows(long rows) { g_bn_rows = rows; }
 }  // namespace unetpp
 
 using namespace unetpp;
@@ -206,8 +206,7 @@ extern "C" int64_t unetpp_gemm_pixel_blocks(int32_t N, int32_t H, int32_t W) {
 extern "C" int64_t unetpp_gemm_stats_rows(int32_t N, int32_t H, int32_t W) {
   const int64_t blocks = unetpp_gemm_pixel_blocks(N, H, W);
   if (blocks <= 0) return 0;
-  const int64_t ws = kBnFusedRows + kBnFusedGroupRowsAsRows;  // per-workgroup rows + the fp64 group rows (bn_fused.h)
-  return blocks > ws ? blocks : ws;
+  return blocks > kBnFusedRows ? blocks : kBnFusedRows;  // per-workgroup rows (bn_fused.h) or per-block rows
 }
 
 namespace {
@@ -218,17 +217,17 @@ extern "C" int unetpp_gemm_fwd(const unetpp_gemm_desc* d, void* stream) {
   if (d == nullptr || d->N <= 0 || d->H <= 0 || d->W <= 0) return UNETPP_EINVAL;
   const unetpp_bn_fused& bn = d->bn;
   if (bn.scale == nullptr) return gemm_fwd_dispatch(d, stream);
-  // BatchNorm finalize fused into this call: in the kernel's last-arriving workgroup where the kernel can, else by a
-  // unetpp_bn_finalize launch behind it (per-block rows); same results up to the row partition of the fp32 sums
-  if (!d->stats_partial || !bn.gamma || !bn.beta || !bn.mean || !bn.invstd || !bn.shift || !bn.ticket || bn.count < 1 ||
+  // BatchNorm finalize attached to this call: over the kernel's per-workgroup rows where it writes those (bn_fused.h),
+  // else over per-block rows
+  if (!d->stats_partial || !bn.gamma || !bn.beta || !bn.mean || !bn.invstd || !bn.shift || bn.count < 1 ||
       (bn.running_mean == nullptr) != (bn.running_var == nullptr) || d->n_out != 1)
     return UNETPP_EINVAL;
-  g_bn_fused_done = false;
+  g_bn_rows = 0;
   const int rc = gemm_fwd_dispatch(d, stream);
-  if (rc != UNETPP_OK || g_bn_fused_done) return rc;
-  return unetpp_bn_finalize(d->stats_partial, unetpp_gemm_pixel_blocks(d->N, d->H, d->W), d->out[0].c_len, bn.count, bn.gamma,
-                            bn.beta, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.mean, bn.invstd, bn.scale,
-                            bn.shift, stream);
+  if (rc != UNETPP_OK) return rc;
+  const int64_t rows = g_bn_rows > 0 ? g_bn_rows : unetpp_gemm_pixel_blocks(d->N, d->H, d->W);
+  return unetpp_bn_finalize(d->stats_partial, rows, d->out[0].c_len, bn.count, bn.gamma, bn.beta, bn.eps, bn.momentum,
+                            bn.running_mean, bn.running_var, bn.mean, bn.invstd, bn.scale, bn.shift, stream);
 }
 
 namespace {

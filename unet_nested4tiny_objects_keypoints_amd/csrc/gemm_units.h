@@ -10,7 +10,7 @@ struct FastArgs {
   int Ktot, Ncols, n_tiles, n_chunks;
   int nt_unit, n_groups;  // column tiles per unit of work, units per pixel patch (n_tiles / nt_unit)
   long total_blocks;
-  int bn_in_kernel;  // the BatchNorm finalize runs in the last-arriving workgroup (bn_fused.h); rows are per workgroup
+  int bn_in_kernel;  // the BatchNorm partial rows are per workgroup, not per pixel block (bn_fused.h)
 };
 
 // 32-bit element offset of a view pixel (the fast kernels only take tensors below 2^31 elements)

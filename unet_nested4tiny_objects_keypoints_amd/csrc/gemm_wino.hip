@@ -120,8 +120,8 @@ __device__ unsigned long long g_wino_stamps[16];
 
 // NH = 16-column halves of the tile that are computed: 2, or 1 when no output view is wider than 16 channels (narrow
 // networks, e.g. the reference's default base width 16) -- the second half would multiply zero weights.
-// BNF: the BatchNorm finalize runs inside this launch (bn_fused.h); an instantiation of its own, so that the 30 launches
-// of a step without statistics keep their registers (the runtime switch cost 8 more scalar spills and 5 % of the kernel)
+// BNF: the BatchNorm partial sums go out as ONE row per workgroup (bn_fused.h); an instantiation of its own, so that the
+// 30 launches of a step without statistics keep their registers (a runtime switch cost 8 more scalar spills and 5 %)
 template <int LOG2TW, int NH, int MODE, bool BNF = false>
 __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a) {
   constexpr bool LEAN = MODE != 0, FOLD = MODE == 2;
@@ -141,10 +141,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
   float* in_tile = smem;             // buffers of the chunk being computed
   float* w_tile = smem + IN_FLOATS;
-  // the four waves' BatchNorm partial sums of the unit just finished; then (fused finalize, bn_fused.h) the sums of ALL
-  // units of this workgroup per column, and the "I am the last arriver" word -- one object: see bn_fused.h on LDS objects
-  constexpr int RUN0 = 4 * WNC * 2, FLAG0 = RUN0 + kBnFusedMaxCols * 2;
-  __shared__ float stat_lds[BNF ? FLAG0 + 4 : RUN0];
+  // the four waves' BatchNorm partial sums of the unit just finished; then (BNF) the sums of ALL units of this workgroup
+  // per column
+  constexpr int RUN0 = 4 * WNC * 2;
+  __shared__ float stat_lds[BNF ? RUN0 + kBnFusedMaxCols * 2 : RUN0];
 
   const unetpp_gemm_desc& d = a.d;
   const int tid = threadIdx.x;
@@ -155,11 +155,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   if constexpr (BNF) {
     for (int i = tid; i < kBnFusedMaxCols * 2; i += kThreads) stat_lds[RUN0 + i] = 0.f;  // (a barrier follows in the prologue)
   }
-  if (ur.count == 0) {  // (cannot happen with the launcher's grids; every workgroup must take its ticket all the same)
+  if (ur.count == 0) {  // (cannot happen with the launcher's grids; the workgroup's row must exist all the same)
     if constexpr (BNF) {
       __syncthreads();
-      bn_fused_finish<kThreads>(a.d.bn, a.d.stats_partial, a.Ncols, stat_lds + RUN0,
-                                reinterpret_cast<unsigned*>(stat_lds + FLAG0));
+      bn_rows_store<kThreads>(a.d.stats_partial, a.Ncols, stat_lds + RUN0);
     }
     return;
   }
@@ -784,7 +783,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 #endif
   if constexpr (BNF) {
     __syncthreads();  // the last unit's sums are in
-    bn_fused_finish<kThreads>(d.bn, d.stats_partial, a.Ncols, stat_lds + RUN0, reinterpret_cast<unsigned*>(stat_lds + FLAG0));
+    bn_rows_store<kThreads>(d.stats_partial, a.Ncols, stat_lds + RUN0);
   }
 }
 
@@ -832,7 +831,7 @@ int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
     fold = fold || v.scale != nullptr || v.relu != 0;
   }
   const int mode = !lean ? 0 : (fold ? 2 : 1);
-  a.bn_in_kernel = (mode != 0 && bn_fused_in_kernel(d, a.Ncols)) ? 1 : 0;  // (the general kernel: trailing finalize launch)
+  a.bn_in_kernel = (mode != 0 && bn_rows_per_workgroup(d, a.Ncols)) ? 1 : 0;  // (the general kernel: per-block rows)
 #define UNETPP_LAUNCH_WINO_M(L, NHV)                                                                    \
   do {                                                                                                  \
     if (mode == 0) hipLaunchKernelGGL((gemm_wino_kernel<L, NHV, 0>), grid, block, 0, st, a);            \
@@ -852,7 +851,7 @@ int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
 #undef UNETPP_LAUNCH_WINO
 #undef UNETPP_LAUNCH_WINO_M
   note_kernel("gemm_wino_kernel");
-  if (a.bn_in_kernel) note_bn_fused();
+  if (a.bn_in_kernel) note_bn_rows(grid.x);
   return launch_status();
 }
 

@@ -110,26 +110,16 @@ def flush_batch_counters():
         _PENDING_COUNTERS.clear()
 
 
-def _ticket_of(bn, device):
-    """The zeroed int32 word the fused finalize counts arriving workgroups in (left zero by every launch); one per
-    BatchNorm layer and device, kept outside the state dict."""
-    t = bn.__dict__.get("_unetpp_ticket")
-    if t is None or t.device != device:
-        t = torch.zeros(ops.BN_TICKET_WORDS, dtype=torch.int32, device=device)
-        bn.__dict__["_unetpp_ticket"] = t
-    return t
-
-
 def _conv_bn_fwd(ins, conv, bn, y, b, h, w, training):
     """conv3x3 + bias -> y, with the BatchNorm partial sums taken in the GEMM epilogue (training)."""
     co = conv.out_channels
     wp = pack_conv_fwd(conv.weight.detach())
     if training:
-        # the statistics are finished INSIDE the convolution launch (ops.BatchNormFinish: last-arriving workgroup of the
-        # persistent kernels, a trailing finalize launch enqueued by the library for the others)
+        # the statistics are finished by the convolution call itself (ops.BatchNormFinish: the persistent kernels write one
+        # row of sums per workgroup -- 512 or 1024 instead of 8192 for a level-0 layer -- and the library enqueues the finalize)
         partial = _empty(ops.gemm_stats_rows(b, h, w) * co * 2, y)
         fin = ops.BatchNormFinish(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps,
-                                  bn.momentum, b * h * w, _ticket_of(bn, y.device))
+                                  bn.momentum, b * h * w)
         ops.gemm_fwd(b, h, w, 9, ins, [V(y)], wp, conv.bias.detach(), partial, bn=fin)
         _PENDING_COUNTERS.append(bn.num_batches_tracked)
         return (fin.mean, fin.invstd, fin.scale, fin.shift)

@@ -320,13 +320,11 @@ def gemm_pixel_blocks(n: int, h: int, w: int) -> int:
     return int(_lib.lib().unetpp_gemm_pixel_blocks(n, h, w))
 
 
-BN_TICKET_WORDS = 65  # UNETPP_BN_TICKET_WORDS
-
-
 @dataclass
 class BatchNormFinish:
-    """BatchNorm finalize fused into the convolution launch that takes the statistics (struct unetpp_bn_fused): the
-    launch leaves mean / invstd / scale / shift and the updated running statistics behind -- no bn_finalize launch."""
+    """BatchNorm finalize attached to the convolution call that takes the statistics (struct unetpp_bn_fused): the call
+    leaves mean / invstd / scale / shift and the updated running statistics behind; the persistent kernels write one
+    row of sums per workgroup and the library finishes those few rows itself."""
     gamma: torch.Tensor
     beta: torch.Tensor
     running_mean: Optional[torch.Tensor]
@@ -334,7 +332,6 @@ class BatchNormFinish:
     eps: float
     momentum: float
     count: int
-    ticket: torch.Tensor   # BN_TICKET_WORDS zeroed int32 words on the device (the launch leaves them zero)
 
     def outputs(self, c: int):
         dev = self.gamma.device
@@ -372,8 +369,6 @@ def gemm_fwd(n: int, h: int, w: int, taps: int, ins: Sequence[V], outs: Sequence
     if bn is not None:
         if stats_partial is None or len(outs) != 1:
             raise ValueError("a fused BatchNorm finalize needs stats_partial and a single output view")
-        if bn.ticket.dtype != torch.int32 or bn.ticket.numel() < BN_TICKET_WORDS or bn.ticket.device != stats_partial.device:
-            raise ValueError("bn.ticket must be %d zeroed int32 words on the launch device" % BN_TICKET_WORDS)
         mean, invstd, scale, shift = bn.outputs(nc)
         for t, what in ((bn.gamma, "gamma"), (bn.beta, "beta")):
             if _need(t, what).numel() != nc:
@@ -383,7 +378,7 @@ def gemm_fwd(n: int, h: int, w: int, taps: int, ins: Sequence[V], outs: Sequence
         d.bn.running_var = None if bn.running_var is None else _need(bn.running_var, "running_var").data_ptr()
         d.bn.mean, d.bn.invstd, d.bn.scale, d.bn.shift = mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr()
         d.bn.count, d.bn.eps, d.bn.momentum = int(bn.count), float(bn.eps), float(bn.momentum)
-        d.bn.ticket = bn.ticket.data_ptr()
+
     d.weight = None if from_src else weight.data_ptr()
     d.bias = None if bias is None else bias.data_ptr()
     d.stats_partial = None if stats_partial is None else stats_partial.data_ptr()
