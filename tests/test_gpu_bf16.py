@@ -81,7 +81,101 @@ def test_conv3x3_bf16_forward(dev, b, h, w, cins, cout, affine):
     yd = y.double().cpu()
     close_f32(part[:, 0], yd.sum((0, 1, 2)), 1e-4, "sum")
     close_f32(part[:, 1], (yd * yd).sum((0, 1, 2)), 1e-4, "sum of squares")
-    assert ops._lib.lib().unetpp_last_kernel_name() == b"gemm_bf16_kernel<9>"
+    assert ops._lib.lib().unetpp_last_kernel_name() in (b"gemm_bf16_kernel<9>", b"gemm_bf16_dma_kernel<9>")
+
+
+def _both_kernels(fn):
+    """run fn() with the LDS-DMA kernel (default where it applies) and with the register-staged one; -> results, names"""
+    import os
+
+    from unet_nested4tiny_objects_keypoints_amd import ops
+    out = []
+    for off in (False, True):
+        if off:
+            os.environ["UNETPP_BF16_NO_DMA"] = "1"
+        try:
+            res = fn()
+            torch.cuda.synchronize()
+            out.append((res, ops._lib.lib().unetpp_last_kernel_name()))
+        finally:
+            os.environ.pop("UNETPP_BF16_NO_DMA", None)
+    return out
+
+
+@pytest.mark.parametrize("b,h,w,cins,cout", [
+    (2, 40, 72, (32,), 32),            # level-0 shape class: one chunk per unit, interior + ragged border patches
+    (1, 24, 40, (64, 32, 32), 64),     # dense-skip concatenation, two column groups
+    (3, 16, 16, (32, 32), 96),         # 16 x 16 patches
+    (2, 8, 8, (128,), 32),             # 8 x 32 patches, four chunks
+    (1, 70, 33, (32,), 64),            # odd sizes
+])
+@pytest.mark.parametrize("mode", ["relu", "stats", "dgrad"])
+def test_bf16_dma_and_register_kernels_agree(dev, b, h, w, cins, cout, mode):
+    """gemm_bf16_dma.hip (both operands by LDS-DMA, hardware zero padding, permuted LDS layout) against gemm_bf16.hip on
+    the same launch: bit-identical outputs and BatchNorm partial sums, for forward (ReLU / statistics epilogue) and for
+    the input-gradient form (store, accumulate, gate, gate of the sum into several views)."""
+    from unet_nested4tiny_objects_keypoints_amd import engine, ops
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    g = torch.Generator().manual_seed(31)
+    xs = [torch.randn(b, h, w, c, generator=g).to(BF).to(dev) for c in cins]
+    if mode == "dgrad":   # K = cout -> the views of cins
+        wt = (torch.randn(cout, sum(cins), 3, 3, generator=g) * 0.05).to(dev)
+        dy = torch.randn(b, h, w, cout, generator=g).to(BF).to(dev)
+        old = [torch.randn(b, h, w, c, generator=g).to(BF).to(dev) for c in cins]
+        gates = [torch.randn(b, h, w, c, generator=g).to(BF).to(dev) for c in cins]
+
+        def run():
+            outs = [o.clone() for o in old]
+            views = []
+            for i, o in enumerate(outs):
+                kind = i % 4
+                views.append(V(o) if kind == 0 else V(o, accumulate=True) if kind == 1 else
+                             V(o, accumulate=True, gate=gates[i], gate_sum=True) if kind == 2 else V(o, gate=gates[i]))
+            ops.gemm_fwd(b, h, w, 9, [V(dy)], views, engine.pack_conv_dgrad(wt))
+            return outs
+    else:
+        wt = (torch.randn(cout, sum(cins), 3, 3, generator=g) * (2.0 / (9 * sum(cins))) ** 0.5).to(dev)
+        bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+
+        def run():
+            y = torch.full((b, h, w, cout), float("nan"), dtype=BF, device=dev)
+            part = None
+            if mode == "stats":
+                part = torch.zeros(ops.gemm_pixel_blocks(b, h, w) * cout * 2, device=dev)
+            ops.gemm_fwd(b, h, w, 9, [V(x) for x in xs], [V(y, relu=(mode == "relu"))], engine.pack_conv_fwd(wt), bias, part)
+            return [y] + ([part] if part is not None else [])
+    (dma, dma_name), (reg, reg_name) = _both_kernels(run)
+    assert dma_name == b"gemm_bf16_dma_kernel<9>" and reg_name == b"gemm_bf16_kernel<9>"
+    for a_, b_ in zip(dma, reg):
+        assert torch.equal(a_.view(torch.int16) if a_.dtype == BF else a_, b_.view(torch.int16) if b_.dtype == BF else b_)
+
+
+@pytest.mark.parametrize("b,hs,ws,ci,co", [(2, 12, 20, 64, 32), (1, 32, 32, 128, 64), (3, 5, 9, 32, 32)])
+def test_bf16_dma_and_register_kernels_agree_on_transposed_convolutions(dev, b, hs, ws, ci, co):
+    """the pointwise GEMMs of ConvTranspose2d(2, 2): forward into the four phase views, input gradient from them
+    (strided INPUT views: the DMA offsets carry the stride, the phase origin sits in the scalar offset)"""
+    from unet_nested4tiny_objects_keypoints_amd import engine, ops
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(b, hs, ws, ci, generator=g).to(BF).to(dev)
+    wt = (torch.randn(ci, co, 2, 2, generator=g) * 0.1).to(dev)
+    bias = (torch.randn(co, generator=g) * 0.1).to(dev)
+    d_up = torch.randn(b, 2 * hs, 2 * ws, co, generator=g).to(BF).to(dev)
+    old = torch.randn(b, hs, ws, ci, generator=g).to(BF).to(dev)
+
+    def fwd():
+        up = torch.full((b, 2 * hs, 2 * ws, co), float("nan"), dtype=BF, device=dev)
+        ops.gemm_fwd(b, hs, ws, 1, [ops.V(x)], engine._phase_views(up), engine.pack_deconv_fwd(wt), engine.tile_bias4(bias))
+        return [up]
+
+    def dgrad():
+        dx = old.clone()
+        ops.gemm_fwd(b, hs, ws, 1, engine._phase_views(d_up), [ops.V(dx, accumulate=True, gate=x, gate_sum=True)],
+                     engine.pack_deconv_dgrad(wt))
+        return [dx]
+    for fn in (fwd, dgrad):
+        (dma, dma_name), (reg, reg_name) = _both_kernels(fn)
+        assert dma_name == b"gemm_bf16_dma_kernel<1>" and reg_name == b"gemm_bf16_kernel<1>"
+        assert torch.equal(dma[0].view(torch.int16), reg[0].view(torch.int16))
 
 
 def test_conv3x3_bf16_input_gradient_targets(dev):

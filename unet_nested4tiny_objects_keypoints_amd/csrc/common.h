@@ -120,6 +120,9 @@ int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st);
 // gemm_bf16.hip: bf16-storage direct implicit GEMM (UNETPP_GEMM_BF16); needs its own weight image
 bool bf16_gemm_args(const unetpp_gemm_desc* d, struct FastArgs& a);
 int launch_gemm_bf16(const unetpp_gemm_desc* d, hipStream_t st);
+// gemm_bf16_dma.hip: the same GEMM with both operands staged by LDS-DMA (plain input views, 32-channel slices); returns 1
+// when the descriptor is not one it takes (same weight image as gemm_bf16.hip)
+int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st);
 // wgrad_bf16.hip: bf16-storage weight gradient (UNETPP_GEMM_BF16); UNETPP_EINVAL when the views do not fit
 int launch_wgrad_bf16(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_tiles_cols, int k_tiles, hipStream_t st);
 // wgrad_fast.hip: 8-wave double-buffered kernel for plain aligned views; returns 1 when it does not apply

@@ -238,7 +238,10 @@ int gemm_fwd_dispatch(const unetpp_gemm_desc* d, void* stream) {
   if (d->weight == nullptr && d->weight_image == nullptr) return UNETPP_EINVAL;
   if (d->stats_partial != nullptr && d->n_out != 1) return UNETPP_EINVAL;
   if (d->flags & UNETPP_GEMM_BF16) {  // bf16 storage: the MFMA kernel, or the VALU first layer (fp32 input, bf16 output)
-    if (d->weight_image != nullptr) return launch_gemm_bf16(d, static_cast<hipStream_t>(stream));
+    if (d->weight_image != nullptr) {
+      const int dma = launch_gemm_bf16_dma(d, static_cast<hipStream_t>(stream));
+      return dma != 1 ? dma : launch_gemm_bf16(d, static_cast<hipStream_t>(stream));
+    }
     const int small = launch_small_cin_fwd(d, static_cast<hipStream_t>(stream));
     return small == 1 ? UNETPP_EINVAL : small;  // no generic bf16 kernel: unaligned views are refused
   }
