@@ -104,7 +104,7 @@ def _both_kernels(fn):
 
 @pytest.mark.parametrize("b,h,w,cins,cout", [
     (2, 40, 72, (32,), 32),            # level-0 shape class: one chunk per unit, interior + ragged border patches
-    (1, 24, 40, (64, 32, 32), 64),     # dense-skip concatenation, two column groups
+    (1, 24, 40, (64, 64, 64), 64),     # dense-skip concatenation (tensors of one level: same C), two column groups
     (3, 16, 16, (32, 32), 96),         # 16 x 16 patches
     (2, 8, 8, (128,), 32),             # 8 x 32 patches, four chunks
     (1, 70, 33, (32,), 64),            # odd sizes
