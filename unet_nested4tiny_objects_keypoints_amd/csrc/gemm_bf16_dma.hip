@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
   constexpr int WBLK = W_BYTES / 1024, NWQ = (WBLK + 3) / 4;
   static_assert(!STATS || IN_BYTES >= 4 * 4096 + 1024, "epilogue scratch + statistics rows do not fit in an input buffer");
   static_assert(2 * (IN_BYTES + W_BYTES) <= 80 * 1024, "two workgroups per CU");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (IN_BYTES + W_BYTES)];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * IN_BYTES + 2 * W_BYTES];
 
   const unetpp_gemm_desc& d = a.d;
   const int tid = threadIdx.x;
@@ -140,10 +140,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
   int p_unit = 0, p_s = 0, p_c0 = 0, p_chunk = 0;
   int p_wimg = 0;  // byte offset of the cursor's column group inside the weight image
   long p_patch = -1;
+  bool p_same_patch = false;  // the cursor's unit reads the pixel patch of the unit before it (next column group)
   auto prefetch_unit = [&]() {
     const UnitGeom& g = p_ug;
     p_wimg = g.group * NT * a.n_chunks * IMG;
-    if (g.patch == p_patch) return;  // same pixel patch (next column group): the offsets stand
+    p_same_patch = g.patch == p_patch;
+    if (p_same_patch) return;  // the offsets stand
     p_patch = g.patch;
     const unsigned img0 = static_cast<unsigned>(g.n) * static_cast<unsigned>(da.img_pitch);
 #pragma unroll
@@ -161,10 +163,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
   // of branching.  Both operands come through buffer resources with a per-lane CONSTANT vector offset and everything
   // that changes in scalar registers (hipcc waits for vmcnt(0) before it rewrites an address register pair of an
   // LDS-DMA in flight, which a 64-bit vector address per weight piece needs).
+  // LDS: input buffers 0 / 1, then weight buffers 0 / 1 (toggled separately: see the pipeline below)
   const int lane16 = lane * 16;
-  auto dma_chunk = [&](int buf) {
-    unsigned char* in_dst = smem + buf * (IN_BYTES + W_BYTES);
-    unsigned char* w_dst = in_dst + IN_BYTES;
+  auto dma_chunk = [&](int in_buf, int w_buf, bool need_in, bool need_w) {
+    unsigned char* in_dst = smem + in_buf * IN_BYTES;
+    unsigned char* w_dst = smem + 2 * IN_BYTES + w_buf * W_BYTES;
+    if (need_in) {  // uniform
     const unetpp_view& V = d.in[p_s];
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V.ptr), 0, da.view_bytes, 0x00020000);
@@ -174,6 +178,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
       const int blk = (wave + 4 * q < NBLK) ? wave + 4 * q : wave;  // uniform
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (dma_lptr_t)(in_dst + blk * 1024), 16, static_cast<int>(voff[q]), soff, 0, 0);
     }
+    }
+    if (!need_w) return;
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.weight_image), 0, da.wimg_bytes, 0x00020000);
     const int wchunk = p_wimg + p_chunk * IMG;
@@ -215,15 +221,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
   struct Frag {
     u32x4 b[NT], a0, a1;
   };
-  auto issue_frag = [&](auto sc, Frag& f, unsigned buf_base) {  // step = tap * 2 + g: channels [16g, 16g + 16) at one tap
+  auto issue_frag = [&](auto sc, Frag& f, unsigned in_base, unsigned w_base) {  // step = tap * 2 + g: channels [16g, 16g + 16) at one tap
     constexpr int step = decltype(sc)::v, tap = step >> 1, g = step & 1;
-    const unsigned wa = buf_base + static_cast<unsigned>(wb);
+    const unsigned wa = w_base + static_cast<unsigned>(wb);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      if (t == 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.b[0]) : "v"(wa), "n"(IN_BYTES + step * DSTEP));
-      else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.b[NT - 1]) : "v"(wa), "n"(IN_BYTES + IMG + step * DSTEP));
+      if (t == 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.b[0]) : "v"(wa), "n"(step * DSTEP));
+      else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.b[NT - 1]) : "v"(wa), "n"(IMG + step * DSTEP));
     }
-    const unsigned aa0 = buf_base + static_cast<unsigned>(a_off[0][tap]), aa1 = buf_base + static_cast<unsigned>(a_off[1][tap]);
+    const unsigned aa0 = in_base + static_cast<unsigned>(a_off[0][tap]), aa1 = in_base + static_cast<unsigned>(a_off[1][tap]);
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.a0) : "v"(aa0), "n"(g * 512));
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.a1) : "v"(aa1), "n"(g * 512));
   };
@@ -446,30 +452,39 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
     }
   };
 
-  // ---- pipeline: chunk c is computed from buffer c & 1 while the DMA of chunk c+1 fills the other one.  Per chunk: issue
-  // DMA(c+1); MFMAs of chunk c; wait for the DMA (before the epilogue's stores are issued: vmcnt counts in order);
-  // epilogue of a finished unit; one barrier (every wave's share of chunk c+1 has landed, nobody reads buffer c & 1 any
-  // more, the epilogue's scratch is free). ----
+  // ---- pipeline: a chunk is computed from input buffer in_cur / weight buffer w_cur while the DMA of the next chunk fills
+  // the other ones.  Per chunk: issue DMA(next); MFMAs; wait for the DMA (before the epilogue's stores are issued: vmcnt
+  // counts in order); epilogue of a finished unit; one barrier (every wave's share of the next chunk has landed, nobody
+  // reads the current buffers any more, the epilogue's scratch is free).
+  // What is NOT fetched again: the weight image when the whole launch uses one (a single chunk and a single column group:
+  // the 32 -> 32 layers of level 0) -- it stays in its buffer; the input patch when the next unit is the next column
+  // group of the same patch and a unit is one chunk (input gradients of a 32-channel dy into 64..128 channels) -- the
+  // input buffer is not toggled.  The kernel is bound by what a CU's memory pipeline moves (~10 B/clk), not by HBM. ----
+  const bool w_resident = a.n_chunks == 1 && a.n_groups == 1;   // uniform
+  const bool in_reuse = !STATS && a.n_chunks == 1;              // (the statistics epilogue uses the input buffer as scratch)
   prefetch_unit();
-  dma_chunk(0);
+  dma_chunk(0, 0, true, true);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  int c_chunk = 0, cur = 0;
+  int c_chunk = 0, in_cur = 0, w_cur = 0;
   bool more = advance();
   while (true) {
-    if (more) dma_chunk(cur ^ 1);
+    const bool need_in = more && !(in_reuse && p_same_patch), need_w = more && !w_resident;
+    if (more) dma_chunk(in_cur ^ 1, w_cur ^ 1, need_in, need_w);
     if constexpr (!STATS) {
       if (c_chunk + 1 == a.n_chunks) fetch_epilogue_operands();  // uniform
     }
-    const unsigned buf_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem)) + static_cast<unsigned>(cur) * (IN_BYTES + W_BYTES);
+    const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
+    const unsigned in_base = lds0 + static_cast<unsigned>(in_cur) * IN_BYTES;
+    const unsigned w_base = lds0 + 2 * IN_BYTES + static_cast<unsigned>(w_cur) * W_BYTES;
     Frag fr[2];
     asm volatile("" ::: "memory");  // the reads below stay behind the barrier that published this buffer
-    issue_frag(IC<0>{}, fr[0], buf_base);
+    issue_frag(IC<0>{}, fr[0], in_base, w_base);
     wait_frag(fr[0]);
     static_for<TAPS * 2>([&](auto sc) {
       constexpr int step = decltype(sc)::v, cs = step & 1, ns = cs ^ 1;
-      if constexpr (step + 1 < TAPS * 2) issue_frag(IC<step + 1>{}, fr[ns], buf_base);
+      if constexpr (step + 1 < TAPS * 2) issue_frag(IC<step + 1>{}, fr[ns], in_base, w_base);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) {
@@ -502,7 +517,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
     if (c_chunk + 1 == a.n_chunks) {
       if constexpr (STATS) {
         __syncthreads();  // the transposing epilogue uses the buffer just computed from as scratch: all waves are done with it
-        epilogue_stats(smem + cur * (IN_BYTES + W_BYTES));
+        epilogue_stats(smem + in_cur * IN_BYTES);
       } else {
         epilogue_direct();
       }
@@ -519,7 +534,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    cur ^= 1;
+    if (need_in) in_cur ^= 1;
+    if (need_w) w_cur ^= 1;
     more = advance();
   }
 }
