@@ -91,14 +91,14 @@ def _both_kernels(fn):
     from unet_nested4tiny_objects_keypoints_amd import ops
     out = []
     for off in (False, True):
-        if off:
-            os.environ["UNETPP_BF16_NO_DMA"] = "1"
+        os.environ["UNETPP_BF16_NO_DMA" if off else "UNETPP_BF16_DMA_ALL"] = "1"   # DMA_ALL: also where it is not the default
         try:
             res = fn()
             torch.cuda.synchronize()
             out.append((res, ops._lib.lib().unetpp_last_kernel_name()))
         finally:
             os.environ.pop("UNETPP_BF16_NO_DMA", None)
+            os.environ.pop("UNETPP_BF16_DMA_ALL", None)
     return out
 
 

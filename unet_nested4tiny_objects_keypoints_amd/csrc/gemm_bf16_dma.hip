@@ -22,6 +22,14 @@
 // Taken for: plain input views (no BatchNorm fold / ReLU / gate on load -- those need VALU on the way and stay with
 // gemm_bf16.hip), channel slices in multiples of 32, tensors below 2 GB.  Same weight image, same results bit for bit
 // (tests/test_gpu_bf16.py::test_bf16_dma_and_register_kernels_agree).
+//
+// What it showed (tools/bf16_dma_ablation.sh, 32 -> 32 at 512 x 512 x 8, HBM floor 33.5 us): 70 us as it stands; without
+// the MFMA phase 61; without the epilogue 43; loads alone (DMA + barriers) 33 us = 5.5 TB/s of patch reads.  Loads and
+// stores do not overlap inside a CU: reads + writes together move 7-9 B/clk/CU whatever the instruction stream looks
+// like -- the register kernel with 3x the instructions is within 8 % -- and neither contiguous 1 KB wave stores (62 us)
+// nor issuing the next DMA and the next unit's epilogue operands BEFORE a unit's stores (counted vmcnt, two operand
+// sets; 76 us at 228 registers) changes that.  The level-0 bf16 layers are bound by the CU's memory pipeline at about
+// 0.45-0.5 of the HBM floor with 8 x 32 patches (1.33x halo); what is left is bytes per pixel (larger patches), not issue.
 #include <cstdlib>
 
 #include "bf16_common.h"
@@ -37,7 +45,6 @@ constexpr int DSTEP = 1024;    // bytes of one (tap, g) weight step: 32 columns 
 constexpr unsigned kDmaOutOfRange = 0x80000000u;  // buffer offset no view reaches (tensors are below 2 GB)
 typedef const __attribute__((address_space(1))) void* dma_gptr_t;
 typedef __attribute__((address_space(3))) void* dma_lptr_t;
-typedef unsigned u32x4s __attribute__((vector_size(16)));  // the buffer-store builtin's own data type
 
 struct DmaArgs {
   FastArgs f;
@@ -47,7 +54,6 @@ struct DmaArgs {
   int img_pitch;    // bytes per image / 1 (Hs * Ws * C * 2), < 2^31
   int view_bytes;   // size of an input tensor in bytes
   int wimg_bytes;   // size of the launch's weight image in bytes (n_tiles * n_chunks * IMG)
-  int out_bytes;    // size of an output tensor in bytes (all output views: one geometry, below 2 GB)
 };
 
 template <int TAPS, int LOG2TW, int NT, bool STATS>
@@ -352,17 +358,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
     f32x4 b4[NT][4];
     u32x4 gate_raw[NT][2][2], old_raw[NT][2][2];
   };
-  EpiOps eo0, eo1;  // operands of the current unit's epilogue / of the next one (requested a unit ahead)
+  EpiOps eo;
   auto asm_load16 = [](auto& dst, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p)); };
-  auto tie_ops = [](EpiOps& e) {  // consumers of these registers stay behind the s_waitcnt in front of this
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      asm volatile("" : "+v"(e.b4[t][0]), "+v"(e.b4[t][1]), "+v"(e.b4[t][2]), "+v"(e.b4[t][3]));
-      asm volatile("" : "+v"(e.gate_raw[t][0][0]), "+v"(e.gate_raw[t][0][1]), "+v"(e.gate_raw[t][1][0]), "+v"(e.gate_raw[t][1][1]));
-      asm volatile("" : "+v"(e.old_raw[t][0][0]), "+v"(e.old_raw[t][0][1]), "+v"(e.old_raw[t][1][0]), "+v"(e.old_raw[t][1][1]));
-    }
-  };
-  auto fetch_epilogue_operands = [&](const UnitGeom& g, EpiOps& eo) {
+  auto fetch_epilogue_operands = [&]() {
+    const UnitGeom& g = c_ug;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const TileCols tc = decode_tile(a, g.group * NT + t);
@@ -395,19 +394,16 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
       }
     }
   };
-  // Exactly kEpiStores vector-memory instructions, whatever the patch: the stores go through a buffer resource and dead
-  // lanes (pixels or columns outside the tensor) get an out-of-range offset, which the hardware drops -- the pipeline's
-  // counted vmcnt wait relies on the number of stores a unit issues.
-  constexpr int kEpiStores = NT * 4;
-  auto epilogue_direct = [&](const UnitGeom& g, EpiOps& eo) {
+  auto epilogue_direct = [&]() {
+    const UnitGeom& g = c_ug;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const TileCols tc = decode_tile(a, g.group * NT + t);
       const unetpp_view& O = d.out[tc.ov];
+      bf16_t* optr = reinterpret_cast<bf16_t*>(O.ptr);
       const bool has_gate = O.gate != nullptr, acc_out = O.accumulate != 0;  // uniform
       const unsigned row_stride = static_cast<unsigned>(O.sy) * O.Ws * O.C, col_stride = static_cast<unsigned>(O.sx) * O.C;
       const unsigned tile_base = view_pixel_offset32(O, g.n, g.ty0, g.tx0) + tc.nt * 32;
-      const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(O.ptr, 0, da.out_bytes, 0x00020000);
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int py = epi_py[mt], px = epi_px[mt];
@@ -458,34 +454,40 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
             }
             out = pack8(v);
           }
-          const unsigned boff = (pix_ok && c0 < tc.n_cnt) ? (pbase + static_cast<unsigned>(c0)) * 2u : kDmaOutOfRange;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, out), orsrc, static_cast<int>(boff), 0, 0);
+          if (pix_ok && c0 < tc.n_cnt) *reinterpret_cast<u32x4*>(optr + pbase + c0) = out;
         }
       }
     }
   };
 
   // ---- pipeline: a chunk is computed from input buffer in_cur / weight buffer w_cur while the DMA of the next chunk fills
-  // the other ones; one barrier per chunk.
+  // the other ones.  Per chunk: issue DMA(next); MFMAs; wait for the DMA (before the epilogue's stores are issued: vmcnt
+  // counts in order); epilogue of a finished unit; one barrier (every wave's share of the next chunk has landed, nobody
+  // reads the current buffers any more, the epilogue's scratch is free).
   // What is NOT fetched again: the weight image when the whole launch uses one (a single chunk and a single column group:
   // the 32 -> 32 layers of level 0) -- it stays in its buffer; the input patch when the next unit is the next column
   // group of the same patch and a unit is one chunk (input gradients of a 32-channel dy into 64..128 channels) -- the
-  // input buffer is not toggled.
-  // Order inside an iteration (plain launches): MFMAs of chunk c; wait for DMA(c+1) and the epilogue operands; barrier;
-  // DMA(c+2) into the buffers chunk c just left; operand requests of the NEXT unit's epilogue; epilogue of a finished
-  // unit (stores).  The reads of the next chunks are therefore in flight while this unit's output drains (an ablation
-  // of the first version, which issued the next DMA only after the epilogue, showed loads and stores taking turns: 70 us
-  // for a level-0 32 -> 32 launch against 33 us for its loads alone and 43 us without the stores).  vmcnt counts in order,
-  // so the wait behind the MFMAs is `vmcnt(kEpiStores)` when the previous iteration ended in an epilogue: everything
-  // older than that unit's stores -- i.e. DMA(c+1) and the operand requests -- has landed, the stores may still be in
-  // flight.  Statistics launches keep the simple order (their epilogue uses the input buffer as scratch and barriers). ----
+  // input buffer is not toggled.  The kernel is bound by what a CU's memory pipeline moves (~10 B/clk), not by HBM. ----
   const bool w_resident = a.n_chunks == 1 && a.n_groups == 1;   // uniform
   const bool in_reuse = !STATS && a.n_chunks == 1;              // (the statistics epilogue uses the input buffer as scratch)
-  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
-  auto mfma_phase = [&](unsigned in_base, unsigned w_base) {
+  prefetch_unit();
+  dma_chunk(0, 0, true, true);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int c_chunk = 0, in_cur = 0, w_cur = 0;
+  bool more = advance();
+  while (true) {
+    const bool need_in = more && !(in_reuse && p_same_patch), need_w = more && !w_resident;
+    if (more) dma_chunk(in_cur ^ 1, w_cur ^ 1, need_in, need_w);
+    if constexpr (!STATS) {
+      if (c_chunk + 1 == a.n_chunks) fetch_epilogue_operands();  // uniform
+    }
+    const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
+    const unsigned in_base = lds0 + static_cast<unsigned>(in_cur) * IN_BYTES;
+    const unsigned w_base = lds0 + 2 * IN_BYTES + static_cast<unsigned>(w_cur) * W_BYTES;
     Frag fr[2];
-    asm volatile("" ::: "memory");  // the reads below stay behind the barrier that published these buffers
-#ifndef UNETPP_DMA_EXP_NO_MFMA
+    asm volatile("" ::: "memory");  // the reads below stay behind the barrier that published this buffer
     issue_frag(IC<0>{}, fr[0], in_base, w_base);
     wait_frag(fr[0]);
     static_for<TAPS * 2>([&](auto sc) {
@@ -509,96 +511,40 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (step + 1 < TAPS * 2) wait_frag(fr[ns]);
     });
-#endif
-  };
-  // raw barrier: __syncthreads() carries a fence that drains vmcnt(0), i.e. would wait for the output stores in flight.
-  // What the barrier has to order is already complete in every wave: its fragment reads (collected by the lgkmcnt waits
-  // of the MFMA phase) and its share of the DMA (the vmcnt wait in front of the barrier).
-  auto chunk_barrier = [&]() {
+    // this wave's share of chunk c+1 has landed, and the epilogue's operands (requested before the MFMAs) are in
+    if constexpr (STATS) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(eo.b4[t][0]), "+v"(eo.b4[t][1]), "+v"(eo.b4[t][2]), "+v"(eo.b4[t][3])::"memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(eo.gate_raw[t][0][0]), "+v"(eo.gate_raw[t][0][1]), "+v"(eo.gate_raw[t][1][0]), "+v"(eo.gate_raw[t][1][1])::"memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(eo.old_raw[t][0][0]), "+v"(eo.old_raw[t][0][1]), "+v"(eo.old_raw[t][1][0]), "+v"(eo.old_raw[t][1][1])::"memory");
+      }
+    }
+    if (c_chunk + 1 == a.n_chunks) {
+      if constexpr (STATS) {
+        __syncthreads();  // the transposing epilogue uses the buffer just computed from as scratch: all waves are done with it
+        epilogue_stats(smem + in_cur * IN_BYTES);
+      } else {
+        epilogue_direct();
+      }
+      step_unit(c_ug, c_index);
+      c_chunk = 0;
+    } else {
+      ++c_chunk;
+    }
+    if (!more) break;
+    // raw barrier: __syncthreads() carries a fence that drains vmcnt(0), i.e. would wait for this unit's output stores.
+    // What the barrier has to order is already complete in every wave: its fragment reads of buffer `cur` (collected by
+    // the lgkmcnt waits of the MFMA phase), its share of the next chunk's DMA (the vmcnt wait above, issued before the
+    // stores), and -- statistics launches -- the epilogue's LDS traffic (it ends in a __syncthreads of its own).
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-  };
-
-  prefetch_unit();
-  dma_chunk(0, 0, true, true);
-  if constexpr (!STATS) fetch_epilogue_operands(c_ug, eo0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  int c_chunk = 0, c_unit = 0, in_cur = 0, w_cur = 0;
-  bool more = advance();  // the cursor is on chunk 1
-  bool need_in = more && !(in_reuse && p_same_patch), need_w = more && !w_resident;
-  if (more) dma_chunk(in_cur ^ 1, w_cur ^ 1, need_in, need_w);
-  bool stores_in_flight = false, par = false;  // par: eo1 (not eo0) holds the current unit's operands
-  while (true) {
-    mfma_phase(lds0 + static_cast<unsigned>(in_cur) * IN_BYTES, lds0 + 2 * IN_BYTES + static_cast<unsigned>(w_cur) * W_BYTES);
-    const bool unit_end = c_chunk + 1 == a.n_chunks;
-    if constexpr (STATS) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next chunk has landed
-      if (unit_end) {
-        __syncthreads();  // the transposing epilogue uses the buffer just computed from as scratch: all waves are done with it
-        epilogue_stats(smem + in_cur * IN_BYTES);
-        step_unit(c_ug, c_index);
-        c_chunk = 0;
-      } else {
-        ++c_chunk;
-      }
-      if (!more) break;
-      chunk_barrier();
-      if (need_in) in_cur ^= 1;
-      if (need_w) w_cur ^= 1;
-      more = advance();
-      need_in = more;
-      need_w = more && !w_resident;
-      if (more) dma_chunk(in_cur ^ 1, w_cur ^ 1, need_in, need_w);
-    } else {
-      // DMA(c+1) and the operand requests have landed; the previous unit's stores (younger than both) may stay in flight
-      if (stores_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kEpiStores) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      tie_ops(eo0);
-      tie_ops(eo1);
-      stores_in_flight = false;
-      if (more) {
-        chunk_barrier();
-        if (need_in) in_cur ^= 1;
-        if (need_w) w_cur ^= 1;
-        more = advance();  // chunk c+2 (its buffers are the ones chunk c just left)
-#ifdef UNETPP_DMA_EXP_NO_INDMA  // experiment builds (tools/bf16_dma_ablation.sh): where does a unit's time go
-        need_in = false;
-#else
-        need_in = more && !(in_reuse && p_same_patch);
-#endif
-        need_w = more && !w_resident;
-        if (more) dma_chunk(in_cur ^ 1, w_cur ^ 1, need_in, need_w);
-        if (!unit_end) {
-          ++c_chunk;
-          continue;
-        }
-      } else if (!unit_end) {
-        break;  // (cannot happen: the last chunk of the run ends a unit)
-      }
-      // ---- the unit is complete: request the next unit's operands, then compute and store this one ----
-      UnitGeom nxt = c_ug;
-      long nxt_index = c_index;
-      const bool has_next = c_unit + 1 < my_units;
-      if (has_next) {
-        step_unit(nxt, nxt_index);
-        if (par) fetch_epilogue_operands(nxt, eo0);
-        else fetch_epilogue_operands(nxt, eo1);
-      }
-#ifndef UNETPP_DMA_EXP_NO_EPI
-      if (par) epilogue_direct(c_ug, eo1);
-      else epilogue_direct(c_ug, eo0);
-      stores_in_flight = true;
-#endif
-      par = !par;
-      c_ug = nxt;
-      c_index = nxt_index;
-      ++c_unit;
-      c_chunk = 0;
-      if (!has_next) break;
-    }
+    if (need_in) in_cur ^= 1;
+    if (need_w) w_cur ^= 1;
+    more = advance();
   }
 }
 
@@ -613,6 +559,12 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
   FastArgs& a = da.f;
   if (!bf16_gemm_args(d, a) || d->weight_image == nullptr) return 1;
   if (d->stats_partial != nullptr && d->n_out != 1) return 1;
+  // Taken where it is measured faster than gemm_bf16.hip (tools/bench_kernels.py, 512 x 512 x 8): 3x3 launches into at
+  // most 32 columns (level 0: 7-8 % on 32 -> 32, 5-10 % on 64..128 -> 32).  With more column tiles this kernel re-stages
+  // the patch per 32-column group (one tile per unit) where the register kernel feeds two tiles from one staging, and the
+  // pointwise GEMMs of the transposed convolutions are faster there too.  UNETPP_BF16_DMA_ALL=1 lifts the restriction
+  // (tests run every shape class through both kernels).
+  if (getenv("UNETPP_BF16_DMA_ALL") == nullptr && (d->taps != 9 || a.n_tiles != 1)) return 1;
   const unetpp_view& V0 = d->in[0];
   for (int i = 0; i < d->n_in; ++i) {
     const unetpp_view& v = d->in[i];
@@ -631,16 +583,9 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
   const long wimg_bytes = static_cast<long>(a.n_tiles) * a.n_chunks * (d->taps * 2 * DSTEP);
   if (wimg_bytes > 0x7fffffffL) return 1;
   da.wimg_bytes = static_cast<int>(wimg_bytes);
-  // the epilogue stores through a buffer resource (dead lanes: out-of-range offsets): output tensors of one size, < 2 GB
-  const unetpp_view& O0 = d->out[0];
-  const long out_bytes = static_cast<long>(d->N) * O0.Hs * O0.Ws * O0.C * 2;
-  if (out_bytes > 0x7fffffffL) return 1;
-  for (int i = 0; i < d->n_out; ++i)
-    if (static_cast<long>(d->N) * d->out[i].Hs * d->out[i].Ws * d->out[i].C * 2 != out_bytes) return 1;
-  da.out_bytes = static_cast<int>(out_bytes);
-  // one column tile per unit (3x3: two weight buffers of 18 KB beside two input buffers of 22 KB: 80 KB, two workgroups
-  // per CU; two operand sets of the epilogue in registers)
-  if (a.nt_unit == 2) {
+  // 3x3: one column tile per unit (two weight buffers of 18 KB beside two input buffers of 22 KB: 80 KB, two workgroups
+  // per CU); pointwise: two tiles when the launch has an even number of them
+  if (d->taps == 9 && a.nt_unit == 2) {
     a.nt_unit = 1;
     a.n_groups = a.n_tiles;
     a.total_blocks *= 2;
@@ -662,7 +607,8 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
   if (d->taps == 9) {
     if (stats) UNETPP_LAUNCH_BF16_DMA(9, 1, true);
     else UNETPP_LAUNCH_BF16_DMA(9, 1, false);
-  } else UNETPP_LAUNCH_BF16_DMA(1, 1, false);
+  } else if (a.nt_unit == 2) UNETPP_LAUNCH_BF16_DMA(1, 2, false);
+  else UNETPP_LAUNCH_BF16_DMA(1, 1, false);
 #undef UNETPP_LAUNCH_BF16_DMA
   note_kernel(d->taps == 9 ? "gemm_bf16_dma_kernel<9>" : "gemm_bf16_dma_kernel<1>");
   return launch_status();
