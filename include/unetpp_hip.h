@@ -302,6 +302,16 @@ int unetpp_head_bwd_bf16(const float* d_out_nchw, const float* out_nchw, const v
                          const uint8_t* mask, void* dx, int32_t accumulate, int32_t gate_x, float* partial,
                          void* stream);
 
+/* is_batchnorm=False in bf16: d_act += d_pooled at the window argmax (unetpp_affine_relu_pool_bf16's pool_idx), then,
+ * with gate != NULL, d_act *= (gate > 0) -- the ReLU mask of the node, applied by its last gradient contribution */
+int unetpp_maxpool_bwd_bf16(const void* d_pooled, const uint8_t* pool_idx, int32_t N, int32_t H, int32_t W, int32_t C,
+                            void* d_act, const void* gate, void* stream);
+/* is_deconv=False in bf16 (nn.UpsamplingBilinear2d, models/unet.py:190): x [N,H,W,C] -> y [N,2H,2W,C]; backward in
+ * gather form: dx = (accumulate ? dx : 0) + stencil^T(dy), then dx *= (gate > 0) when gate != NULL */
+int unetpp_bilinear2x_fwd_bf16(const void* x, int32_t N, int32_t H, int32_t W, int32_t C, void* y, void* stream);
+int unetpp_bilinear2x_bwd_bf16(const void* dy, int32_t N, int32_t H, int32_t W, int32_t C, void* dx, int32_t accumulate,
+                               const void* gate, void* stream);
+
 /* ---- heat-map side of validation (tools/misc/heatmap.py; SURVEY 8 row f3 -- parity unpinned: the reference needs
  * OpenCV, absent from the build image) ------------------------------------------------------------------------------
  * unetpp_heatmap_pattern: Heatmap.create_heatmap (heatmap.py:203-230).  points [N, P, 2] as (x, y); map m draws the

@@ -7,6 +7,7 @@ bf16 (straight-through in backward), and the convolution weights are rounded as 
   * every conv / transposed-conv output (+ bias, + ReLU for the BatchNorm-less decoder blocks) is stored in bf16;
   * BatchNorm statistics are those of the STORED tensor; its apply + ReLU is one fp32 fma, stored (or consumed) in bf16;
   * max-pool, concatenation and the heads' dropout / 1x1 / sigmoid see the stored values; the probabilities are fp32;
+  * is_deconv=False: the bilinear interpolation of the stored tensor is stored in bf16, its 1x1 convolution as above;
   * the network's first convolution (1..4 input channels) and the heads use the fp32 weights (VALU kernels).
 
 Backward is plain autograd through this forward: the activation GRADIENTS are not rounded here (the HIP path stores
@@ -125,7 +126,7 @@ def routing_of(hip_saved):
 
 
 def forward_bf16_sim(model, inputs, training=True, dtype=torch.float64, routing=None, stats=None):
-    """model: a UNetNestedOracle (is_deconv=True).  Dropout must be off (model.drop_out.eval() / p = 0).
+    """model: a UNetNestedOracle.  Dropout must be off (model.drop_out.eval() / p = 0).
     routing = routing_of(hip_saved) or None; stats (dict) receives the counts of differing gates / winners."""
     d = model.depth
     x = inputs.to(dtype)
@@ -142,7 +143,12 @@ def forward_bf16_sim(model, inputs, training=True, dtype=torch.float64, routing=
     for j in range(1, d):
         for i in range(d - j):
             up = getattr(model, "up_concat%d%d" % (i, j))
-            u = rb(F.conv_transpose2d(X[i + 1][j - 1], rb(up.up.weight.to(dtype)), up.up.bias.to(dtype), stride=2))
+            if model.is_deconv:
+                u = rb(F.conv_transpose2d(X[i + 1][j - 1], rb(up.up.weight.to(dtype)), up.up.bias.to(dtype), stride=2))
+            else:  # bilinear x2 (align_corners) stored in bf16, then the 1x1 convolution on the MFMA (bf16 weights)
+                conv = up.up[1]
+                interp = rb(F.interpolate(X[i + 1][j - 1], scale_factor=2, mode="bilinear", align_corners=True))
+                u = rb(F.conv2d(interp, rb(conv.weight.to(dtype)), conv.bias.to(dtype)))
             X[i][j] = _pair(up.conv, torch.cat([u] + X[i][:j], 1), False, training, gates.get((i, j), none2), stats)
     outs = []
     for j in range(1, d):

@@ -412,6 +412,56 @@ def test_heads_bf16(dev, c, n_cls, p_drop):
         assert torch.equal(o1, o2) and not torch.equal(o1, o3)
 
 
+@pytest.mark.parametrize("b,h,w,c", [(2, 8, 12, 16), (1, 5, 7, 8), (3, 16, 16, 64)])
+def test_bilinear2x_bf16(dev, b, h, w, c):
+    """unetpp_bilinear2x_{fwd,bwd}_bf16 against float64 interpolate / its autograd on the same bf16 operands; backward
+    also with accumulate and with the fused ReLU mask"""
+    from unet_nested4tiny_objects_keypoints_amd import ops
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(b, c, h, w, generator=g)
+    xd = nhwc(x).to(BF).to(dev)
+    y = torch.empty(b, 2 * h, 2 * w, c, dtype=BF, device=dev)
+    ops.bilinear2x_fwd(xd, y)
+    want = F.interpolate(rb(x), scale_factor=2, mode="bilinear", align_corners=True)
+    close_bf16(y.permute(0, 3, 1, 2), want, "bilinear forward")
+    dy = torch.randn(b, c, 2 * h, 2 * w, generator=g)
+    xr = rb(x).requires_grad_(True)
+    (F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=True) * rb(dy)).sum().backward()
+    old = torch.randn(b, c, h, w, generator=g)
+    gate = torch.randn(b, c, h, w, generator=g)
+    for accumulate, use_gate in ((False, False), (True, False), (True, True)):
+        dx = nhwc(old).to(BF).to(dev)
+        ops.bilinear2x_bwd(nhwc(dy).to(BF).to(dev), dx, accumulate, nhwc(gate).to(BF).to(dev) if use_gate else None)
+        w_ = xr.grad + (rb(old) if accumulate else 0)
+        if use_gate:
+            w_ = w_ * (rb(gate) > 0)
+        close_bf16(dx.permute(0, 3, 1, 2), w_, "bilinear backward acc=%s gate=%s" % (accumulate, use_gate))
+
+
+@pytest.mark.parametrize("b,h,w,c", [(2, 8, 12, 16), (1, 4, 6, 24), (3, 16, 16, 64)])
+def test_maxpool_bwd_bf16(dev, b, h, w, c):
+    """unetpp_maxpool_bwd_bf16: the pooled gradient lands on the argmax recorded by the forward kernel (first maximum in
+    scan order), is added to d_act, and the optional ReLU mask follows the sum"""
+    from unet_nested4tiny_objects_keypoints_amd import ops
+    g = torch.Generator().manual_seed(42)
+    act = torch.randn(b, h, w, c, generator=g).clamp_min(0).to(BF).to(dev)   # ReLU zeros: ties
+    pooled = torch.empty(b, h // 2, w // 2, c, dtype=BF, device=dev)
+    idx = torch.empty(b, h // 2, w // 2, c, dtype=torch.uint8, device=dev)
+    ops.affine_relu_pool(act, None, None, False, None, pooled, idx)
+    ref_pool, ref_idx = F.max_pool2d(act.float().permute(0, 3, 1, 2), 2, return_indices=True)
+    assert torch.equal(pooled.float().permute(0, 3, 1, 2), ref_pool)
+    d_pool = torch.randn(b, h // 2, w // 2, c, generator=g).to(BF).to(dev)
+    base = torch.randn(b, h, w, c, generator=g).to(BF).to(dev)
+    for use_gate in (False, True):
+        d_act = base.clone()
+        ops.maxpool_bwd(d_pool, idx, d_act, gate=act if use_gate else None)
+        want = base.double().permute(0, 3, 1, 2).contiguous()
+        want.view(b, c, -1).scatter_add_(2, ref_idx.view(b, c, -1), d_pool.double().permute(0, 3, 1, 2).reshape(b, c, -1))
+        if use_gate:
+            want = want * (act.double().permute(0, 3, 1, 2) > 0)
+        close_bf16(d_act.permute(0, 3, 1, 2), want, "maxpool backward gate=%s" % use_gate)
+
+
 # ---------------------------------------------------------------------------------- whole network
 def _bf16_vs_oracle(dev, ctor, b, h, w, seed, probe=False):
     """One train step (dropout off) of the HIP model with bf16 activation storage against (a) the fp32 CPU oracle and
@@ -487,7 +537,13 @@ def _bf16_vs_oracle(dev, ctor, b, h, w, seed, probe=False):
     # bf16 weight gradient and the swapped-operand epilogue at scale, 2.6e5 / 1.5e5 values per BatchNorm channel
     (dict(in_channels=1, n_classes=4, feature_scale=1), 1, 512, 512),
     (dict(in_channels=3, n_classes=5, feature_scale=0.5, depth=5), 1, 384, 384),
-], ids=["base32", "d5-base64-rgb5", "base8", "configs3-512x512", "configs4-d5-base64-384x384"])
+    # the reference's non-default structures in bf16 storage (models/unet.py:189-191 bilinear + 1x1 up path, :138-143
+    # blocks without BatchNorm): bilinear kernels, max-pool backward with the fused ReLU mask
+    (dict(in_channels=1, n_classes=4, feature_scale=2, is_deconv=False), 2, 64, 64),
+    (dict(in_channels=3, n_classes=4, feature_scale=2, is_batchnorm=False), 2, 64, 64),
+    (dict(in_channels=1, n_classes=4, feature_scale=4, is_deconv=False, is_batchnorm=False, depth=3), 2, 32, 48),
+], ids=["base32", "d5-base64-rgb5", "base8", "configs3-512x512", "configs4-d5-base64-384x384", "bilinear", "no-batchnorm",
+        "bilinear-no-batchnorm-d3"])
 def test_bf16_train_step_vs_oracles(dev, ctor, b, h, w):
     """The separately stated bf16 tolerance (north_star's 1e-4 is the fp32 bar).
 
@@ -579,10 +635,9 @@ def test_bf16_long_trajectory_tracks_fp32_at_base32(dev):
 def test_bf16_unsupported_configurations_raise(dev):
     from unet_nested4tiny_objects_keypoints_amd import UNet_Nested
     x = torch.randn(1, 1, 32, 32, device=dev)
-    for kw in (dict(is_deconv=False), dict(is_batchnorm=False)):
-        m = UNet_Nested(in_channels=1, n_classes=4, feature_scale=4, **kw).to(dev).set_activation_dtype(BF)
-        with pytest.raises(NotImplementedError):
-            m(x)
+    m = UNet_Nested(in_channels=1, n_classes=4, feature_scale=3).to(dev).set_activation_dtype(BF)   # widths 10, 21, 42, 85
+    with pytest.raises(NotImplementedError):
+        m(x)
     with pytest.raises(ValueError):
         UNet_Nested().set_activation_dtype(torch.float16)
 

@@ -137,6 +137,9 @@ SIGNATURES = {
     "unetpp_bn_bwd_reduce_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "unetpp_bn_bwd_apply_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "unetpp_head_fwd_bf16": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _P]),
+    "unetpp_maxpool_bwd_bf16": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    "unetpp_bilinear2x_fwd_bf16": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P]),
+    "unetpp_bilinear2x_bwd_bf16": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _I32, _P, _P]),
     # heat-map side of validation (keypoints.hip)
     "unetpp_heatmap_pattern_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32]),
     "unetpp_heatmap_pattern": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _I32, _I32, _F, _P, _P, _P]),

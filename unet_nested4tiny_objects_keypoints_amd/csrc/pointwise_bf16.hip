@@ -8,6 +8,10 @@
 //                                  argmax while they read d_act: no scatter pass, no read-modify-write)
 //   unetpp_head_fwd_bf16 / unetpp_head_bwd_bf16   dropout + 1x1 convolution + sigmoid heads: bf16 features in,
 //                                  fp32 NCHW probabilities out (the loss stays fp32), bf16 feature gradient back
+//   unetpp_maxpool_bwd_bf16        max-pool gradient routed to the window argmax and added to d_act, optionally followed
+//                                  by the ReLU mask of the node (is_batchnorm=False: no BatchNorm backward to route through)
+//   unetpp_bilinear2x_fwd_bf16 / unetpp_bilinear2x_bwd_bf16   the is_deconv=False up path (align_corners=True), fp32
+//                                  interpolation of bf16 values; backward in gather form, optional accumulate + ReLU mask
 #include "bf16_common.h"
 #include "common.h"
 #include "lds_asm.h"
@@ -380,6 +384,141 @@ inline bool octets_ok(int C) {  // C = 8 * CG, CG a power of two <= 256 (a threa
   return C >= 8 && (C & 7) == 0 && (cg & (cg - 1)) == 0 && cg <= 256;
 }
 
+
+// ---- max-pool backward without a BatchNorm to route through (is_batchnorm=False): thread = (pixel, octet) ----
+__global__ __launch_bounds__(kThreads) void maxpool_bwd_bf16_kernel(const bf16_t* __restrict__ d_pooled,
+                                                                    const uint8_t* __restrict__ pool_idx, int N, int H, int W,
+                                                                    int CG, bf16_t* __restrict__ d_act,
+                                                                    const bf16_t* __restrict__ gate) {
+  const long items = static_cast<long>(N) * H * W * CG;
+  const unsigned ucg = static_cast<unsigned>(CG);
+  for (long i = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; i < items;
+       i += static_cast<long>(gridDim.x) * kThreads) {
+    const unsigned iu = static_cast<unsigned>(i);  // items < 2^31 (launcher)
+    const unsigned cg = iu % ucg;
+    unsigned r = iu / ucg;
+    const unsigned x = r % static_cast<unsigned>(W);
+    r /= static_cast<unsigned>(W);
+    const unsigned y = r % static_cast<unsigned>(H);
+    const unsigned n = r / static_cast<unsigned>(H);
+    const unsigned wi = ((n * (static_cast<unsigned>(H) >> 1) + (y >> 1)) * (static_cast<unsigned>(W) >> 1) + (x >> 1)) * ucg + cg;
+    const unsigned pos = (y & 1u) * 2u + (x & 1u);
+    const u32x2 ib = reinterpret_cast<const u32x2*>(pool_idx)[wi];
+    float g[8], dp[8];
+    unpack8(reinterpret_cast<const u32x4*>(d_act)[i], g);
+    unpack8(reinterpret_cast<const u32x4*>(d_pooled)[wi], dp);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (((ib[e >> 2] >> (8 * (e & 3))) & 0xffu) == pos) g[e] += dp[e];
+    if (gate != nullptr) {
+      float gt[8];
+      unpack8(reinterpret_cast<const u32x4*>(gate)[i], gt);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = (gt[e] > 0.f) ? g[e] : 0.f;
+    }
+    reinterpret_cast<u32x4*>(d_act)[i] = pack8(g);
+  }
+}
+
+// ---- bilinear x2, align_corners=True (nn.UpsamplingBilinear2d, models/unet.py:190) on bf16 NHWC ----
+__device__ __forceinline__ void bilinear_src_bf(int dst, int in_size, float rscale, int& i0, int& i1, float& l1) {
+  const float s = rscale * static_cast<float>(dst);
+  i0 = static_cast<int>(s);
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = s - static_cast<float>(i0);
+}
+
+// thread = (output pixel, octet): four 16-byte loads, the fp32 expression of the fp32 kernel, one rounding
+__global__ __launch_bounds__(kThreads) void bilinear2x_fwd_bf16_kernel(const bf16_t* __restrict__ x, int N, int H, int W,
+                                                                       int CG, bf16_t* __restrict__ y) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const float ry = (Ho > 1) ? static_cast<float>(H - 1) / static_cast<float>(Ho - 1) : 0.f;
+  const float rx = (Wo > 1) ? static_cast<float>(W - 1) / static_cast<float>(Wo - 1) : 0.f;
+  const long items = static_cast<long>(N) * Ho * Wo * CG;
+  for (long i = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; i < items;
+       i += static_cast<long>(gridDim.x) * kThreads) {
+    const int cg = static_cast<int>(i % CG);
+    long r = i / CG;
+    const int xo = static_cast<int>(r % Wo);
+    r /= Wo;
+    const int yo = static_cast<int>(r % Ho);
+    const long n = r / Ho;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilinear_src_bf(yo, H, ry, y0, y1, ly);
+    bilinear_src_bf(xo, W, rx, x0, x1, lx);
+    const u32x4* b = reinterpret_cast<const u32x4*>(x) + n * H * W * CG + cg;
+    float v00[8], v01[8], v10[8], v11[8], o[8];
+    unpack8(b[(static_cast<long>(y0) * W + x0) * CG], v00);
+    unpack8(b[(static_cast<long>(y0) * W + x1) * CG], v01);
+    unpack8(b[(static_cast<long>(y1) * W + x0) * CG], v10);
+    unpack8(b[(static_cast<long>(y1) * W + x1) * CG], v11);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      o[e] = (1.f - ly) * ((1.f - lx) * v00[e] + lx * v01[e]) + ly * ((1.f - lx) * v10[e] + lx * v11[e]);
+    reinterpret_cast<u32x4*>(y)[i] = pack8(o);
+  }
+}
+
+// gather form of the transposed stencil (fixed summation order, no atomics): thread = (source pixel, octet)
+__global__ __launch_bounds__(kThreads) void bilinear2x_bwd_bf16_kernel(const bf16_t* __restrict__ dy, int N, int H, int W,
+                                                                       int CG, bf16_t* __restrict__ dx, int accumulate,
+                                                                       const bf16_t* __restrict__ gate) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const float ry = (Ho > 1) ? static_cast<float>(H - 1) / static_cast<float>(Ho - 1) : 0.f;
+  const float rx = (Wo > 1) ? static_cast<float>(W - 1) / static_cast<float>(Wo - 1) : 0.f;
+  const long items = static_cast<long>(N) * H * W * CG;
+  for (long i = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; i < items;
+       i += static_cast<long>(gridDim.x) * kThreads) {
+    const int cg = static_cast<int>(i % CG);
+    long r = i / CG;
+    const int xs = static_cast<int>(r % W);
+    r /= W;
+    const int ys = static_cast<int>(r % H);
+    const long n = r / H;
+    const int ylo = max(0, 2 * ys - 3), yhi = min(Ho - 1, 2 * ys + 3);
+    const int xlo = max(0, 2 * xs - 3), xhi = min(Wo - 1, 2 * xs + 3);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int yo = ylo; yo <= yhi; ++yo) {
+      int y0, y1;
+      float ly;
+      bilinear_src_bf(yo, H, ry, y0, y1, ly);
+      float wy = 0.f;
+      if (y0 == ys) wy += 1.f - ly;
+      if (y1 == ys) wy += ly;
+      if (wy == 0.f) continue;
+      for (int xo = xlo; xo <= xhi; ++xo) {
+        int x0, x1;
+        float lx;
+        bilinear_src_bf(xo, W, rx, x0, x1, lx);
+        float wx = 0.f;
+        if (x0 == xs) wx += 1.f - lx;
+        if (x1 == xs) wx += lx;
+        if (wx != 0.f) {
+          float v[8];
+          unpack8(reinterpret_cast<const u32x4*>(dy)[((n * Ho + yo) * Wo + xo) * CG + cg], v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s[e] += wy * wx * v[e];
+        }
+      }
+    }
+    if (accumulate) {
+      float old[8];
+      unpack8(reinterpret_cast<const u32x4*>(dx)[i], old);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += old[e];
+    }
+    if (gate != nullptr) {
+      float gt[8];
+      unpack8(reinterpret_cast<const u32x4*>(gate)[i], gt);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] = (gt[e] > 0.f) ? s[e] : 0.f;
+    }
+    reinterpret_cast<u32x4*>(dx)[i] = pack8(s);
+  }
+}
+
 }  // namespace
 }  // namespace unetpp
 
@@ -533,5 +672,35 @@ extern "C" int unetpp_head_bwd_bf16(const float* d_out_nchw, const float* out_nc
 #undef UNETPP_HEAD_BWD_BF_L
 #undef UNETPP_HEAD_BWD_BF
 #undef UNETPP_HEAD_BWD_BF_P
+  return launch_status();
+}
+
+extern "C" int unetpp_maxpool_bwd_bf16(const void* d_pooled, const uint8_t* pool_idx, int32_t N, int32_t H, int32_t W,
+                                       int32_t C, void* d_act, const void* gate, void* stream) {
+  if (!d_pooled || !pool_idx || !d_act || N < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 8 || (C & 7)) return UNETPP_EINVAL;
+  if (!a16(d_pooled) || !a16(d_act) || (gate && !a16(gate)) || (reinterpret_cast<uintptr_t>(pool_idx) & 7)) return UNETPP_EINVAL;
+  const long items = static_cast<long>(N) * H * W * (C >> 3);
+  if (items >= 0x7fffffffL) return UNETPP_EINVAL;
+  hipLaunchKernelGGL(maxpool_bwd_bf16_kernel, dim3(grid_for8(items)), dim3(kThreads), 0, ST(stream),
+                     static_cast<const bf16_t*>(d_pooled), pool_idx, N, H, W, C >> 3, static_cast<bf16_t*>(d_act),
+                     static_cast<const bf16_t*>(gate));
+  return launch_status();
+}
+
+extern "C" int unetpp_bilinear2x_fwd_bf16(const void* x, int32_t N, int32_t H, int32_t W, int32_t C, void* y, void* stream) {
+  if (!x || !y || N < 1 || H < 1 || W < 1 || C < 8 || (C & 7) || !a16(x) || !a16(y)) return UNETPP_EINVAL;
+  const long items = static_cast<long>(N) * 4 * H * W * (C >> 3);
+  hipLaunchKernelGGL(bilinear2x_fwd_bf16_kernel, dim3(grid_for8(items)), dim3(kThreads), 0, ST(stream),
+                     static_cast<const bf16_t*>(x), N, H, W, C >> 3, static_cast<bf16_t*>(y));
+  return launch_status();
+}
+
+extern "C" int unetpp_bilinear2x_bwd_bf16(const void* dy, int32_t N, int32_t H, int32_t W, int32_t C, void* dx,
+                                          int32_t accumulate, const void* gate, void* stream) {
+  if (!dy || !dx || N < 1 || H < 1 || W < 1 || C < 8 || (C & 7) || !a16(dy) || !a16(dx) || (gate && !a16(gate))) return UNETPP_EINVAL;
+  const long items = static_cast<long>(N) * H * W * (C >> 3);
+  hipLaunchKernelGGL(bilinear2x_bwd_bf16_kernel, dim3(grid_for8(items)), dim3(kThreads), 0, ST(stream),
+                     static_cast<const bf16_t*>(dy), N, H, W, C >> 3, static_cast<bf16_t*>(dx), accumulate,
+                     static_cast<const bf16_t*>(gate));
   return launch_status();
 }

@@ -173,9 +173,9 @@ def _up_fwd(upmod, is_deconv, src, b, hs, ws, adt=torch.float32) -> _UpRec:
     else:
         conv = getattr(upmod, "1")
         ci, co = conv.in_channels, conv.out_channels
-        u.interp = torch.empty((b, 2 * hs, 2 * ws, ci), dtype=torch.float32, device=src.device)
+        u.interp = torch.empty((b, 2 * hs, 2 * ws, ci), dtype=adt, device=src.device)
         ops.bilinear2x_fwd(src, u.interp)
-        u.up = torch.empty((b, 2 * hs, 2 * ws, co), dtype=torch.float32, device=src.device)
+        u.up = torch.empty((b, 2 * hs, 2 * ws, co), dtype=adt, device=src.device)
         ops.gemm_fwd(b, 2 * hs, 2 * ws, 1, [V(u.interp)], [V(u.up)], pack_conv_fwd(conv.weight.detach()),
                      conv.bias.detach())
     return u
@@ -200,11 +200,10 @@ def _check_input(model, x):
 
 def _activation_dtype(model):
     """fp32, or bf16 storage (UNet_Nested.set_activation_dtype): BASELINE configs[3]/[4].  The bf16 kernels cover the
-    reference's default structure (transposed-convolution up path, BatchNorm encoder, channel counts 8 * 2^k)."""
+    reference's structures (transposed-convolution or bilinear up path, encoder with or without BatchNorm) at channel
+    counts 8 * 2^k."""
     adt = getattr(model, "activation_dtype", torch.float32)
     if adt == torch.bfloat16:
-        if not (model.is_deconv and model.is_batchnorm):
-            raise NotImplementedError("bf16 storage supports is_deconv=True, is_batchnorm=True only")
         if any(f % 8 or (f // 8) & (f // 8 - 1) for f in model.filters):
             raise NotImplementedError("bf16 storage needs channel counts 8 * 2^k, got %s" % (model.filters,))
     return adt
@@ -401,7 +400,7 @@ def _up_bwd(upmod, is_deconv, u: _UpRec, d_up, d_src, accumulate, gate, b, grads
         _conv_wgrad(conv, [V(u.interp)], [V(d_up)], b, 2 * hs, 2 * ws, grads)
         d_interp = torch.empty_like(u.interp)
         ops.gemm_fwd(b, 2 * hs, 2 * ws, 1, [V(d_up)], [V(d_interp)], pack_conv_dgrad(conv.weight.detach()))
-        ops.bilinear2x_bwd(d_interp, d_src, accumulate)
+        ops.bilinear2x_bwd(d_interp, d_src, accumulate, gate)  # (gate: bf16 storage only, see backward_impl)
 
 
 def backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=None):
@@ -426,6 +425,7 @@ def _backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=No
     # (decoder nodes always; encoder nodes only when is_batchnorm=False -- with BN the mask lives in BN backward).
     gate_keys = {k for k in s.X if k[1] >= 1 or not model.is_batchnorm}
     book = _GradBook(s.X, d, gate_keys)
+    bf16 = s.X[(0, 0)].dtype == torch.bfloat16
     seen = set()
 
     def flush():
@@ -463,7 +463,10 @@ def _backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=No
                 t, acc, gate = book.target((i, jj), can_gate=True)
                 targets.append(V(t, accumulate=acc, gate=gate, gate_sum=True))
             _pair_bwd(mod.conv, r, d_out, targets, b, grads, pre_gated, flush=flush)
-            t, acc, gate = book.target((i + 1, j - 1), can_gate=model.is_deconv)
+            # the ReLU mask of a BatchNorm-less node is applied by its LAST gradient contribution: the transposed
+            # convolution's input-gradient epilogue, or (bf16 storage, whose kernels take no gate on load) the bilinear
+            # backward kernel
+            t, acc, gate = book.target((i + 1, j - 1), can_gate=model.is_deconv or bf16)
             _up_bwd(mod.up, model.is_deconv, u, d_up, t, acc, gate, b, grads)
             flush()
     dx_in = None
@@ -473,7 +476,10 @@ def _backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=No
         r = s.pairs[(i, 0)]
         d_out, pre_gated = book.take((i, 0))
         if pool_grad is not None and not model.is_batchnorm:
-            ops.maxpool_bwd(pool_grad[0], pool_grad[1], d_out)  # (is_batchnorm=False never gates encoder nodes early)
+            # fp32: the ReLU mask follows as a gate on the consumers' loads (is_batchnorm=False never gates encoder nodes
+            # early); bf16 storage: the pool gradient is the node's last contribution and its kernel applies the mask
+            ops.maxpool_bwd(pool_grad[0], pool_grad[1], d_out, gate=r.out if (bf16 and not pre_gated) else None)
+            pre_gated = pre_gated or bf16
             pool_grad = None
         mine, pool_grad = pool_grad, None
         if i > 0:

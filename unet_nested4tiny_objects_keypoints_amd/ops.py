@@ -486,11 +486,15 @@ def affine_relu_pool(y, scale, shift, relu, act, pooled, pool_idx):
                                              _ptr(pooled), _ptr(pool_idx), _stream()), "unetpp_affine_relu_pool")
 
 
-def maxpool_bwd(d_pooled, pool_idx, d_act):
+def maxpool_bwd(d_pooled, pool_idx, d_act, gate=None):
+    """d_act[window argmax] += d_pooled; bf16 storage: optionally followed by d_act *= (gate > 0) (the node's ReLU mask)"""
     n, h, w, c = d_act.shape
     if _is_bf16(d_act):
-        raise NotImplementedError("bf16 storage: the pool gradient is only routed inside BatchNorm backward "
-                                  "(is_batchnorm=False is an fp32-only configuration)")
+        check(_lib.lib().unetpp_maxpool_bwd_bf16(_ptr(d_pooled), _ptr(pool_idx), n, h, w, c, _ptr(d_act), _ptr(gate), _stream()),
+              "unetpp_maxpool_bwd_bf16")
+        return
+    if gate is not None:
+        raise ValueError("the fused ReLU mask is a bf16-storage option")
     check(_lib.lib().unetpp_maxpool_bwd(_ptr(d_pooled), _ptr(pool_idx), n, h, w, c, _ptr(d_act), _stream()),
           "unetpp_maxpool_bwd")
 
@@ -578,14 +582,22 @@ def head_bwd(d_out, out, x, weight, p_drop, seed, mask, dx, accumulate, gate_x=F
 
 
 def bilinear2x_fwd(x, y):
-    if _is_bf16(x):
-        raise NotImplementedError("bf16 storage covers the default transposed-convolution up path only (is_deconv=True)")
     n, h, w, c = x.shape
+    if _is_bf16(x):
+        check(_lib.lib().unetpp_bilinear2x_fwd_bf16(_ptr(x), n, h, w, c, _ptr(y), _stream()), "unetpp_bilinear2x_fwd_bf16")
+        return
     check(_lib.lib().unetpp_bilinear2x_fwd(_ptr(x), n, h, w, c, _ptr(y), _stream()), "unetpp_bilinear2x_fwd")
 
 
-def bilinear2x_bwd(dy, dx, accumulate):
+def bilinear2x_bwd(dy, dx, accumulate, gate=None):
+    """dx (+)= stencil^T(dy); bf16 storage: optionally followed by dx *= (gate > 0) (the node's ReLU mask)"""
     n, h, w, c = dx.shape
+    if _is_bf16(dx):
+        check(_lib.lib().unetpp_bilinear2x_bwd_bf16(_ptr(dy), n, h, w, c, _ptr(dx), int(accumulate), _ptr(gate), _stream()),
+              "unetpp_bilinear2x_bwd_bf16")
+        return
+    if gate is not None:
+        raise ValueError("the fused ReLU mask is a bf16-storage option")
     check(_lib.lib().unetpp_bilinear2x_bwd(_ptr(dy), n, h, w, c, _ptr(dx), int(accumulate), _stream()),
           "unetpp_bilinear2x_bwd")
 
