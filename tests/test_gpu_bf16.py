@@ -524,8 +524,8 @@ def _bf16_vs_oracle(dev, ctor, b, h, w, seed, probe=False):
         res["sim_grad_l2"][k] = float((gd - gsim[k].flatten()).norm() / gsim[k].norm())
         res["cos"][k] = float(torch.dot(gd, gsim[k].flatten()) / (gd.norm() * gsim[k].norm()))
     res["flips"] = flips
-    res["bn_rel"] = max(float((bh.cpu() - bufs32[k]).abs().max() / bufs32[k].abs().max())
-                        for k, bh in m.named_buffers() if bh.dtype.is_floating_point)
+    res["bn_rel"] = max([float((bh.cpu() - bufs32[k]).abs().max() / bufs32[k].abs().max())
+                         for k, bh in m.named_buffers() if bh.dtype.is_floating_point] + [0.0])   # (no buffers without BatchNorm)
     return res
 
 
