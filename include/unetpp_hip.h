@@ -312,6 +312,12 @@ int unetpp_bilinear2x_fwd_bf16(const void* x, int32_t N, int32_t H, int32_t W, i
 int unetpp_bilinear2x_bwd_bf16(const void* dy, int32_t N, int32_t H, int32_t W, int32_t C, void* dx, int32_t accumulate,
                                const void* gate, void* stream);
 
+/* Input gradient of the network's first convolution (models/unet.py:220, 1..4 input channels) with bf16 activation
+ * storage: dy bf16 [N,H,W,COUT] (COUT a multiple of 8, <= 128), weight fp32 in its torch layout [COUT][CIN][3][3],
+ * dx fp32 [N,H,W,CIN].  (fp32 storage: unetpp_gemm_fwd with the rotated weights, as for every other layer.) */
+int unetpp_first_layer_dgrad_bf16(const void* dy, const float* weight, int32_t N, int32_t H, int32_t W, int32_t CIN,
+                                  int32_t COUT, float* dx, void* stream);
+
 /* ---- heat-map side of validation (tools/misc/heatmap.py; SURVEY 8 row f3 -- parity unpinned: the reference needs
  * OpenCV, absent from the build image) ------------------------------------------------------------------------------
  * unetpp_heatmap_pattern: Heatmap.create_heatmap (heatmap.py:203-230).  points [N, P, 2] as (x, y); map m draws the

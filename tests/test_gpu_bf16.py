@@ -632,6 +632,37 @@ def test_bf16_long_trajectory_tracks_fp32_at_base32(dev):
     assert la[-1] < 0.75 * la[0] and lb[-1] < 0.75 * lb[0], (la, lb)
 
 
+@pytest.mark.parametrize("cin,bn", [(3, True), (1, False)])
+def test_bf16_input_gradient(dev, cin, bn):
+    """The gradient with respect to the (fp32) network input in bf16 storage: against the fp32 oracle's input gradient
+    evaluated with the bf16 path's roundings and the HIP forward's gates (oracle/bf16_sim.py), relative L2 <= 6 %."""
+    from oracle.bf16_sim import forward_bf16_sim, routing_of
+    from oracle.unet_nested_oracle import UNetNestedOracle
+    from unet_nested4tiny_objects_keypoints_amd import UNet_Nested
+    ctor = dict(in_channels=cin, n_classes=4, feature_scale=4, is_batchnorm=bn)
+    torch.manual_seed(71)
+    ref = UNetNestedOracle(**ctor).train()
+    ref.drop_out.eval()
+    m = UNet_Nested(**ctor)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(dev).train().set_activation_dtype(BF)
+    m.drop_out.eval()
+    m._debug_keep_saved = True
+    x = torch.randn(2, cin, 32, 48)
+    probe = torch.randn(2, 4, 32, 48)
+    xg = x.to(dev).requires_grad_(True)
+    sum((o * probe.to(dev)).sum() for o in m(xg)).backward()
+    xr = x.double().requires_grad_(True)
+    so = forward_bf16_sim(ref, xr, routing=routing_of(m._debug_saved))
+    sum((o * probe.double()).sum() for o in so).backward()
+    got, want = xg.grad.double().cpu(), xr.grad
+    assert got.shape == want.shape and torch.isfinite(got).all()
+    l2 = float((got - want).norm() / want.norm())
+    cos = float((got * want).sum() / (got.norm() * want.norm()))
+    print("bf16 input gradient: rel L2 %.4f, cosine %.5f" % (l2, cos))
+    assert l2 <= 0.06 and cos >= 0.998, (l2, cos)
+
+
 def test_bf16_unsupported_configurations_raise(dev):
     from unet_nested4tiny_objects_keypoints_amd import UNet_Nested
     x = torch.randn(1, 1, 32, 32, device=dev)

@@ -137,6 +137,7 @@ SIGNATURES = {
     "unetpp_bn_bwd_reduce_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "unetpp_bn_bwd_apply_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "unetpp_head_fwd_bf16": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _P]),
+    "unetpp_first_layer_dgrad_bf16": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "unetpp_maxpool_bwd_bf16": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "unetpp_bilinear2x_fwd_bf16": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P]),
     "unetpp_bilinear2x_bwd_bf16": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _I32, _P, _P]),

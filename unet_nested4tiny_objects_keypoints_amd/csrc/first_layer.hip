@@ -283,6 +283,48 @@ __global__ __launch_bounds__(kThreads) void small_cin_wgrad_kernel(const SmallAr
   }
 }
 
+// Input gradient of the first convolution with bf16 activation storage: dx[n, y, x, ci] = sum_{r, s, co}
+// dy[n, y + 1 - r, x + 1 - s, co] * w[co, ci, r, s], dy bf16 NHWC [.., COUT], dx fp32 NHWC [.., CIN <= 4].  A rare path
+// (saliency / adversarial inputs: the training step needs no input gradient), so a plain VALU kernel: thread = pixel,
+// the 9 x COUT x CIN weights in LDS as [tap][co][ci], dy read in 16-byte pieces straight from L2.
+template <int CIN>
+__global__ __launch_bounds__(kThreads) void small_cin_dgrad_bf16_kernel(const bf16_t* __restrict__ dy,
+                                                                        const float* __restrict__ w, int N, int H, int W,
+                                                                        int COUT, float* __restrict__ dx) {
+  __shared__ float ws[9 * kMaxCout * CIN];
+  for (int i = threadIdx.x; i < 9 * COUT * CIN; i += kThreads) {
+    const int ci = i % CIN, co = (i / CIN) % COUT, tap = i / (CIN * COUT);
+    ws[i] = w[(static_cast<long>(co) * CIN + ci) * 9 + tap];  // torch layout [co][ci][3][3]
+  }
+  __syncthreads();
+  const long pixels = static_cast<long>(N) * H * W;
+  for (long p = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; p < pixels; p += static_cast<long>(gridDim.x) * kThreads) {
+    const int x = static_cast<int>(p % W);
+    const long r = p / W;
+    const int y = static_cast<int>(r % H);
+    const long n = r / H;
+    float acc[CIN];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) acc[ci] = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int yy = y + 1 - tap / 3, xx = x + 1 - tap % 3;
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+      const u32x4* src = reinterpret_cast<const u32x4*>(dy + ((n * H + yy) * W + xx) * COUT);
+      const float* wt = &ws[tap * COUT * CIN];
+      for (int c8 = 0; c8 < COUT; c8 += 8) {
+        float g[8];
+        unpack8(src[c8 >> 3], g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+          for (int ci = 0; ci < CIN; ++ci) acc[ci] = fmaf(g[e], wt[(c8 + e) * CIN + ci], acc[ci]);
+      }
+    }
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) dx[p * CIN + ci] = acc[ci];
+  }
+}
+
 bool plain_view(const unetpp_view& v) {
   return v.scale == nullptr && v.gate == nullptr && !v.relu && v.sy == 1 && v.sx == 1 && v.oy == 0 && v.ox == 0;
 }
@@ -392,3 +434,25 @@ int launch_small_cin_wgrad(const unetpp_wgrad_desc* d, hipStream_t st) {
 }
 
 }  // namespace unetpp
+
+// dy bf16 [N, H, W, COUT] (COUT a multiple of 8, at most 128), weight fp32 in torch layout [COUT][CIN][3][3], dx fp32 [N, H, W, CIN]
+extern "C" int unetpp_first_layer_dgrad_bf16(const void* dy, const float* weight, int32_t N, int32_t H, int32_t W,
+                                             int32_t CIN, int32_t COUT, float* dx, void* stream) {
+  using namespace unetpp;
+  if (!dy || !weight || !dx || N < 1 || H < 1 || W < 1 || CIN < 1 || CIN > 4 || COUT < 8 || (COUT & 7) || COUT > kMaxCout)
+    return UNETPP_EINVAL;
+  if (reinterpret_cast<uintptr_t>(dy) & 15) return UNETPP_EINVAL;
+  const long pixels = static_cast<long>(N) * H * W;
+  long blocks = (pixels + kThreads - 1) / kThreads;
+  if (blocks > 4096) blocks = 4096;
+  const dim3 grid(static_cast<unsigned>(blocks)), block(kThreads);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bf16_t* g = static_cast<const bf16_t*>(dy);
+  switch (CIN) {
+    case 1: hipLaunchKernelGGL(small_cin_dgrad_bf16_kernel<1>, grid, block, 0, st, g, weight, N, H, W, COUT, dx); break;
+    case 2: hipLaunchKernelGGL(small_cin_dgrad_bf16_kernel<2>, grid, block, 0, st, g, weight, N, H, W, COUT, dx); break;
+    case 3: hipLaunchKernelGGL(small_cin_dgrad_bf16_kernel<3>, grid, block, 0, st, g, weight, N, H, W, COUT, dx); break;
+    default: hipLaunchKernelGGL(small_cin_dgrad_bf16_kernel<4>, grid, block, 0, st, g, weight, N, H, W, COUT, dx); break;
+  }
+  return launch_status();
+}

@@ -382,7 +382,11 @@ def _pair_bwd(blk, r: _PairRec, d_out, in_targets: Optional[List[V]], b, grads, 
     if flush is not None:
         flush()
     if in_targets is not None:
-        ops.gemm_fwd(b, h, w, 9, [dy1], in_targets, pack_conv_dgrad(conv1.weight.detach()))
+        if dy1.t.dtype == torch.bfloat16 and in_targets[0].t.dtype == torch.float32:
+            # bf16 storage, gradient of the fp32 network input (1..4 channels): the first layer's own VALU kernel
+            ops.first_layer_dgrad_bf16(dy1.t, conv1.weight.detach(), in_targets[0].t)
+        else:
+            ops.gemm_fwd(b, h, w, 9, [dy1], in_targets, pack_conv_dgrad(conv1.weight.detach()))
 
 
 def _up_bwd(upmod, is_deconv, u: _UpRec, d_up, d_src, accumulate, gate, b, grads):
@@ -492,8 +496,8 @@ def _backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=No
                 t.zero_()
             pool_grad = (d_pooled, s.pairs[(i - 1, 0)].pool_idx)
         elif want_input_grad:
-            if s.X[(0, 0)].dtype != torch.float32:
-                raise NotImplementedError("the input gradient is not available with bf16 activation storage")
+            if bf16 and s.x_nhwc.shape[3] > 4:
+                raise NotImplementedError("bf16 storage: the input gradient needs at most 4 input channels")
             dx_in = torch.empty_like(s.x_nhwc)
             _pair_bwd(blk, r, d_out, [V(dx_in)], b, grads, pre_gated, pool_grad=mine, flush=flush)
         else:

@@ -416,6 +416,19 @@ def gemm_fwd(n: int, h: int, w: int, taps: int, ins: Sequence[V], outs: Sequence
                 (2.0 if d.flags & _lib.GEMM_BF16 else 4.0) * n * h * w * (k + nc + acc))
 
 
+def first_layer_dgrad_bf16(dy: torch.Tensor, weight: torch.Tensor, dx: torch.Tensor) -> None:
+    """dx fp32 [N,H,W,Cin<=4] = input gradient of the first 3x3 convolution from a bf16 dy [N,H,W,Cout]"""
+    n, h, w, co = dy.shape
+    ci = dx.shape[3]
+    _need(dy, "dy", torch.bfloat16)
+    _need(weight, "weight")
+    _need(dx, "dx")
+    if tuple(weight.shape) != (co, ci, 3, 3) or tuple(dx.shape[:3]) != (n, h, w):
+        raise ValueError("shape mismatch")
+    check(_lib.lib().unetpp_first_layer_dgrad_bf16(_ptr(dy), _ptr(weight), n, h, w, ci, co, _ptr(dx), _stream()),
+          "unetpp_first_layer_dgrad_bf16")
+
+
 def pack_weight(dst: torch.Tensor, src: torch.Tensor, t: int, k: int, n: int, dstr, sstr, flip: bool = False) -> None:
     _need(dst, "pack dst")
     _need(src, "pack src")
