@@ -298,6 +298,12 @@ def main():
         run_plain_unet_case("unet_ref_rgb5_64x64_b1", None, 5, 3, 1, (64, 64), 3, seeded=True)
         if only == "plain":
             return
+    if only in (None, "plain_odd"):
+        # sizes that are NOT multiples of 16: MaxPool2d floors (40x56 -> 20x28 -> 10x14 -> 5x7 -> 2x3) and `up` zero-pads
+        # the upsampled tensor to its skip partner (models/unet.py:63-70: 4x6 -> 5x7, pad right / bottom)
+        run_plain_unet_case("unet_w8_rgb5_40x56_b2", (8, 16, 32, 64, 64), 5, 3, 2, (40, 56), 4, seeded=False)
+        if only == "plain_odd":
+            return
     # configs[0]-sized: the reference-instantiable 4-level net at base width 8
     run_case("c1_fs4_64x64_b4_seed0", dict(in_channels=1, n_classes=4, feature_scale=4),
              4, (64, 64), 0, with_opt_steps=True, keypoints=True)

@@ -29,7 +29,7 @@ DEPTH_CASES = [
 # the reference's classic U-Net: a small-width instance built from the reference's own blocks with
 # its full state, and the reference's UNet() itself (13.4 M parameters: the state comes from `seeded_state`, the
 # fixture keeps the seed, outputs, loss, BatchNorm buffers and subsampled gradients)
-PLAIN_CASES = ["unet_w8_rgb5_32x48_b2", "unet_ref_rgb5_64x64_b1"]
+PLAIN_CASES = ["unet_w8_rgb5_32x48_b2", "unet_ref_rgb5_64x64_b1", "unet_w8_rgb5_40x56_b2"]
 GRAD_STRIDE = 1009  # large gradients are stored as flat[::GRAD_STRIDE]
 
 

@@ -492,7 +492,9 @@ def test_batchnorm_relu_pool_fwd_bwd(dev, c):
 
 
 @pytest.mark.parametrize("b,h,w,c,affine,relu", [(2, 8, 64, 32, True, True), (3, 6, 40, 20, True, True),
-                                                 (1, 4, 128, 64, False, False), (2, 4, 8, 8, True, True)])
+                                                 (1, 4, 128, 64, False, False), (2, 4, 8, 8, True, True),
+                                                 (2, 5, 7, 8, True, True), (1, 9, 6, 3, True, True),    # odd sizes: floor
+                                                 (1, 6, 5, 16, False, False)])
 def test_pool_argmax_and_routing_exact(dev, b, h, w, c, affine, relu):
     """Max-pool value, argmax (first maximum in scan order, ties from the ReLU zeros included) and the gradient
     routing, bit-exact against torch on the same activation; covers the row-structured and the generic kernels."""

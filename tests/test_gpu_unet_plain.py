@@ -51,7 +51,7 @@ def _pre_bn_bias(k):
     return k.endswith(".bias") and ".conv." in k and k.split(".")[-2] in ("0", "3")
 
 
-@pytest.mark.parametrize("name", ["unet_w8_rgb5_32x48_b2", "unet_ref_rgb5_64x64_b1"])
+@pytest.mark.parametrize("name", ["unet_w8_rgb5_32x48_b2", "unet_ref_rgb5_64x64_b1", "unet_w8_rgb5_40x56_b2"])
 def test_plain_unet_golden(dev, name):
     from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d
     z, ctor = load_golden(name)
@@ -140,6 +140,10 @@ def test_plain_unet_module_protocol(dev):
     assert torch.equal(a, b) and float(a.min()) >= 0.0 and float(a.max()) <= 1.0
     assert UNet().n_classes == 5 and UNet().n_channels == 3   # zero-argument constructor (models/unet.py:95)
     with pytest.raises(ValueError):
-        m(torch.randn(1, 3, 24, 32, device=dev))   # the HIP path takes sizes divisible by 16 only
+        m(torch.randn(1, 3, 12, 32, device=dev))   # four poolings need at least 16 pixels a side
+    with torch.no_grad():                          # sizes that are not multiples of 16: floor pooling + zero padding
+        odd = torch.randn(1, 3, 24, 37)
+        ref.eval()
+        assert rel_err(m(odd.to(dev)).cpu(), ref(odd)) < TOL
     with pytest.raises(RuntimeError):
         m(torch.randn(1, 3, 32, 32))               # CPU tensor: no fallback

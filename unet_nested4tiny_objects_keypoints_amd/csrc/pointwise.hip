@@ -1196,7 +1196,30 @@ extern "C" int unetpp_affine_relu_pool(const float* y, const float* scale, const
     }
     return launch_status();
   }
-  if ((H & 1) || (W & 1)) return UNETPP_EINVAL;
+  if (H < 2 || W < 2 || !pool_idx) return UNETPP_EINVAL;
+  if ((H & 1) || (W & 1)) {
+    // nn.MaxPool2d(2) floors (the classic UNet on sizes that are not multiples of 16, models/unet.py:40-46): the last
+    // odd row / column is in no window, but the activation is wanted for ALL pixels -- apply pass over the whole
+    // tensor first, then the window kernel on the activation (its index arithmetic uses H, W as strides and H/2, W/2 as
+    // the window grid; the winners are those of the transformed values either way)
+    const float* src = y;
+    if (act != nullptr) {
+      const int rc = unetpp_affine_relu_pool(y, scale, shift, relu, N, H, W, C, act, nullptr, nullptr, stream);
+      if (rc != UNETPP_OK) return rc;
+      src = act;
+      scale = shift = nullptr;
+      relu = 0;
+    }
+    const long win = static_cast<long>(N) * (H / 2) * (W / 2);
+    const bool v4 = (C % 4 == 0) && aligned16(src) && aligned16(pooled);
+    if (v4)
+      hipLaunchKernelGGL(affine_relu_pool_kernel<4>, dim3(grid_for(win * (C / 4))), dim3(kThreads), 0, ST(stream), src, scale,
+                         shift, relu, N, H, W, C / 4, static_cast<float*>(nullptr), pooled, pool_idx);
+    else
+      hipLaunchKernelGGL(affine_relu_pool_kernel<1>, dim3(grid_for(win * C)), dim3(kThreads), 0, ST(stream), src, scale, shift,
+                         relu, N, H, W, C, static_cast<float*>(nullptr), pooled, pool_idx);
+    return launch_status();
+  }
   const long windows = static_cast<long>(N) * (H / 2) * (W / 2);
   const unsigned rows = static_cast<unsigned>(N * (H / 2)), row_items = static_cast<unsigned>((W / 2) * (C / 4));
   if (vec && rows_form_ok(N, H, W, C) && (scale == nullptr || (aligned16(scale) && aligned16(shift))) &&
@@ -1217,10 +1240,10 @@ extern "C" int unetpp_affine_relu_pool(const float* y, const float* scale, const
 
 extern "C" int unetpp_maxpool_bwd(const float* d_pooled, const uint8_t* pool_idx, int32_t N, int32_t H, int32_t W,
                                   int32_t C, float* d_act, void* stream) {
-  if (!d_pooled || !pool_idx || !d_act || N < 1 || H < 2 || W < 2 || C < 1 || (H & 1) || (W & 1)) return UNETPP_EINVAL;
-  const long windows = static_cast<long>(N) * (H / 2) * (W / 2);
+  if (!d_pooled || !pool_idx || !d_act || N < 1 || H < 2 || W < 2 || C < 1) return UNETPP_EINVAL;
+  const long windows = static_cast<long>(N) * (H / 2) * (W / 2);  // odd H / W: the last row / column is in no window (floor)
   const unsigned rows = static_cast<unsigned>(N * (H / 2));
-  if (C % 4 == 0 && rows_form_ok(N, H, W, C) && aligned16(d_pooled) && aligned16(d_act) &&
+  if (!(H & 1) && !(W & 1) && C % 4 == 0 && rows_form_ok(N, H, W, C) && aligned16(d_pooled) && aligned16(d_act) &&
       (reinterpret_cast<uintptr_t>(pool_idx) & 3) == 0)
     hipLaunchKernelGGL(maxpool_bwd_rows_kernel, dim3(rows < 16384u ? rows : 16384u), dim3(kThreads), 0, ST(stream),
                        reinterpret_cast<const f32x4*>(d_pooled), reinterpret_cast<const uint32_t*>(pool_idx), rows,

@@ -9,8 +9,9 @@ One ``torch.autograd.Function`` covers the network.  Gradient fan-in: every enco
 block's input-gradient GEMM, the pooled contribution is routed to the window argmax inside the node's BatchNorm
 backward (no scatter pass, no memset).
 
-H and W must be divisible by 16: the pooling kernels take even sizes only, so the reference's pad-to-match branch
-(models/unet.py:68-72, active for other sizes) never has anything to pad here; other sizes raise ValueError.
+Any H, W >= 16: for sizes that are not multiples of 16 the pooling floors (nn.MaxPool2d, models/unet.py:41) and the
+upsampled tensor is zero-padded to its skip partner as the reference does (models/unet.py:63-70) -- pinned by the
+reference-generated fixture unet_w8_rgb5_40x56_b2.
 """
 from __future__ import annotations
 
@@ -57,8 +58,8 @@ def _check_input(model, x):
         raise TypeError("expected float32 input, got %s" % x.dtype)
     if x.shape[1] != model.n_channels:
         raise ValueError("expected %d input channels, got %d" % (model.n_channels, x.shape[1]))
-    if x.shape[2] % 16 or x.shape[3] % 16:
-        raise ValueError("H and W must be divisible by 16 on the HIP path, got %dx%d" % (x.shape[2], x.shape[3]))
+    if x.shape[2] < 16 or x.shape[3] < 16:
+        raise ValueError("H and W must be at least 16 (four 2x2 poolings), got %dx%d" % (x.shape[2], x.shape[3]))
     if next(model.parameters()).device != x.device:
         raise RuntimeError("model and input are on different devices")
 
@@ -79,8 +80,19 @@ def _forward(model, x, training: bool, save: bool):
     for k, name in enumerate(_DEC):  # :111-114: up(x1 = low, x2 = skip) -> cat([x2, up(x1)]) -> double_conv
         skip = enc[3 - k]
         hs, ws = skip.h, skip.w
-        interp = torch.empty((b, hs, ws, low.shape[3]), dtype=torch.float32, device=x.device)
-        ops.bilinear2x_fwd(low, interp)
+        hl, wl = low.shape[1], low.shape[2]
+        if (2 * hl, 2 * wl) == (hs, ws):
+            interp = torch.empty((b, hs, ws, low.shape[3]), dtype=torch.float32, device=x.device)
+            ops.bilinear2x_fwd(low, interp)
+        else:
+            # sizes that are not multiples of 16: the pooling floored, so the upsampled tensor is a row / column short
+            # of its skip partner and the reference zero-pads it (models/unet.py:63-70: diff // 2 before, the rest after).
+            # Pure data movement, by PyTorch: a zeroed tensor with the interpolation copied into its window.
+            tmp = torch.empty((b, 2 * hl, 2 * wl, low.shape[3]), dtype=torch.float32, device=x.device)
+            ops.bilinear2x_fwd(low, tmp)
+            interp = torch.zeros((b, hs, ws, low.shape[3]), dtype=torch.float32, device=x.device)
+            oy, ox = (hs - 2 * hl) // 2, (ws - 2 * wl) // 2
+            interp[:, oy:oy + 2 * hl, ox:ox + 2 * wl].copy_(tmp)
         r = _pair_fwd(pair_of(getattr(model, name).conv), [V(skip.out), V(interp)], b, hs, ws, training, pool=False)
         dec.append(r)
         interps.append(interp)
@@ -115,6 +127,10 @@ def _backward(model, s, d_out, want_input_grad: bool):
         _pair_bwd(pair_of(getattr(model, _DEC[k]).conv), r, d_cur, [V(d_skip[skip_i]), V(d_interp)], b, grads)
         low = s.dec[k - 1].out if k > 0 else s.enc[4].out
         d_low = torch.empty_like(low)
+        hl, wl, (hs, ws) = low.shape[1], low.shape[2], s.low_shapes[k][1:3]
+        if (2 * hl, 2 * wl) != (hs, ws):  # the padding's backward: the gradient of the window the interpolation was copied into
+            oy, ox = (hs - 2 * hl) // 2, (ws - 2 * wl) // 2
+            d_interp = d_interp[:, oy:oy + 2 * hl, ox:ox + 2 * wl].contiguous()
         ops.bilinear2x_bwd(d_interp, d_low, False)
         d_cur = d_low
     # encoder, deepest first: d_cur is the gradient of x5; every level hands the gradient of its pooled input upwards,
