@@ -312,6 +312,13 @@ def main():
     averager = None
     if distributed:
         averager = dp.make_data_parallel(model)
+    elif os.environ.get("UNETPP_BENCH_FORCE_DP") == "1":
+        # diagnostic (never set by the driver): the data-parallel machinery in a world of one -- flat gradient buffer,
+        # bucketed RCCL all-reduce on the side stream, delivery into p.grad -- to price what it costs beside the kernels
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29544")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        averager = dp.make_data_parallel(model, always_reduce=True)
     torch.manual_seed(1000 + rank)  # every rank its own shard of synthetic data
     x = torch.randn(args.batch, args.in_channels, args.size, args.size, device=dev)
     target = torch.rand(args.batch, n_cls, args.size, args.size, device=dev)
