@@ -84,20 +84,22 @@ def test_conv3x3_bf16_forward(dev, b, h, w, cins, cout, affine):
     assert ops._lib.lib().unetpp_last_kernel_name() in (b"gemm_bf16_kernel<9>", b"gemm_bf16_dma_kernel<9>")
 
 
-def _both_kernels(fn):
-    """run fn() with the LDS-DMA kernel (default where it applies) and with the register-staged one; -> results, names"""
+def _both_kernels(fn, forms=(4, 0)):
+    """run fn() with the LDS-DMA kernel in the given forms (8 = 8 waves / 512-pixel patches, 4 = 4 waves / 256-pixel
+    patches; forced also where they are not the default) and with the register-staged one (0); -> [(results, name)]"""
     import os
 
     from unet_nested4tiny_objects_keypoints_amd import ops
     out = []
-    for off in (False, True):
-        os.environ["UNETPP_BF16_NO_DMA" if off else "UNETPP_BF16_DMA_ALL"] = "1"   # DMA_ALL: also where it is not the default
+    for form in forms:
+        os.environ["UNETPP_BF16_DMA_FORM"] = str(form)
+        os.environ["UNETPP_BF16_DMA_ALL"] = "1"
         try:
             res = fn()
             torch.cuda.synchronize()
             out.append((res, ops._lib.lib().unetpp_last_kernel_name()))
         finally:
-            os.environ.pop("UNETPP_BF16_NO_DMA", None)
+            os.environ.pop("UNETPP_BF16_DMA_FORM", None)
             os.environ.pop("UNETPP_BF16_DMA_ALL", None)
     return out
 
@@ -108,6 +110,9 @@ def _both_kernels(fn):
     (3, 16, 16, (32, 32), 96),         # 16 x 16 patches
     (2, 8, 8, (128,), 32),             # 8 x 32 patches, four chunks
     (1, 70, 33, (32,), 64),            # odd sizes
+    (2, 40, 64, (128,), 32),           # four chunks into one tile: the 8-wave form keeps the whole weight image in LDS
+    (1, 24, 96, (64,), 64),            # two chunks x two tiles: resident, two tiles per staged patch
+    (1, 50, 40, (32, 32, 32), 96),     # three tiles (one per unit), ragged 16-row patches
 ])
 @pytest.mark.parametrize("mode", ["relu", "stats", "dgrad"])
 def test_bf16_dma_and_register_kernels_agree(dev, b, h, w, cins, cout, mode):
@@ -144,10 +149,13 @@ def test_bf16_dma_and_register_kernels_agree(dev, b, h, w, cins, cout, mode):
                 part = torch.zeros(ops.gemm_pixel_blocks(b, h, w) * cout * 2, device=dev)
             ops.gemm_fwd(b, h, w, 9, [V(x) for x in xs], [V(y, relu=(mode == "relu"))], engine.pack_conv_fwd(wt), bias, part)
             return [y] + ([part] if part is not None else [])
-    (dma, dma_name), (reg, reg_name) = _both_kernels(run)
-    assert dma_name == b"gemm_bf16_dma_kernel<9>" and reg_name == b"gemm_bf16_kernel<9>"
-    for a_, b_ in zip(dma, reg):
-        assert torch.equal(a_.view(torch.int16) if a_.dtype == BF else a_, b_.view(torch.int16) if b_.dtype == BF else b_)
+    (dma8, name8), (dma, dma_name), (reg, reg_name) = _both_kernels(run, forms=(8, 4, 0))
+    assert name8 == dma_name == b"gemm_bf16_dma_kernel<9>" and reg_name == b"gemm_bf16_kernel<9>"
+    bits = lambda t: t.view(torch.int16) if t.dtype == BF else t   # noqa: E731
+    for a8, a_, b_ in zip(dma8, dma, reg):
+        assert torch.equal(bits(a_), bits(b_))
+        if mode != "stats":   # (statistics launches have no 8-wave form: the request falls back to 4 waves)
+            assert torch.equal(bits(a8), bits(b_))
 
 
 @pytest.mark.parametrize("b,hs,ws,ci,co", [(2, 12, 20, 64, 32), (1, 32, 32, 128, 64), (3, 5, 9, 32, 32)])

@@ -56,22 +56,30 @@ struct DmaArgs {
   int wimg_bytes;   // size of the launch's weight image in bytes (n_tiles * n_chunks * IMG)
 };
 
-template <int TAPS, int LOG2TW, int NT, bool STATS>
-__global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArgs da) {
+// WAVES = 4: 256-pixel patches (8 x 32), two workgroups per CU (2 x 80 KB).  WAVES = 8: 512-pixel patches (16 x 32:
+// 1.19x halo instead of 1.33x), one workgroup per CU, up to two column tiles per staged patch and a 72 KB weight region
+// that holds the launch's WHOLE weight image when it has at most four (tile, chunk) images (K = 128 -> 32, 64 -> 64):
+// everything that passes through a CU's vector memory path costs the same whether it comes from HBM or hits the L2, so
+// the bytes per pixel -- halo, patch re-staging per column group, weight re-streaming per chunk -- are what to cut.
+template <int TAPS, int LOG2TW, int NT, bool STATS, int WAVES = 4>
+__global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaArgs da) {
   const FastArgs& a = da.f;
+  constexpr int THREADS = 64 * WAVES, PIX = 64 * WAVES;
+  static_assert(WAVES == 4 || (WAVES == 8 && TAPS == 9 && !STATS), "the 8-wave form: plain 3x3 launches");
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
-  constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;
+  constexpr int TW = 1 << LOG2TW, TH = PIX >> LOG2TW;
   constexpr int HWp = TW + 2 * HALO, HHp = TH + 2 * HALO;
   constexpr int NPIX = HWp * HHp;
   constexpr int NBLK = (NPIX + 15) / 16;        // 1 KB blocks of 16 pixels x 4 octets
   constexpr int IN_BYTES = NBLK * 1024;         // 22528 (3x3) / 16384 (pointwise): >= the 4 x 4 KB epilogue scratch + 1 KB
   constexpr int IMG = TAPS * 2 * DSTEP;         // bytes of one (column tile, chunk) image
-  constexpr int W_BYTES = NT * IMG;
-  constexpr int NQ = (NBLK + 3) / 4;            // input blocks per wave
-  constexpr int WBLK = W_BYTES / 1024, NWQ = (WBLK + 3) / 4;
+  constexpr int W_BYTES = NT * IMG;             // the NT images of one chunk
+  constexpr int W_SLOTS = (WAVES == 8) ? 4 / NT : 2;   // chunks the weight region holds (two of them = the streaming ring)
+  constexpr int NQ = (NBLK + WAVES - 1) / WAVES;       // input blocks per wave
+  constexpr int WBLK = W_BYTES / 1024, NWQ = (WBLK + WAVES - 1) / WAVES;
   static_assert(!STATS || IN_BYTES >= 4 * 4096 + 1024, "epilogue scratch + statistics rows do not fit in an input buffer");
-  static_assert(2 * (IN_BYTES + W_BYTES) <= 80 * 1024, "two workgroups per CU");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * IN_BYTES + 2 * W_BYTES];
+  static_assert(2 * IN_BYTES + W_SLOTS * W_BYTES <= (WAVES == 4 ? 80 : 160) * 1024, "LDS: two workgroups (one) per CU");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * IN_BYTES + W_SLOTS * W_BYTES];
 
   const unetpp_gemm_desc& d = a.d;
   const int tid = threadIdx.x;
@@ -82,10 +90,24 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
   const int my_units = __builtin_amdgcn_readfirstlane(static_cast<int>(ur.count));
   if (my_units == 0) return;
   long p_index = ur.first, c_index = ur.first;
+  auto decode = [&](long lb) {  // (gemm_units.h's decode_unit with this kernel's patch height; a.tiles_y counts TH-row patches)
+    UnitGeom g;
+    unsigned bid = static_cast<unsigned>(lb);
+    g.group = static_cast<int>(bid % static_cast<unsigned>(a.n_groups));
+    bid /= static_cast<unsigned>(a.n_groups);
+    g.patch = bid;
+    const int txi = static_cast<int>(bid % static_cast<unsigned>(a.tiles_x));
+    bid /= static_cast<unsigned>(a.tiles_x);
+    const int tyi = static_cast<int>(bid % static_cast<unsigned>(a.tiles_y));
+    g.n = static_cast<int>(bid / static_cast<unsigned>(a.tiles_y));
+    g.ty0 = tyi * TH;
+    g.tx0 = txi * TW;
+    return g;
+  };
   auto step_unit = [&](UnitGeom& u, long& index) {
     if constexpr (!CONTIG) {
       index += ur.step;
-      u = decode_unit<LOG2TW>(a, index);
+      u = decode(index);
       u.n = __builtin_amdgcn_readfirstlane(u.n);
       u.ty0 = __builtin_amdgcn_readfirstlane(u.ty0);
       u.tx0 = __builtin_amdgcn_readfirstlane(u.tx0);
@@ -104,7 +126,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
     u.ty0 = 0;
     ++u.n;
   };
-  UnitGeom p_ug = decode_unit<LOG2TW>(a, ur.first);
+  UnitGeom p_ug = decode(ur.first);
   p_ug.n = __builtin_amdgcn_readfirstlane(p_ug.n);
   p_ug.ty0 = __builtin_amdgcn_readfirstlane(p_ug.ty0);
   p_ug.tx0 = __builtin_amdgcn_readfirstlane(p_ug.tx0);
@@ -138,7 +160,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
   int item_hy[NQ], item_hx[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const int blk = (wave + 4 * q < NBLK) ? wave + 4 * q : wave;  // (see dma_chunk: a block past the patch repeats block `wave`)
+    const int blk = (wave + WAVES * q < NBLK) ? wave + WAVES * q : wave;  // (see dma_chunk: a block past the patch repeats block `wave`)
     const int hp = blk * 16 + (lane & 15);
     item_hy[q] = hp / HWp;
     item_hx[q] = hp - item_hy[q] * HWp;
@@ -173,9 +195,21 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
   // LDS-DMA in flight, which a 64-bit vector address per weight piece needs).
   // LDS: input buffers 0 / 1, then weight buffers 0 / 1 (toggled separately: see the pipeline below)
   const int lane16 = lane * 16;
+  auto dma_weights = [&](int w_slot, int group_off, int chunk) {  // the NT images of (column group, chunk) -> region slot
+    unsigned char* w_dst = smem + 2 * IN_BYTES + w_slot * W_BYTES;
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.weight_image), 0, da.wimg_bytes, 0x00020000);
+    const int wchunk = group_off + chunk * IMG;
+#pragma unroll
+    for (int q = 0; q < NWQ; ++q) {
+      const int blk = (wave + WAVES * q < WBLK) ? wave + WAVES * q : wave;  // 1 KB block of the NT images (uniform)
+      const int t = blk / (IMG / 1024), r = blk - t * (IMG / 1024);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (dma_lptr_t)(w_dst + blk * 1024), 16, lane16,
+                                               wchunk + t * a.n_chunks * IMG + r * 1024, 0, 0);
+    }
+  };
   auto dma_chunk = [&](int in_buf, int w_buf, bool need_in, bool need_w) {
     unsigned char* in_dst = smem + in_buf * IN_BYTES;
-    unsigned char* w_dst = smem + 2 * IN_BYTES + w_buf * W_BYTES;
     if (need_in) {  // uniform
     const unetpp_view& V = d.in[p_s];
     const __amdgpu_buffer_rsrc_t rsrc =
@@ -183,21 +217,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
     const int soff = ((V.oy * V.Ws + V.ox) * V.C + V.c_off + p_c0) * 2;  // phase origin, channel slice, chunk (bytes)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int blk = (wave + 4 * q < NBLK) ? wave + 4 * q : wave;  // uniform
+      const int blk = (wave + WAVES * q < NBLK) ? wave + WAVES * q : wave;  // uniform
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (dma_lptr_t)(in_dst + blk * 1024), 16, static_cast<int>(voff[q]), soff, 0, 0);
     }
     }
-    if (!need_w) return;
-    const __amdgpu_buffer_rsrc_t wrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.weight_image), 0, da.wimg_bytes, 0x00020000);
-    const int wchunk = p_wimg + p_chunk * IMG;
-#pragma unroll
-    for (int q = 0; q < NWQ; ++q) {
-      const int blk = (wave + 4 * q < WBLK) ? wave + 4 * q : wave;  // 1 KB block of the NT images of this chunk (uniform)
-      const int t = blk / (IMG / 1024), r = blk - t * (IMG / 1024);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (dma_lptr_t)(w_dst + blk * 1024), 16, lane16,
-                                               wchunk + t * a.n_chunks * IMG + r * 1024, 0, 0);
-    }
+    if (need_w) dma_weights(w_buf, p_wimg, p_chunk);
   };
   // next chunk of the unit, or chunk 0 of the next unit; false when nothing is left
   auto advance = [&]() -> bool {
@@ -468,10 +492,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
   // the 32 -> 32 layers of level 0) -- it stays in its buffer; the input patch when the next unit is the next column
   // group of the same patch and a unit is one chunk (input gradients of a 32-channel dy into 64..128 channels) -- the
   // input buffer is not toggled.  The kernel is bound by what a CU's memory pipeline moves (~10 B/clk), not by HBM. ----
-  const bool w_resident = a.n_chunks == 1 && a.n_groups == 1;   // uniform
+  const bool w_resident = a.n_groups == 1 && a.n_chunks <= W_SLOTS;   // uniform: the whole image fits the weight region
   const bool in_reuse = !STATS && a.n_chunks == 1;              // (the statistics epilogue uses the input buffer as scratch)
   prefetch_unit();
   dma_chunk(0, 0, true, true);
+  if (w_resident) {
+    for (int c = 1; c < a.n_chunks; ++c) dma_weights(c, 0, c);  // slot c = chunk c, for the whole launch
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -485,7 +512,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_dma_kernel(const DmaArg
     }
     const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
     const unsigned in_base = lds0 + static_cast<unsigned>(in_cur) * IN_BYTES;
-    const unsigned w_base = lds0 + 2 * IN_BYTES + static_cast<unsigned>(w_cur) * W_BYTES;
+    const unsigned w_base = lds0 + 2 * IN_BYTES + static_cast<unsigned>(w_resident ? c_chunk : w_cur) * W_BYTES;
     Frag fr[2];
     asm volatile("" ::: "memory");  // the reads below stay behind the barrier that published this buffer
     issue_frag(IC<0>{}, fr[0], in_base, w_base);
@@ -559,12 +586,22 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
   FastArgs& a = da.f;
   if (!bf16_gemm_args(d, a) || d->weight_image == nullptr) return 1;
   if (d->stats_partial != nullptr && d->n_out != 1) return 1;
-  // Taken where it is measured faster than gemm_bf16.hip (tools/bench_kernels.py, 512 x 512 x 8): 3x3 launches into at
-  // most 32 columns (level 0: 7-8 % on 32 -> 32, 5-10 % on 64..128 -> 32).  With more column tiles this kernel re-stages
-  // the patch per 32-column group (one tile per unit) where the register kernel feeds two tiles from one staging, and the
-  // pointwise GEMMs of the transposed convolutions are faster there too.  UNETPP_BF16_DMA_ALL=1 lifts the restriction
-  // (tests run every shape class through both kernels).
-  if (getenv("UNETPP_BF16_DMA_ALL") == nullptr && (d->taps != 9 || a.n_tiles != 1)) return 1;
+  // Which form (tools/bench_kernels.py, 512 x 512 x 8; UNETPP_BF16_DMA_FORM = 0 / 4 / 8 forces none / one of them, and
+  // UNETPP_BF16_DMA_ALL=1 lifts the restrictions: the tests run every shape class through both kernels):
+  //   8 waves, 512-pixel patches   plain 3x3 launches on images at least 32 wide with more than one chunk or column tile
+  //   4 waves, 256-pixel patches   3x3 launches of ONE chunk into ONE tile (32 -> 32: its image is resident either way
+  //                                and two independent workgroups per CU overlap better), statistics launches never
+  //   neither (gemm_bf16.hip)      BatchNorm-statistics launches, load transforms, the pointwise GEMMs
+  const bool all = getenv("UNETPP_BF16_DMA_ALL") != nullptr;
+  const bool stats = d->stats_partial != nullptr;
+  int form = 4;
+  if (d->taps == 9 && !stats && a.log2tw == 5 && (a.n_chunks > 1 || a.n_tiles > 1)) form = 8;
+  if (const char* e = getenv("UNETPP_BF16_DMA_FORM"); e != nullptr) {
+    const int want = atoi(e);
+    if (want == 0) return 1;
+    if (want == 4 || (want == 8 && d->taps == 9 && !stats && a.log2tw == 5)) form = want;
+  }
+  if (!all && form == 4 && (d->taps != 9 || a.n_tiles != 1 || stats)) return 1;
   const unetpp_view& V0 = d->in[0];
   for (int i = 0; i < d->n_in; ++i) {
     const unetpp_view& v = d->in[i];
@@ -583,17 +620,32 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
   const long wimg_bytes = static_cast<long>(a.n_tiles) * a.n_chunks * (d->taps * 2 * DSTEP);
   if (wimg_bytes > 0x7fffffffL) return 1;
   da.wimg_bytes = static_cast<int>(wimg_bytes);
-  // 3x3: one column tile per unit (two weight buffers of 18 KB beside two input buffers of 22 KB: 80 KB, two workgroups
-  // per CU); pointwise: two tiles when the launch has an even number of them
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return UNETPP_ELAUNCH;
+  if (form == 8) {
+    // 16 x 32 patches; two column tiles per unit when the launch has an even number of them
+    const int nt = (a.n_tiles % 2 == 0) ? 2 : 1;
+    a.nt_unit = nt;
+    a.n_groups = a.n_tiles / nt;
+    a.tiles_y = (d->H + 15) / 16;
+    a.total_blocks = static_cast<long>(d->N) * a.tiles_y * a.tiles_x * a.n_groups;
+    long workers = static_cast<long>(cus) & ~7L;  // one 8-wave workgroup per CU
+    if (workers < 8) workers = 8;
+    const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(512);
+    if (nt == 2) hipLaunchKernelGGL((gemm_bf16_dma_kernel<9, 5, 2, false, 8>), grid, block, 0, st, da);
+    else hipLaunchKernelGGL((gemm_bf16_dma_kernel<9, 5, 1, false, 8>), grid, block, 0, st, da);
+    note_kernel("gemm_bf16_dma_kernel<9>");
+    return launch_status();
+  }
+  // 4 waves, 3x3: one column tile per unit (two weight buffers of 18 KB beside two input buffers of 22 KB: 80 KB, two
+  // workgroups per CU); pointwise: two tiles when the launch has an even number of them
   if (d->taps == 9 && a.nt_unit == 2) {
     a.nt_unit = 1;
     a.n_groups = a.n_tiles;
     a.total_blocks *= 2;
   }
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-    return UNETPP_ELAUNCH;
   long workers = (2L * cus) & ~7L;
   if (workers < 8) workers = 8;
   const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(kThreads);
@@ -603,7 +655,6 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
     else if (a.log2tw == 4) hipLaunchKernelGGL((gemm_bf16_dma_kernel<T, 4, NTU, ST>), grid, block, 0, st, da); \
     else hipLaunchKernelGGL((gemm_bf16_dma_kernel<T, 3, NTU, ST>), grid, block, 0, st, da);                    \
   } while (0)
-  const bool stats = d->stats_partial != nullptr;
   if (d->taps == 9) {
     if (stats) UNETPP_LAUNCH_BF16_DMA(9, 1, true);
     else UNETPP_LAUNCH_BF16_DMA(9, 1, false);
