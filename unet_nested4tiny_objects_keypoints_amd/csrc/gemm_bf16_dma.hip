@@ -492,13 +492,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
   // the 32 -> 32 layers of level 0) -- it stays in its buffer; the input patch when the next unit is the next column
   // group of the same patch and a unit is one chunk (input gradients of a 32-channel dy into 64..128 channels) -- the
   // input buffer is not toggled.  The kernel is bound by what a CU's memory pipeline moves (~10 B/clk), not by HBM. ----
-  const bool w_resident = a.n_groups == 1 && a.n_chunks <= W_SLOTS;   // uniform: the whole image fits the weight region
+  // uniform: the launch's whole weight image fits the weight region (slot = column group * chunks + chunk)
+  const bool w_resident = a.n_groups * a.n_chunks <= W_SLOTS;
   const bool in_reuse = !STATS && a.n_chunks == 1;              // (the statistics epilogue uses the input buffer as scratch)
   prefetch_unit();
-  dma_chunk(0, 0, true, true);
   if (w_resident) {
-    for (int c = 1; c < a.n_chunks; ++c) dma_weights(c, 0, c);  // slot c = chunk c, for the whole launch
+    for (int g = 0; g < a.n_groups; ++g)
+      for (int c = 0; c < a.n_chunks; ++c) dma_weights(g * a.n_chunks + c, g * NT * a.n_chunks * IMG, c);  // for the whole launch
   }
+  dma_chunk(0, 0, true, !w_resident);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
     }
     const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
     const unsigned in_base = lds0 + static_cast<unsigned>(in_cur) * IN_BYTES;
-    const unsigned w_base = lds0 + 2 * IN_BYTES + static_cast<unsigned>(w_resident ? c_chunk : w_cur) * W_BYTES;
+    const unsigned w_base = lds0 + 2 * IN_BYTES + static_cast<unsigned>(w_resident ? c_ug.group * a.n_chunks + c_chunk : w_cur) * W_BYTES;
     Frag fr[2];
     asm volatile("" ::: "memory");  // the reads below stay behind the barrier that published this buffer
     issue_frag(IC<0>{}, fr[0], in_base, w_base);
@@ -595,7 +597,13 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
   const bool all = getenv("UNETPP_BF16_DMA_ALL") != nullptr;
   const bool stats = d->stats_partial != nullptr;
   int form = 4;
-  if (d->taps == 9 && !stats && a.log2tw == 5 && (a.n_chunks > 1 || a.n_tiles > 1)) form = 8;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    return UNETPP_ELAUNCH;
+  // (the 8-wave form only when its 512-pixel units still cover the chip: the deepest layers of a small image do not)
+  const long units8 = static_cast<long>(d->N) * ((d->H + 15) / 16) * a.tiles_x * ((a.n_tiles % 2 == 0) ? a.n_tiles / 2 : a.n_tiles);
+  if (d->taps == 9 && !stats && a.log2tw == 5 && (a.n_chunks > 1 || a.n_tiles > 1) && units8 >= 2L * cus) form = 8;
   if (const char* e = getenv("UNETPP_BF16_DMA_FORM"); e != nullptr) {
     const int want = atoi(e);
     if (want == 0) return 1;
@@ -620,10 +628,6 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
   const long wimg_bytes = static_cast<long>(a.n_tiles) * a.n_chunks * (d->taps * 2 * DSTEP);
   if (wimg_bytes > 0x7fffffffL) return 1;
   da.wimg_bytes = static_cast<int>(wimg_bytes);
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-    return UNETPP_ELAUNCH;
   if (form == 8) {
     // 16 x 32 patches; two column tiles per unit when the launch has an even number of them
     const int nt = (a.n_tiles % 2 == 0) ? 2 : 1;
