@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNETPP_ABI_VERSION 6
+#define UNETPP_ABI_VERSION 7
 #define UNETPP_MAX_VIEWS 8
 
 #define UNETPP_OK 0
@@ -175,6 +175,10 @@ int32_t unetpp_wgrad_max_split(int32_t N, int32_t H, int32_t W);
  * F(2x2,3x3) kernel (3x3, plain 16-byte aligned views, images at least 17 wide, no UNETPP_GEMM_DIRECT in flags): it
  * accumulates transform-domain products and unetpp_wgrad_finish(taps = 16) maps them back to the 9 taps. */
 int32_t unetpp_wgrad_slab_planes(const unetpp_wgrad_desc* d);
+/* (32-channel, 32-column) tile pairs one workgroup of the kernel chosen for this descriptor owns: 1, or 4 for the bf16
+ * kernel of layers whose views are all multiples of 64 channels wide (one workgroup per CU).  unetpp_wgrad launches
+ * n_split * pairs / this workgroups; the caller sizes n_split with it. */
+int32_t unetpp_wgrad_pairs_per_workgroup(const unetpp_wgrad_desc* d);
 int unetpp_wgrad(const unetpp_wgrad_desc* d, void* stream);
 /* `taps` = planes per slab.  column n = o*n_inner + i:  dw[t*d_t + k*d_k + i*d_n + o*d_o] = sum_s slabs[s][t*K + k][n];
  * db[i] = sum_o sum_s slabs[s][taps*K][o*n_inner + i]   (n_inner = Ncols for a plain convolution) */

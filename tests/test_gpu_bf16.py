@@ -7,6 +7,8 @@ rounding of the stored result to bf16 (half an ulp = 2^-9 relative), so the bar 
     |got - want| <= 2^-8 * |want| + 1e-5 * max|want|                    (TOL_ULP)
 for bf16 outputs and 1e-4 relative for fp32 outputs (weight gradients, statistics).
 """
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -234,13 +236,27 @@ def test_deconv2x2_bf16_forward_and_input_gradient(dev):
     close_bf16(dx.permute(0, 3, 1, 2), want_dx, "deconv input gradient")
 
 
+def _quad_layer(cis, cols):
+    """views all multiples of 64 channels wide: the 64 x 64 quad kernel (wgrad_bf16.hip) takes the layer"""
+    return all(c % 64 == 0 for c in cis) and all(c % 64 == 0 for c in cols)
+
+
 @pytest.mark.parametrize("b,h,w,cis,co,affine", [
     (2, 16, 16, (32,), 32, False),
     (3, 24, 40, (64, 32), 64, False),
     (2, 8, 16, (16, 40), 24, False),
     (2, 32, 32, (32,), 32, True),
+    # quad kernel: the three patch shapes (W >= 32, 16, 8), ragged borders, several views, BatchNorm + ReLU on load
+    (2, 32, 64, (64,), 64, False),
+    (3, 24, 40, (64, 128), 64, True),
+    (2, 16, 16, (128,), 128, True),
+    (5, 8, 8, (64, 64), 192, False),
+    (2, 72, 100, (64,), 128, True),
+    (1, 16, 24, (256,), 256, True),       # wide: few slabs, the transposing finish kernel
+    (1, 8, 16, (128, 192), 320, False),
 ])
-def test_conv3x3_bf16_weight_gradient(dev, b, h, w, cis, co, affine):
+@pytest.mark.parametrize("target_blocks", [256, 3, 4096])
+def test_conv3x3_bf16_weight_gradient(dev, b, h, w, cis, co, affine, target_blocks):
     from unet_nested4tiny_objects_keypoints_amd import ops
     from unet_nested4tiny_objects_keypoints_amd.ops import V
     g = torch.Generator().manual_seed(4)
@@ -257,25 +273,39 @@ def test_conv3x3_bf16_weight_gradient(dev, b, h, w, cis, co, affine):
     ci = sum(cis)
     dw = torch.empty(co, ci, 3, 3, device=dev)
     db = torch.empty(co, device=dev)
-    ops.wgrad(b, h, w, 9, views, [V(nhwc(dy).to(BF).to(dev))], dw, (1, 9, ci * 9, 0), db)
-    assert ops._lib.lib().unetpp_last_kernel_name() == b"wgrad_bf16_kernel<9>"
+    dyd = nhwc(dy).to(BF).to(dev)
+    ops.wgrad(b, h, w, 9, views, [V(dyd)], dw, (1, 9, ci * 9, 0), db, target_blocks=target_blocks)
+    quad = _quad_layer(cis, (co,))
+    assert ops._lib.lib().unetpp_last_kernel_name() == (b"wgrad_bf16_quad_kernel<9>" if quad else b"wgrad_bf16_kernel<9>")
     xcat, dyr = torch.cat(xin, 1), rb(dy)
     want = torch.nn.grad.conv2d_weight(xcat, (co, ci, 3, 3), dyr, padding=1)
     close_f32(dw, want, 1e-4, "dW")
     close_f32(db, dyr.sum((0, 2, 3)), 1e-4, "db")
+    if quad:   # the pair kernel on the same operands: same products, another summation order
+        dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
+        os.environ["UNETPP_BF16_WGRAD_QUAD"] = "0"
+        try:
+            ops.wgrad(b, h, w, 9, views, [V(dyd)], dw2, (1, 9, ci * 9, 0), db2, target_blocks=target_blocks)
+            assert ops._lib.lib().unetpp_last_kernel_name() == b"wgrad_bf16_kernel<9>"
+        finally:
+            del os.environ["UNETPP_BF16_WGRAD_QUAD"]
+        close_f32(dw2, dw.double().cpu(), 1e-5, "dW pair vs quad")
+        close_f32(db2, db.double().cpu(), 1e-5, "db pair vs quad")
 
 
-def test_deconv2x2_bf16_weight_gradient(dev):
+@pytest.mark.parametrize("b,hs,ws,ci,co", [(2, 12, 20, 64, 32), (2, 12, 20, 64, 64), (3, 16, 16, 128, 64), (1, 40, 8, 128, 128)])
+def test_deconv2x2_bf16_weight_gradient(dev, b, hs, ws, ci, co):
     from unet_nested4tiny_objects_keypoints_amd import engine, ops
     from unet_nested4tiny_objects_keypoints_amd.ops import V
     g = torch.Generator().manual_seed(5)
-    b, hs, ws, ci, co = 2, 12, 20, 64, 32
     x = torch.randn(b, ci, hs, ws, generator=g)
     d_up = torch.randn(b, co, 2 * hs, 2 * ws, generator=g)
     dw = torch.empty(ci, co, 2, 2, device=dev)
     db = torch.empty(co, device=dev)
     ops.wgrad(b, hs, ws, 1, [V(nhwc(x).to(BF).to(dev))], engine._phase_views(nhwc(d_up).to(BF).to(dev)), dw,
               (0, 4 * co, 4, 1), db, n_inner=co)
+    assert ops._lib.lib().unetpp_last_kernel_name() == (b"wgrad_bf16_quad_kernel<1>" if _quad_layer((ci,), (co,))
+                                                        else b"wgrad_bf16_kernel<1>")
     xr, dr = rb(x), rb(d_up)
     want = torch.einsum("nchw,nkhawb->ckab", xr, dr.view(b, co, hs, 2, ws, 2))
     close_f32(dw, want, 1e-4, "deconv dW")

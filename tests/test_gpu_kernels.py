@@ -374,7 +374,8 @@ def test_conv3x3_wgrad(dev, shape):
 
 @pytest.mark.parametrize("shape", [(1, 32, 32, [32, 32, 32], 32), (3, 64, 64, [16], 16), (2, 24, 40, [8], 12),
                                    (1, 37, 21, [20, 12], 36), (2, 16, 16, [8], 8), (1, 128, 128, [64], 64),
-                                   (2, 6, 18, [12], 40)])
+                                   (2, 6, 18, [12], 40),
+                                   (1, 16, 24, [256], 256), (1, 8, 8, [128, 192], 224)])   # wide: the transposing finish
 @pytest.mark.parametrize("direct", [False, True])
 def test_conv3x3_wgrad_plain_views(dev, shape, direct):
     """Plain views: the LDS-DMA kernels.  Winograd F(2x2,3x3) weight gradient (images at least 17 wide) and the direct

@@ -73,7 +73,7 @@ for name, hw, cins, co in CONVS:
     t_d = timeit(lambda: ops.gemm_fwd(B, hw, hw, 9, [V(y)], [V(t) for t in dxs], wd))
     dw, db = torch.empty_like(w), torch.empty_like(bias)
     t_w = timeit(lambda: ops.wgrad(B, hw, hw, 9, [V(t) for t in xs], [V(y)], dw, (1, 9, ci * 9, 0), db,
-                                   target_blocks=int(os.environ.get("TB", "512"))))
+                                   target_blocks=int(os.environ.get("TB", "256"))))
     for k, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)):
         tot_ms[k] += t
         tot_fl[k] += flops

@@ -18,7 +18,7 @@ INCLUDE = os.path.join(_REPO, "include")
 SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_wino.hip", "gemm_bf16.hip", "gemm_bf16_dma.hip", "wgrad_bf16.hip", "pointwise_bf16.hip", "keypoints.hip", "weight_image.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "wgrad_wino.hip", "first_layer.hip", "pointwise.hip", "caller.hip")
 HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h", "lds_asm.h", "bf16_common.h", "dropout.h", "bn_fused.h")
 MAX_VIEWS = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 # packed-f32 VALU (SLP-vectorised add pairs) costs issue slots beside MFMAs: keep the Winograd transforms scalar
 EXTRA_FLAGS = {"gemm_wino.hip": ("-fno-slp-vectorize",), "wgrad_wino.hip": ("-fno-slp-vectorize",)}
 GEMM_DIRECT = 1  # unetpp_gemm_desc.flags: direct summation only (no Winograd)
@@ -105,6 +105,7 @@ SIGNATURES = {
     "unetpp_gemm_pack_weight_images": (C.c_int, [_P, _I32, _I64, _P]),
     "unetpp_wgrad_max_split": (_I32, [_I32, _I32, _I32]),
     "unetpp_wgrad_slab_planes": (_I32, [C.POINTER(WgradDesc)]),
+    "unetpp_wgrad_pairs_per_workgroup": (_I32, [C.POINTER(WgradDesc)]),
     "unetpp_wgrad": (C.c_int, [C.POINTER(WgradDesc), _P]),
     "unetpp_wgrad_finish": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _I64, _I64, _I64, _I64, _P, _P]),
     "unetpp_pack_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _P]),

@@ -125,6 +125,7 @@ int launch_gemm_bf16(const unetpp_gemm_desc* d, hipStream_t st);
 int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st);
 // wgrad_bf16.hip: bf16-storage weight gradient (UNETPP_GEMM_BF16); UNETPP_EINVAL when the views do not fit
 int launch_wgrad_bf16(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_tiles_cols, int k_tiles, hipStream_t st);
+bool wgrad_bf16_quads(const unetpp_wgrad_desc* d);  // the bf16 kernel will give a workgroup 2 x 2 (channel, column) tile pairs
 // wgrad_fast.hip: 8-wave double-buffered kernel for plain aligned views; returns 1 when it does not apply
 int launch_wgrad_fast(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_tiles_cols, int k_tiles, hipStream_t st);
 // wgrad_dma.hip: LDS-DMA staged kernel for views without load transforms; returns 1 when it does not apply

@@ -219,6 +219,67 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ slabs, int n_split
   dw[t * d_t + k * d_k + (nn % n_inner) * d_n + (nn / n_inner) * d_o] = s;
 }
 
+// Wide plain convolutions (K * Ncols >= 64 K elements, dense torch layout dw[n][k][t]): in the kernel above
+// neighbouring threads hold neighbouring COLUMNS n, whose destinations are 4 * taps * K bytes apart -- every 4-byte
+// store its own cache line (a 256 -> 256 layer: 37 us for 2.4 MB of output).  Here a block owns 8 channels x 32
+// columns x all taps, sums the slabs with 128-byte row reads (SG <= 4 slab groups of 256 threads, combined in fixed
+// order: reproducible) and transposes through LDS, so that every column's 8 * taps values leave as one contiguous run.
+constexpr int kTrK = 8, kTrN = 32;
+__global__ __launch_bounds__(1024) void wgrad_finish_tr_kernel(const float* __restrict__ slabs, int n_split, int taps,
+                                                               int K, int Ncols, float* __restrict__ dw,
+                                                               float* __restrict__ db, int log2_sg) {
+  constexpr int EMAX = 9 * kTrK * kTrN;
+  __shared__ float part[4][EMAX];
+  __shared__ float out_t[kTrN][9 * kTrK + 1];
+  __shared__ float part_db[4][kTrN];
+  const int SG = 1 << log2_sg;
+  const int g = threadIdx.x >> 8, e0 = threadIdx.x & 255;
+  const int n_blocks = Ncols / kTrN;
+  const int n0 = (blockIdx.x % n_blocks) * kTrN, k0 = (blockIdx.x / n_blocks) * kTrK;
+  const long total = (static_cast<long>(taps) * K + 1) * Ncols;
+  const int E = taps * kTrK * kTrN;
+  auto sum_slabs = [&](long addr) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = g;
+    for (; b + 3 * SG < n_split; b += 4 * SG) {
+      s0 += slabs[static_cast<long>(b) * total + addr];
+      s1 += slabs[static_cast<long>(b + SG) * total + addr];
+      s2 += slabs[static_cast<long>(b + 2 * SG) * total + addr];
+      s3 += slabs[static_cast<long>(b + 3 * SG) * total + addr];
+    }
+    for (; b < n_split; b += SG) s0 += slabs[static_cast<long>(b) * total + addr];
+    return (s0 + s1) + (s2 + s3);
+  };
+  for (int idx = e0; idx < E; idx += 256) {
+    const int n = idx & (kTrN - 1), row = idx >> 5;  // row = t * kTrK + kk
+    const int t = row / kTrK, kk = row - t * kTrK;
+    part[g][idx] = sum_slabs((static_cast<long>(t) * K + k0 + kk) * Ncols + n0 + n);
+  }
+  const bool with_db = k0 == 0 && db != nullptr;
+  if (with_db && e0 < kTrN) part_db[g][e0] = sum_slabs(static_cast<long>(taps) * K * Ncols + n0 + e0);
+  __syncthreads();
+  if (g == 0) {
+    for (int idx = e0; idx < E; idx += 256) {
+      float s = 0.f;
+      for (int q = 0; q < SG; ++q) s += part[q][idx];  // fixed order
+      const int n = idx & (kTrN - 1), row = idx >> 5;
+      const int t = row / kTrK, kk = row - t * kTrK;
+      out_t[n][kk * taps + t] = s;
+    }
+    if (with_db && e0 < kTrN) {
+      float s = 0.f;
+      for (int q = 0; q < SG; ++q) s += part_db[q][e0];
+      db[n0 + e0] = s;
+    }
+  }
+  __syncthreads();
+  const int run = kTrK * taps;  // contiguous floats per column
+  for (int idx = threadIdx.x; idx < E; idx += blockDim.x) {
+    const int n = idx / run, r = idx - n * run;
+    dw[(static_cast<long>(n0 + n) * K + k0) * taps + r] = out_t[n][r];
+  }
+}
+
 __global__ void pack_weight_kernel(float* __restrict__ dst, const float* __restrict__ src, int T, int K, int Ncols,
                                    long d_t, long d_k, long d_n, long s_t, long s_k, long s_n, int flip) {
   const long total = static_cast<long>(T) * K * Ncols;
@@ -250,6 +311,11 @@ extern "C" int32_t unetpp_wgrad_slab_planes(const unetpp_wgrad_desc* d) {
   const bool small = d->taps == 9 && d->n_x == 1 && d->x[0].c_len <= 4;
   if (d->flags & UNETPP_GEMM_BF16) return d->taps;  // bf16 storage: direct summation only
   return (!small && wgrad_wino_applies(d)) ? 16 : d->taps;
+}
+
+extern "C" int32_t unetpp_wgrad_pairs_per_workgroup(const unetpp_wgrad_desc* d) {
+  if (d == nullptr) return 0;
+  return wgrad_bf16_quads(d) ? 4 : 1;
 }
 
 extern "C" int unetpp_wgrad(const unetpp_wgrad_desc* d, void* stream) {
@@ -315,6 +381,15 @@ extern "C" int unetpp_wgrad_finish(const float* slabs, int32_t n_split, int32_t 
   }
   const long total = (static_cast<long>(taps) * K + 1) * Ncols;
   if (Ncols / n_inner > 4) return UNETPP_EINVAL;  // at most 4 pixel phases per output channel
+  if (n_inner == Ncols && dw != nullptr && taps <= 9 && d_t == 1 && d_k == taps && d_n == static_cast<int64_t>(K) * taps &&
+      K % kTrK == 0 && Ncols % kTrN == 0 && static_cast<long>(K) * Ncols >= 65536 && n_split <= 32) {
+    int log2_tr = 0;
+    while ((1 << log2_tr) < n_split && log2_tr < 2) ++log2_tr;
+    const unsigned tr_blocks = static_cast<unsigned>((K / kTrK) * (Ncols / kTrN));
+    hipLaunchKernelGGL(wgrad_finish_tr_kernel, dim3(tr_blocks), dim3(256u << log2_tr), 0, static_cast<hipStream_t>(stream),
+                       slabs, n_split, taps, K, Ncols, dw, db, log2_tr);
+    return launch_status();
+  }
   const int log2_sg = finish_log2_groups(n_split);
   const long epb = 1024 >> log2_sg;
   const unsigned blocks = static_cast<unsigned>((total + epb - 1) / epb + (n_inner != Ncols ? (n_inner + 15) / 16 : 0));

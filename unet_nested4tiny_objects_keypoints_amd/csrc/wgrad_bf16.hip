@@ -23,6 +23,7 @@
 // Fixed-order tree sum of the 4 waves; one slab per workgroup in the format of wgrad.hip ([taps*K + 1][Ncols] fp32,
 // last row = db).
 #include <atomic>
+#include <cstdlib>
 
 #include "bf16_common.h"
 #include "common.h"
@@ -368,7 +369,396 @@ int launch_one(const WBfArgs& a, dim3 grid, hipStream_t st) {
   return launch_status();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wide layers -- every x and dy view a multiple of 64 channels.  The kernel above gives a workgroup ONE (32-channel,
+// 32-column) pair and every MFMA its own operand reads: (18 x + 2 dy) fragments per 9 MFMAs, 4.4 ds_read_b64_tr_b16
+// per MFMA -- with four SIMDs issuing, 36 LDS-array cycles per 32-cycle MFMA slot: the LDS array, not the matrix pipe,
+// paces it (0.33 matrix-pipe occupancy in the PMC pass), and its global loads are 64-byte slices of pixel rows (half
+// an L2 line), each x slice fetched again by every column tile and each dy slice by every channel tile.
+// Here a workgroup owns a QUAD, 64 channels x 64 columns = 2 x 2 pairs, and stages 128-byte rows (whole L2 lines, half
+// the bytes per pair).  3x3: THREE waves per pair, wave s owning the filter COLUMN s (taps s, 3+s, 6+s: 48
+// accumulator registers) over all 256 pixels of the tile.  A filter row only shifts the x fragment by one image row,
+// so the wave walks the INPUT rows of the patch: the fragment of input row i feeds output rows i, i-1, i-2 (filter
+// rows 0, 1, 2) against dy fragments it keeps for three rows -- 20 x + 16 dy fragments per 48 MFMAs (1.5 reads per
+// MFMA), no sum across waves at the end, every wave writes its three taps of the slab block.  12 waves, ONE workgroup
+// per CU (two 75 KB LDS buffers).  1x1 (transposed-convolution phases): two waves per pair, half the pixels each,
+// summed through LDS.
+template <int TAPS>
+struct QuadShape {
+  static constexpr int WPP = TAPS == 9 ? 3 : 2;  // waves per pair
+  static constexpr int THREADS = 4 * WPP * 64;
+};
+
+template <int TAPS, int LOG2TW>
+__global__ __launch_bounds__(QuadShape<TAPS>::THREADS, 1) void wgrad_bf16_quad_kernel(const WBfArgs a) {
+  constexpr int WPP = QuadShape<TAPS>::WPP, THREADS = QuadShape<TAPS>::THREADS;
+  constexpr int HALO = (TAPS == 9) ? 1 : 0;
+  constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;
+  constexpr int HWp = TW + 2 * HALO, HHp = TH + 2 * HALO;
+  constexpr int NPIX = HWp * HHp;
+  constexpr int XPIX = (TAPS == 9) ? kMaxHaloPixels : kBlockPixels;
+  constexpr int X_ITEMS = (NPIX * 8 + THREADS - 1) / THREADS;          // 16-byte items (8 channels), 8 per pixel
+  constexpr int DY_ITEMS = (kBlockPixels * 8 + THREADS - 1) / THREADS;
+  constexpr int N_ITEMS = X_ITEMS + DY_ITEMS;                          // 7 (3x3) / 8 (1x1)
+  // a plane = one 32-channel tile of all pixels ([pixel][64 bytes], the layout the transposed reads want); the two
+  // planes of an operand are 128 bytes out of phase so that a pixel's two 64-byte halves fall into different banks
+  constexpr int XP = XPIX * 64 + 128;
+  constexpr int YP = kBlockPixels * 64 + 128;
+  constexpr int BUF = 2 * XP + 2 * YP;
+  static_assert(TAPS == 9 || 4 * TAPS * 4096 + 512 <= 2 * BUF, "the pair sums alias the tile buffers");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 * BUF + 512
+
+  const unetpp_wgrad_desc& d = a.d;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int pair = wave / WPP, sub = wave - pair * WPP;  // sub = filter column (3x3) / pixel half (1x1)
+  const int kl = pair >> 1, nl = pair & 1;               // (channel tile, column tile) of the pair inside the quad
+
+  int nq = blockIdx.y % a.n_tiles_cols;   // n_tiles_cols = column QUADS here
+  int kq = blockIdx.y / a.n_tiles_cols;
+  const bool want_db = kq == 0;
+  int dv = 0, col_base = 0;
+  while (dv < d.n_dy - 1) {
+    const int quads_v = d.dy[dv].c_len >> 6;
+    if (nq < quads_v) break;
+    nq -= quads_v;
+    col_base += d.dy[dv].c_len;
+    ++dv;
+  }
+  const unetpp_view& DY = d.dy[dv];
+  int xv = 0, kbase = 0;
+  while (xv < d.n_x - 1) {
+    const int quads_v = d.x[xv].c_len >> 6;
+    if (kq < quads_v) break;
+    kq -= quads_v;
+    kbase += d.x[xv].c_len;
+    ++xv;
+  }
+  const unetpp_view& X = d.x[xv];
+  const bf16_t* xptr = reinterpret_cast<const bf16_t*>(X.ptr);
+  const bf16_t* dyptr = reinterpret_cast<const bf16_t*>(DY.ptr);
+  const int c0 = kq * 64, nc0 = nq * 64;
+
+  float* coef = reinterpret_cast<float*>(smem + 2 * BUF);  // [scale 64][shift 64] of this workgroup's channels
+  const bool x_affine = X.scale != nullptr;
+  if (x_affine) {
+    if (tid < 64) {
+      coef[tid] = X.scale[c0 + tid];
+      coef[64 + tid] = X.shift[c0 + tid];
+    }
+    __syncthreads();
+  }
+
+  // ---- staging: item = (pixel, channel octet 0..7); a thread keeps its octet (THREADS % 8 == 0), eight neighbouring
+  // threads fetch the 128 contiguous bytes of a pixel ----
+  const int oct = tid & 7;
+  const int ch = oct << 3;                                   // channel inside the 64
+  const unsigned plane = static_cast<unsigned>(oct >> 2);    // 32-channel plane of the octet
+  const unsigned x_plane = plane * XP + (oct & 3) * 16;
+  const unsigned y_plane = 2u * XP + plane * YP + (oct & 3) * 16;
+  unsigned x_rel[X_ITEMS], y_rel[DY_ITEMS];
+  auto item_hy = [&](int q) __attribute__((always_inline)) { return min((tid + q * THREADS) >> 3, NPIX - 1) / HWp; };
+  auto item_hx = [&](int q) __attribute__((always_inline)) { return min((tid + q * THREADS) >> 3, NPIX - 1) - item_hy(q) * HWp; };
+  auto item_p = [&](int q) __attribute__((always_inline)) { return min((tid + q * THREADS) >> 3, kBlockPixels - 1); };
+#pragma unroll
+  for (int q = 0; q < X_ITEMS; ++q)
+    x_rel[q] = (static_cast<unsigned>(item_hy(q)) * X.sy * X.Ws + static_cast<unsigned>(item_hx(q)) * X.sx) * X.C + ch;
+#pragma unroll
+  for (int q = 0; q < DY_ITEMS; ++q) {
+    const int p = item_p(q);
+    y_rel[q] = (static_cast<unsigned>(p >> LOG2TW) * DY.sy * DY.Ws + static_cast<unsigned>(p & (TW - 1)) * DY.sx) * DY.C + ch;
+  }
+  int ty0 = 0, tx0 = 0, img = 0;
+  auto set_tile = [&](long tile) __attribute__((always_inline)) {
+    unsigned b = static_cast<unsigned>(tile);
+    const unsigned txi = b % static_cast<unsigned>(a.tiles_x);
+    b /= static_cast<unsigned>(a.tiles_x);
+    const unsigned tyi = b % static_cast<unsigned>(a.tiles_y);
+    img = static_cast<int>(b / static_cast<unsigned>(a.tiles_y));
+    ty0 = static_cast<int>(tyi) * TH;
+    tx0 = static_cast<int>(txi) * TW;
+  };
+  auto load_tile = [&](u32x4 (&stage)[N_ITEMS]) __attribute__((always_inline)) {
+    if (ty0 >= HALO && tx0 >= HALO && ty0 + TH + HALO <= d.H && tx0 + TW + HALO <= d.W) {  // uniform
+      const bf16_t* xo = xptr + view_pixel_offset(X, img, ty0 - HALO, tx0 - HALO) + c0;
+      const bf16_t* yo = dyptr + view_pixel_offset(DY, img, ty0, tx0) + nc0;
+#pragma unroll
+      for (int q = 0; q < X_ITEMS; ++q) stage[q] = *reinterpret_cast<const u32x4*>(xo + x_rel[q]);
+#pragma unroll
+      for (int q = 0; q < DY_ITEMS; ++q) stage[X_ITEMS + q] = *reinterpret_cast<const u32x4*>(yo + y_rel[q]);
+      return;
+    }
+#pragma unroll
+    for (int q = 0; q < X_ITEMS; ++q) {
+      const int y = min(max(ty0 + item_hy(q) - HALO, 0), d.H - 1), x = min(max(tx0 + item_hx(q) - HALO, 0), d.W - 1);
+      stage[q] = *reinterpret_cast<const u32x4*>(xptr + view_pixel_offset(X, img, y, x) + c0 + ch);
+    }
+#pragma unroll
+    for (int q = 0; q < DY_ITEMS; ++q) {
+      const int p = item_p(q);
+      const int y = min(ty0 + (p >> LOG2TW), d.H - 1), x = min(tx0 + (p & (TW - 1)), d.W - 1);
+      stage[X_ITEMS + q] = *reinterpret_cast<const u32x4*>(dyptr + view_pixel_offset(DY, img, y, x) + nc0 + ch);
+    }
+  };
+  // bias gradient = column sums of dy: taken where every dy value passes through a thread's registers exactly once
+  // (the staging writes), not beside the MFMAs -- there 16 VALU instructions per dy fragment filled the SIMD's vector
+  // issue (4 cycles each against 24 free cycles per MFMA) and the loop ran at half the matrix rate
+  float dbacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto store_tile = [&](const u32x4 (&stage)[N_ITEMS], int s_ty0, int s_tx0, unsigned char* buf) __attribute__((always_inline)) {
+    const bool interior = s_ty0 >= HALO && s_tx0 >= HALO && s_ty0 + TH + HALO <= d.H && s_tx0 + TW + HALO <= d.W;
+#pragma unroll
+    for (int q = 0; q < X_ITEMS; ++q) {
+      const int hp = (tid + q * THREADS) >> 3;
+      u32x4 v = stage[q];
+      if (x_affine || X.relu) {
+        float f[8];
+        unpack8(v, f);
+        if (x_affine) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], coef[ch + e], coef[64 + ch + e]);
+        }
+        if (X.relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+        }
+        v = pack8(f);
+      }
+      if (!interior) {
+        const int y = s_ty0 + item_hy(q) - HALO, x = s_tx0 + item_hx(q) - HALO;
+        const bool keep = y >= 0 && y < d.H && x >= 0 && x < d.W;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0u;
+      }
+      if (hp < NPIX) *reinterpret_cast<u32x4*>(&buf[x_plane + hp * 64]) = v;
+    }
+#pragma unroll
+    for (int q = 0; q < DY_ITEMS; ++q) {
+      const int p = (tid + q * THREADS) >> 3;
+      u32x4 v = stage[X_ITEMS + q];
+      if (!interior) {
+        const bool keep = s_ty0 + (p >> LOG2TW) < d.H && s_tx0 + (p & (TW - 1)) < d.W;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0u;
+      }
+      if (p < kBlockPixels) {
+        *reinterpret_cast<u32x4*>(&buf[y_plane + p * 64]) = v;
+        if (want_db) {   // uniform; the thread's 8 columns of this pixel
+          float f[8];
+          unpack8(v, f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dbacc[e] += f[e];
+        }
+      }
+    }
+  };
+
+  constexpr int NACC = TAPS == 9 ? 3 : 1;   // 3x3: acc[r] = tap (filter row r, filter column sub)
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int t = 0; t < NACC; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // transposed-read geometry as in the kernel above; the lane's pixel for (step ks, block b) is
+  // p = p0 + 16*ks + 8*h + 4*b + q4 with p0 = 0 (3x3: all 16 steps) or 128 * sub (1x1: 8 steps), i.e. step ks sits at
+  // image row DROW(ks), column DCOL(ks) of the patch (TW = 32: ks >> 1, 16*(ks & 1); TW = 16: ks, 0; TW = 8: 2ks, 0 --
+  // there the lane's h is the second row)
+  const int cblock = (lane >> 4) & 1, q4 = (lane >> 2) & 3, pp = lane & 3;
+  const int lane_off = cblock * 32 + pp * 8;
+  const int p_lane = (TAPS == 9 ? 0 : 128 * sub) + 8 * h + q4;
+  const int x_shift = TAPS == 9 ? sub : 0;   // filter column
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>(smem));
+  const unsigned x_base =
+      lds0 + static_cast<unsigned>(kl * XP + ((p_lane >> LOG2TW) * HWp + (p_lane & (TW - 1)) + x_shift) * 64 + lane_off);
+  const unsigned y_base = lds0 + static_cast<unsigned>(2 * XP + nl * YP + p_lane * 64 + lane_off);
+
+  auto compute = [&](unsigned buf_off) __attribute__((always_inline)) {
+    const unsigned xb = x_base + buf_off, yb_addr = y_base + buf_off;
+    if constexpr (TAPS == 9) {
+      constexpr int NCOL = LOG2TW == 5 ? 2 : 1;          // 16-pixel steps per image row
+      constexpr int RSTEP = LOG2TW == 3 ? 2 : 1;         // image rows per step
+      constexpr int ROWS = LOG2TW == 5 ? 8 : (LOG2TW == 4 ? 16 : 32);
+      // fragments of input row `key` (x) / output row `key` (dy) are requested one row ahead of the MFMAs that use
+      // them; the step at output row ro = key - r meets input row `key` under filter row r.  TW = 32: the two 16-pixel
+      // halves of the rows one after the other (half the live fragments: two x and four dy).
+      auto row_used = [](int key) {
+        for (int r = 0; r < 3; ++r) {
+          const int ro = key - r;
+          if (ro >= 0 && ro < ROWS && ro % RSTEP == 0) return true;
+        }
+        return false;
+      };
+      static_for<NCOL>([&](auto cv) {
+        constexpr int c = decltype(cv)::v;
+        s16x8 afr[ROWS + 2], bfr[ROWS];
+        auto request = [&](auto kk) __attribute__((always_inline)) {
+          constexpr int key = decltype(kk)::v;
+          if constexpr (key < ROWS + 2 && row_used(key)) {
+            afr[key] = lds_tr_frag(xb + (key * HWp + 16 * c) * 64);
+            if constexpr (key < ROWS && key % RSTEP == 0)   // a new output row: its dy fragment
+              bfr[key] = lds_tr_frag(yb_addr + 16 * ((key / RSTEP) * NCOL + c) * 64);
+          }
+        };
+        request(IC<0>{});
+        static_for<ROWS + 2>([&](auto kk) {
+          constexpr int key = decltype(kk)::v;
+          request(IC<key + 1>{});
+          static_for<3>([&](auto rv) {
+            constexpr int r = 2 - decltype(rv)::v;          // oldest dy fragment first
+            constexpr int ro = key - r;
+            if constexpr (ro >= 0 && ro < ROWS && ro % RSTEP == 0)
+              acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[key]),
+                                                               __builtin_bit_cast(bf16x8, bfr[ro]), acc[r], 0, 0, 0);
+          });
+#ifndef UNETPP_WQ_EXP_NO_FENCE
+          __builtin_amdgcn_sched_barrier(0);   // keep the reads of later rows out of this row's registers
+#endif
+        });
+      });
+    } else {
+      static_for<8>([&](auto kc) {
+        constexpr int ks = decltype(kc)::v;
+        constexpr int DROW = LOG2TW == 5 ? (ks >> 1) : (LOG2TW == 4 ? ks : 2 * ks);
+        constexpr int DCOL = LOG2TW == 5 ? 16 * (ks & 1) : 0;
+        const s16x8 bfrag = lds_tr_frag(yb_addr + 16 * ks * 64);
+        const s16x8 afrag = lds_tr_frag(xb + (DROW * HWp + DCOL) * 64);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afrag), __builtin_bit_cast(bf16x8, bfrag),
+                                                         acc[0], 0, 0, 0);
+      });
+    }
+  };
+
+  // ---- tile loop: as above (registers hold tile i+1, tile i+2 requested, tile i's MFMAs; one barrier per tile) ----
+  const long stride = gridDim.x;
+  const long t0 = blockIdx.x;
+  const long n_my = (t0 < a.n_pix_tiles) ? (a.n_pix_tiles - t0 + stride - 1) / stride : 0;
+  u32x4 stage[N_ITEMS];
+  int s_ty0 = 0, s_tx0 = 0;
+  if (n_my > 0) {
+    set_tile(t0);
+    load_tile(stage);
+    store_tile(stage, ty0, tx0, smem);
+  }
+  if (n_my > 1) {
+    set_tile(t0 + stride);
+    s_ty0 = ty0;
+    s_tx0 = tx0;
+    load_tile(stage);
+  }
+  __syncthreads();
+  // All waves stage, then all run their MFMAs.  Letting the first wave of every SIMD stage while the other two multiply
+  // (the two halves of an iteration are independent) was measured: 151 us against 136 us for the [64,64,64] -> 64 layer
+  // at 256 x 256 x 8 -- with the matrix pipe busy the chip holds ~1.6 GHz and the phases cost what they cost in
+  // sequence or side by side, and the second copy of the staging code spills.  MFMAs alone are 3.2 us of the 5.2 us
+  // per tile (tools/wgrad_quad_ablation.sh; profiles/r3/ablation_wgrad_bf16_quad.txt).
+  // (UNETPP_WQ_EXP_*: timing experiments of that script -- wrong results, never in the shipped build)
+  for (long i = 0; i < n_my; ++i) {
+    const unsigned cur = static_cast<unsigned>(i & 1) * BUF;
+#ifndef UNETPP_WQ_EXP_NO_STORE
+    if (i + 1 < n_my) store_tile(stage, s_ty0, s_tx0, smem + ((i + 1) & 1) * BUF);
+#endif
+#ifndef UNETPP_WQ_EXP_NO_LOAD
+    if (i + 2 < n_my) {
+      set_tile(t0 + (i + 2) * stride);
+      s_ty0 = ty0;
+      s_tx0 = tx0;
+      load_tile(stage);
+    }
+#endif
+#ifndef UNETPP_WQ_EXP_NO_COMPUTE
+    compute(cur);
+#endif
+#ifndef UNETPP_WQ_EXP_NO_BARRIER
+    __syncthreads();
+#endif
+  }
+#ifdef UNETPP_WQ_EXP_NO_SLAB
+  if (a.n_pix_tiles >= 0) return;
+#endif
+
+  const long slab_stride = (static_cast<long>(TAPS) * a.Ktot + 1) * a.Ncols;
+  float* slab = d.slabs + blockIdx.x * slab_stride;
+  const int k0 = kbase + c0 + 32 * kl, n0 = col_base + nc0 + 32 * nl;
+  if constexpr (TAPS == 9) {
+    // every wave owns its three taps of the pair's block (MFMA D map: reg r of lane (j, h) = row (r&3) + 8*(r>>2) + 4h)
+#pragma unroll
+    for (int fr = 0; fr < 3; ++fr) {
+      const int t = 3 * fr + sub;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        slab[(static_cast<long>(t) * a.Ktot + k0 + row) * a.Ncols + n0 + j] = acc[fr][r];
+      }
+    }
+  } else {
+    // the second wave of every pair hands its sums to the first one through LDS
+    float* region = reinterpret_cast<float*>(smem) + pair * 1024 + lane * 4;
+    if (sub == 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4*>(region + q * 256) = f32x4{acc[0][4 * q], acc[0][4 * q + 1], acc[0][4 * q + 2], acc[0][4 * q + 3]};
+    }
+    __syncthreads();
+    if (sub == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(region + q * 256);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[0][4 * q + i] += v[i];
+      }
+      store_slab_block<1>(acc, slab, a.Ktot, a.Ncols, k0, 32, n0, 32, j, h);
+    }
+  }
+  if (want_db) {   // uniform: per-thread column sums -> [thread][8] in LDS -> 64 columns, fixed order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem) + 4 * 1024;   // past the 1x1 pair sums
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[tid * 8 + e] = dbacc[e];
+    __syncthreads();
+    if (tid < 64) {   // column tid = octet (tid >> 3), element (tid & 7): threads octet + 8m
+      float sum = 0.f;
+      for (int m = 0; m < THREADS / 8; ++m) sum += red[((tid >> 3) + 8 * m) * 8 + (tid & 7)];
+      slab[static_cast<long>(TAPS) * a.Ktot * a.Ncols + col_base + nc0 + tid] = sum;
+    }
+  }
+}
+
+template <int TAPS, int LOG2TW>
+int launch_quad(const WBfArgs& a, dim3 grid, hipStream_t st) {
+  constexpr int XPIX = (TAPS == 9) ? kMaxHaloPixels : kBlockPixels;
+  constexpr int BUF = 2 * (XPIX * 64 + 128) + 2 * (kBlockPixels * 64 + 128);
+  constexpr size_t lds = 2 * BUF + 512;
+  static_assert(lds <= 160 * 1024, "one workgroup per CU");
+  static std::atomic<unsigned long long> opted_in[4] = {};
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess || device < 0 || device > 255) return UNETPP_ELAUNCH;
+  const unsigned long long bit = 1ull << (device & 63);
+  if (!(opted_in[device >> 6].load(std::memory_order_acquire) & bit)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_bf16_quad_kernel<TAPS, LOG2TW>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)) != hipSuccess)
+      return UNETPP_ELAUNCH;
+    opted_in[device >> 6].fetch_or(bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL((wgrad_bf16_quad_kernel<TAPS, LOG2TW>), grid, dim3(QuadShape<TAPS>::THREADS), lds, st, a);
+  note_kernel(TAPS == 9 ? "wgrad_bf16_quad_kernel<9>" : "wgrad_bf16_quad_kernel<1>");
+  return launch_status();
+}
+
 }  // namespace
+
+// the quad kernel takes a layer when every view is a multiple of 64 channels wide (UNETPP_BF16_WGRAD_QUAD=0 keeps the
+// pair kernel, for A/B runs and the tests that compare the two)
+bool wgrad_bf16_quads(const unetpp_wgrad_desc* d) {
+  const char* e = getenv("UNETPP_BF16_WGRAD_QUAD");  // read per call: the tests switch it inside one process
+  if ((e != nullptr && e[0] == '0') || !(d->flags & UNETPP_GEMM_BF16)) return false;
+  if (d->taps == 9 && d->n_x == 1 && d->x[0].c_len <= 4) return false;  // first layer: its own kernel
+  for (int i = 0; i < d->n_x; ++i)
+    if (d->x[i].c_len <= 0 || (d->x[i].c_len & 63) != 0) return false;
+  for (int i = 0; i < d->n_dy; ++i)
+    if (d->dy[i].c_len <= 0 || (d->dy[i].c_len & 63) != 0) return false;
+  return true;
+}
 
 // UNETPP_OK after launching, UNETPP_EINVAL when the views are not 8-channel aligned plain bf16 views (x may carry an
 // affine + ReLU load transform; ReLU gates on load are not supported in bf16)
@@ -390,6 +780,21 @@ int launch_wgrad_bf16(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_til
   if (a.n_pix_tiles > 0x7fffffffL) return UNETPP_EINVAL;
   for (int i = 0; i < d->n_x; ++i)   // 32-bit element offsets inside a tile
     if (static_cast<long>(d->x[i].Hs) * d->x[i].Ws * d->x[i].C >= 0x7fffffffL) return UNETPP_EINVAL;
+  if (wgrad_bf16_quads(d)) {
+    int kq = 0, nq = 0;
+    for (int i = 0; i < d->n_x; ++i) kq += d->x[i].c_len >> 6;
+    for (int i = 0; i < d->n_dy; ++i) nq += d->dy[i].c_len >> 6;
+    a.n_tiles_cols = nq;
+    const dim3 qgrid(static_cast<unsigned>(d->n_split), static_cast<unsigned>(kq * nq));
+    if (d->taps == 9) {
+      if (g.log2tw == 5) return launch_quad<9, 5>(a, qgrid, st);
+      if (g.log2tw == 4) return launch_quad<9, 4>(a, qgrid, st);
+      return launch_quad<9, 3>(a, qgrid, st);
+    }
+    if (g.log2tw == 5) return launch_quad<1, 5>(a, qgrid, st);
+    if (g.log2tw == 4) return launch_quad<1, 4>(a, qgrid, st);
+    return launch_quad<1, 3>(a, qgrid, st);
+  }
   const dim3 grid(static_cast<unsigned>(d->n_split), static_cast<unsigned>(static_cast<long>(k_tiles) * n_tiles_cols));
   if (d->taps == 9) {
     if (g.log2tw == 5) return launch_one<9, 5>(a, grid, st);

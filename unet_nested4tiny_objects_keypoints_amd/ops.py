@@ -450,11 +450,12 @@ def wgrad(n: int, h: int, w: int, taps: int, xs: Sequence[V], dys: Sequence[V], 
     pairs = sum((v.c_len + 31) // 32 for v in d.x[:len(xs)]) * sum((v.c_len + 31) // 32 for v in d.dy[:len(dys)])
     if len(xs) == 1 and xs[0].t.shape[3] <= 4:
         target_blocks = 2048  # the 1..4-channel first layer runs an HBM-bound VALU kernel: many small workgroups
-    if dys[0].t.dtype == torch.bfloat16 and target_blocks == 256:
-        target_blocks = 512  # the bf16 kernel runs two 4-wave workgroups per CU
-    split = max(1, min(int(lib.unetpp_wgrad_max_split(n, h, w)), target_blocks // max(1, pairs)))
-    d.n_split = split
     d.flags = (_lib.GEMM_DIRECT if (direct or not USE_WINOGRAD) else 0) | _storage_flag(dys, xs)
+    wg_pairs = int(lib.unetpp_wgrad_pairs_per_workgroup(C.byref(d)))
+    if dys[0].t.dtype == torch.bfloat16 and target_blocks == 256 and wg_pairs == 1:
+        target_blocks = 512  # the bf16 pair kernel runs two 4-wave workgroups per CU (the quad kernel one of 8 waves)
+    split = max(1, min(int(lib.unetpp_wgrad_max_split(n, h, w)), target_blocks // max(1, pairs // max(1, wg_pairs))))
+    d.n_split = split
     planes = int(lib.unetpp_wgrad_slab_planes(C.byref(d)))  # taps, or 16 for the Winograd kernel
     slabs = torch.empty(split * (planes * k + 1) * nc, dtype=torch.float32, device=xs[0].t.device)
     d.slabs = slabs.data_ptr()
