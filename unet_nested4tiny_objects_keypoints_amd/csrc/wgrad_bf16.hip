@@ -266,30 +266,66 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_bf16_kernel(const WBfArgs 
   const unsigned x_base = lds0 + static_cast<unsigned>(((p_lane >> LOG2TW) * HWp + (p_lane & (TW - 1))) * 64 + lane_off);
   const unsigned y_base = lds0 + static_cast<unsigned>(X_BYTES + p_lane * 64 + lane_off);
 
-  // one MFMA per (step, tap)
+  // One MFMA per (step, tap).  A filter row only moves the x fragment by one image row, so the wave walks the INPUT
+  // rows of its 64 pixels: the fragment of input row i (one per filter column and 16-pixel half) feeds the output rows
+  // i, i-1, i-2 under filter rows 0, 1, 2 against the four dy fragments of the tile, which stay in registers --
+  // 24 x + 4 dy fragment reads per 36 MFMAs where reading per (step, tap) took 72 + 8: 4.4 ds_read_b64_tr_b16 per
+  // MFMA kept the LDS array busy 36 cycles of every 32-cycle MFMA slot of the CU's four SIMDs.
   auto compute = [&](unsigned buf_off) {
     const unsigned xb = x_base + buf_off, yb_addr = y_base + buf_off;
+    s16x8 bfr[kSteps];
     static_for<kSteps>([&](auto kc) {
       constexpr int ks = decltype(kc)::v;
-      constexpr int DROW = LOG2TW == 5 ? (ks >> 1) : (LOG2TW == 4 ? ks : 2 * ks);
-      constexpr int DCOL = LOG2TW == 5 ? 16 * (ks & 1) : 0;
-      constexpr int X0 = (DROW * HWp + DCOL) * 64;
-      constexpr int Y0 = (16 * ks) * 64;
-      const s16x8 bfrag = lds_tr_frag(yb_addr + Y0);
-      const u32x4 bu = __builtin_bit_cast(u32x4, bfrag);
+      bfr[ks] = lds_tr_frag(yb_addr + 16 * ks * 64);
+      const u32x4 bu = __builtin_bit_cast(u32x4, bfr[ks]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) dbsum += bf_lo(bu[e]) + bf_hi(bu[e]);
-      static_for<TAPS>([&](auto tc) {
-        constexpr int t = decltype(tc)::v;
-        constexpr int TOFF = (TAPS == 9) ? ((t / 3) * HWp + (t % 3)) * 64 : 0;
-        const s16x8 afrag = lds_tr_frag(xb + X0 + TOFF);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afrag), __builtin_bit_cast(bf16x8, bfrag),
-                                                         acc[t], 0, 0, 0);
-        // a scheduling fence per filter row: left alone hipcc hoists all 72 reads of a tile to the top of the loop body,
-        // and with 144 accumulators and 40 staging registers live that spills
-        if constexpr (t % 3 == 2) __builtin_amdgcn_sched_barrier(0);
-      });
     });
+    if constexpr (TAPS == 9) {
+      constexpr int NCOL = LOG2TW == 5 ? 2 : 1;          // 16-pixel steps per image row
+      constexpr int RSTEP = LOG2TW == 3 ? 2 : 1;         // image rows per step
+      constexpr int ROWS = LOG2TW == 5 ? 2 : (LOG2TW == 4 ? 4 : 8);   // image rows of the wave's 64 pixels
+      static_for<ROWS + 2>([&](auto kk) {
+        constexpr int key = decltype(kk)::v;             // input row (halo included)
+        constexpr bool used = [] {
+          for (int r = 0; r < 3; ++r) {
+            const int ro = key - r;
+            if (ro >= 0 && ro < ROWS && ro % RSTEP == 0) return true;
+          }
+          return false;
+        }();
+        if constexpr (used) {
+          static_for<NCOL>([&](auto cv) {
+            constexpr int c = decltype(cv)::v;
+            static_for<3>([&](auto sv) {
+              constexpr int sh = decltype(sv)::v;        // filter column
+              const s16x8 afrag = lds_tr_frag(xb + (key * HWp + 16 * c + sh) * 64);
+              static_for<3>([&](auto rv) {
+                constexpr int r = 2 - decltype(rv)::v;   // filter row
+                constexpr int ro = key - r;
+                if constexpr (ro >= 0 && ro < ROWS && ro % RSTEP == 0) {
+                  constexpr int ks = (ro / RSTEP) * NCOL + c;
+                  acc[3 * r + sh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                      __builtin_bit_cast(bf16x8, afrag), __builtin_bit_cast(bf16x8, bfr[ks]), acc[3 * r + sh], 0, 0, 0);
+                }
+              });
+            });
+            // a scheduling fence per input row half: left alone hipcc hoists all reads of a tile to the top of the
+            // loop body, and with 144 accumulators and 40 staging registers live that spills
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
+      });
+    } else {
+      static_for<kSteps>([&](auto kc) {
+        constexpr int ks = decltype(kc)::v;
+        constexpr int DROW = LOG2TW == 5 ? (ks >> 1) : (LOG2TW == 4 ? ks : 2 * ks);
+        constexpr int DCOL = LOG2TW == 5 ? 16 * (ks & 1) : 0;
+        const s16x8 afrag = lds_tr_frag(xb + (DROW * HWp + DCOL) * 64);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afrag), __builtin_bit_cast(bf16x8, bfr[ks]),
+                                                         acc[0], 0, 0, 0);
+      });
+    }
   };
 
   // ---- tile loop: prefetch distance two (one register stage, two LDS buffers), one barrier per tile ----
