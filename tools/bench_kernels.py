@@ -42,14 +42,21 @@ def rnd(*shape, act=True):
 
 # (name, level spatial, [cin per view], cout)
 CONVS = []
-f = [32, 64, 128, 256]
-for i in range(4):
+BASE = int(os.environ.get("BASE", "32"))
+if os.environ.get("FULL", "0") == "1":   # every 3x3 layer of a depth-DEPTH network (bottom level and its decoders included)
+    L = int(os.environ.get("DEPTH", "4"))
+    f = [BASE << i for i in range(L + 1)]
+    n_lev, n_dec = L + 1, L
+else:                                     # the four upper levels of the depth-4 network (tables of rounds 1-3)
+    f = [BASE << i for i in range(4)]
+    n_lev, n_dec = 4, 3
+for i in range(n_lev):
     hw = SIZE >> i
     CONVS.append(("enc%d.conv2" % i, hw, [f[i]], f[i]))
     if i > 0:
         CONVS.append(("enc%d.conv1" % i, hw, [f[i - 1]], f[i]))
-for j in range(1, 4):
-    for i in range(4 - j):
+for j in range(1, n_dec + 1):
+    for i in range(n_lev - j):
         hw = SIZE >> i
         CONVS.append(("X%d%d.conv1" % (i, j), hw, [f[i]] * (j + 1), f[i]))
         CONVS.append(("X%d%d.conv2" % (i, j), hw, [f[i]], f[i]))
@@ -91,7 +98,7 @@ for k in ("fwd", "dgrad", "wgrad"):
 # ---- 2x2 stride-2 transposed convolutions (pointwise GEMM + pixel phases) ----
 print("%-14s %5s %5s %5s | %9s %7s %7s | %9s %7s | %9s %7s" % ("deconv", "hw_lo", "cin", "cout", "fwd ms", "TF/s", "GB/s",
                                                                "dgrad ms", "TF/s", "wgrad ms", "TF/s"))
-for i in range(3):
+for i in range(len(f) - 1):
     if only and "deconv" not in only:
         break
     hw = (SIZE // 2) >> i
