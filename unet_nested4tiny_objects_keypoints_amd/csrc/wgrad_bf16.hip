@@ -42,8 +42,11 @@ struct WBfArgs {
   int tiles_x, tiles_y;
   int Ktot, Ncols, n_tiles_cols;
   long n_pix_tiles;
+  unsigned x_bytes[UNETPP_MAX_VIEWS], dy_bytes[UNETPP_MAX_VIEWS];  // tensor sizes (quad kernel: buffer resources), < 2^31
 };
+constexpr unsigned kOutOfRange = 0x80000000u;  // buffer offset no view reaches
 
+typedef unsigned u32x4v __attribute__((vector_size(16)));  // the buffer-load builtin's own return type
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) s16x4* lds_tr_ptr;
@@ -406,6 +409,12 @@ int launch_one(const WBfArgs& a, dim3 grid, hipStream_t st) {
 }
 
 
+#ifdef UNETPP_WQ_EXP_CLOCK
+// diagnostic build (tools/wgrad_quad_ablation.sh CLOCK): shader clocks and 100 MHz reference ticks spent in the tile
+// loops, summed over workgroups -- in-kernel clock = cycles / ticks * 100 MHz (MI355X_MICROARCH.md, DVFS item 6)
+__device__ unsigned long long g_wq_clock[2];
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Wide layers -- every x and dy view a multiple of 64 channels.  The kernel above gives a workgroup ONE (32-channel,
 // 32-column) pair and every MFMA its own operand reads: (18 x + 2 dy) fragments per 9 MFMAs, 4.4 ds_read_b64_tr_b16
@@ -493,18 +502,38 @@ __global__ __launch_bounds__(QuadShape<TAPS>::THREADS, 1) void wgrad_bf16_quad_k
   const unsigned plane = static_cast<unsigned>(oct >> 2);    // 32-channel plane of the octet
   const unsigned x_plane = plane * XP + (oct & 3) * 16;
   const unsigned y_plane = 2u * XP + plane * YP + (oct & 3) * 16;
+  // Both operands come through buffer resources: an item's byte offset is the tile origin (scalar; "negative" for
+  // the halo of a border tile, in wrapping 32-bit arithmetic) + a per-thread constant, and an item outside the image
+  // gets an offset past the end of the tensor -- the hardware returns zeros without touching memory.  One path for
+  // interior and border tiles (the clamped-address border path cost ~100 vector instructions per item, and 30 % of the
+  // tiles of a 256 x 256 image are border tiles).
   unsigned x_rel[X_ITEMS], y_rel[DY_ITEMS];
-  auto item_hy = [&](int q) __attribute__((always_inline)) { return min((tid + q * THREADS) >> 3, NPIX - 1) / HWp; };
-  auto item_hx = [&](int q) __attribute__((always_inline)) { return min((tid + q * THREADS) >> 3, NPIX - 1) - item_hy(q) * HWp; };
-  auto item_p = [&](int q) __attribute__((always_inline)) { return min((tid + q * THREADS) >> 3, kBlockPixels - 1); };
+  int x_pos[X_ITEMS];   // (halo row << 16) | halo column of the item; rows past the patch never pass the range test
 #pragma unroll
-  for (int q = 0; q < X_ITEMS; ++q)
-    x_rel[q] = (static_cast<unsigned>(item_hy(q)) * X.sy * X.Ws + static_cast<unsigned>(item_hx(q)) * X.sx) * X.C + ch;
+  for (int q = 0; q < X_ITEMS; ++q) {
+    const int hp = (tid + q * THREADS) >> 3;
+    const int hy = hp / HWp, hx = hp - hy * HWp;
+    x_pos[q] = hp < NPIX ? ((hy << 16) | hx) : (0x4000 << 16);
+    x_rel[q] = ((static_cast<unsigned>(hy) * X.sy * X.Ws + static_cast<unsigned>(hx) * X.sx) * X.C + ch) * 2u;
+  }
 #pragma unroll
   for (int q = 0; q < DY_ITEMS; ++q) {
-    const int p = item_p(q);
-    y_rel[q] = (static_cast<unsigned>(p >> LOG2TW) * DY.sy * DY.Ws + static_cast<unsigned>(p & (TW - 1)) * DY.sx) * DY.C + ch;
+    const int p = (tid + q * THREADS) >> 3;
+    y_rel[q] = ((static_cast<unsigned>(p >> LOG2TW) * DY.sy * DY.Ws + static_cast<unsigned>(p & (TW - 1)) * DY.sx) * DY.C + ch) * 2u;
   }
+  const __amdgpu_buffer_rsrc_t x_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X.ptr), 0, static_cast<int>(a.x_bytes[xv]), 0x00020000);
+  const __amdgpu_buffer_rsrc_t y_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DY.ptr), 0, static_cast<int>(a.dy_bytes[dv]), 0x00020000);
+  // range tests of an item of the tile at (y0, x0)
+  auto x_inside = [&](int q, int y0, int x0) __attribute__((always_inline)) {
+    const int y = y0 - HALO + (x_pos[q] >> 16), x = x0 - HALO + (x_pos[q] & 0xffff);
+    return (static_cast<unsigned>(y) < static_cast<unsigned>(d.H)) & (static_cast<unsigned>(x) < static_cast<unsigned>(d.W));
+  };
+  auto y_inside = [&](int q, int y0, int x0) __attribute__((always_inline)) {
+    const int p = (tid + q * THREADS) >> 3;
+    return (p < kBlockPixels) & (y0 + (p >> LOG2TW) < d.H) & (x0 + (p & (TW - 1)) < d.W);
+  };
   int ty0 = 0, tx0 = 0, img = 0;
   auto set_tile = [&](long tile) __attribute__((always_inline)) {
     unsigned b = static_cast<unsigned>(tile);
@@ -515,38 +544,34 @@ __global__ __launch_bounds__(QuadShape<TAPS>::THREADS, 1) void wgrad_bf16_quad_k
     ty0 = static_cast<int>(tyi) * TH;
     tx0 = static_cast<int>(txi) * TW;
   };
-  auto load_tile = [&](u32x4 (&stage)[N_ITEMS]) __attribute__((always_inline)) {
-    if (ty0 >= HALO && tx0 >= HALO && ty0 + TH + HALO <= d.H && tx0 + TW + HALO <= d.W) {  // uniform
-      const bf16_t* xo = xptr + view_pixel_offset(X, img, ty0 - HALO, tx0 - HALO) + c0;
-      const bf16_t* yo = dyptr + view_pixel_offset(DY, img, ty0, tx0) + nc0;
-#pragma unroll
-      for (int q = 0; q < X_ITEMS; ++q) stage[q] = *reinterpret_cast<const u32x4*>(xo + x_rel[q]);
-#pragma unroll
-      for (int q = 0; q < DY_ITEMS; ++q) stage[X_ITEMS + q] = *reinterpret_cast<const u32x4*>(yo + y_rel[q]);
-      return;
-    }
-#pragma unroll
-    for (int q = 0; q < X_ITEMS; ++q) {
-      const int y = min(max(ty0 + item_hy(q) - HALO, 0), d.H - 1), x = min(max(tx0 + item_hx(q) - HALO, 0), d.W - 1);
-      stage[q] = *reinterpret_cast<const u32x4*>(xptr + view_pixel_offset(X, img, y, x) + c0 + ch);
-    }
-#pragma unroll
-    for (int q = 0; q < DY_ITEMS; ++q) {
-      const int p = item_p(q);
-      const int y = min(ty0 + (p >> LOG2TW), d.H - 1), x = min(tx0 + (p & (TW - 1)), d.W - 1);
-      stage[X_ITEMS + q] = *reinterpret_cast<const u32x4*>(dyptr + view_pixel_offset(DY, img, y, x) + nc0 + ch);
+  // one staged item (q < X_ITEMS: an x pixel octet, else a dy pixel octet) at a time, so that the tile loop can place
+  // the items between its MFMAs
+  u32x4 stage[N_ITEMS];
+  auto load_item = [&](auto qc) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::v;
+    if constexpr (q < X_ITEMS) {
+      const unsigned org = static_cast<unsigned>(((img * X.Hs + (ty0 - HALO) * X.sy + X.oy) * X.Ws + (tx0 - HALO) * X.sx + X.ox) * X.C +
+                                                 X.c_off + c0) * 2u;
+      const unsigned off = x_inside(q, ty0, tx0) ? org + x_rel[q] : kOutOfRange;
+      stage[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, static_cast<int>(off), 0, 0));
+    } else {
+      constexpr int qy = q - X_ITEMS;
+      const unsigned org = static_cast<unsigned>(((img * DY.Hs + ty0 * DY.sy + DY.oy) * DY.Ws + tx0 * DY.sx + DY.ox) * DY.C +
+                                                 DY.c_off + nc0) * 2u;
+      const unsigned off = y_inside(qy, ty0, tx0) ? org + y_rel[qy] : kOutOfRange;
+      stage[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, static_cast<int>(off), 0, 0));
     }
   };
   // bias gradient = column sums of dy: taken where every dy value passes through a thread's registers exactly once
   // (the staging writes), not beside the MFMAs -- there 16 VALU instructions per dy fragment filled the SIMD's vector
   // issue (4 cycles each against 24 free cycles per MFMA) and the loop ran at half the matrix rate
   float dbacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  auto store_tile = [&](const u32x4 (&stage)[N_ITEMS], int s_ty0, int s_tx0, unsigned char* buf) __attribute__((always_inline)) {
-    const bool interior = s_ty0 >= HALO && s_tx0 >= HALO && s_ty0 + TH + HALO <= d.H && s_tx0 + TW + HALO <= d.W;
-#pragma unroll
-    for (int q = 0; q < X_ITEMS; ++q) {
+  // writes item q of the tile held in `stage` (geometry s_y0 / s_x0) into an LDS buffer
+  auto store_item = [&](auto qc, int s_y0, int s_x0, unsigned char* buf) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::v;
+    u32x4 v = stage[q];
+    if constexpr (q < X_ITEMS) {
       const int hp = (tid + q * THREADS) >> 3;
-      u32x4 v = stage[q];
       if (x_affine || X.relu) {
         float f[8];
         unpack8(v, f);
@@ -559,24 +584,16 @@ __global__ __launch_bounds__(QuadShape<TAPS>::THREADS, 1) void wgrad_bf16_quad_k
           for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
         }
         v = pack8(f);
-      }
-      if (!interior) {
-        const int y = s_ty0 + item_hy(q) - HALO, x = s_tx0 + item_hx(q) - HALO;
-        const bool keep = y >= 0 && y < d.H && x >= 0 && x < d.W;
+        if (x_affine) {   // the padding is zero AFTER the transform
+          const bool keep = x_inside(q, s_y0, s_x0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0u;
+          for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0u;
+        }
       }
       if (hp < NPIX) *reinterpret_cast<u32x4*>(&buf[x_plane + hp * 64]) = v;
-    }
-#pragma unroll
-    for (int q = 0; q < DY_ITEMS; ++q) {
-      const int p = (tid + q * THREADS) >> 3;
-      u32x4 v = stage[X_ITEMS + q];
-      if (!interior) {
-        const bool keep = s_ty0 + (p >> LOG2TW) < d.H && s_tx0 + (p & (TW - 1)) < d.W;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0u;
-      }
+    } else {
+      constexpr int qy = q - X_ITEMS;
+      const int p = (tid + qy * THREADS) >> 3;
       if (p < kBlockPixels) {
         *reinterpret_cast<u32x4*>(&buf[y_plane + p * 64]) = v;
         if (want_db) {   // uniform; the thread's 8 columns of this pixel
@@ -609,7 +626,7 @@ __global__ __launch_bounds__(QuadShape<TAPS>::THREADS, 1) void wgrad_bf16_quad_k
       lds0 + static_cast<unsigned>(kl * XP + ((p_lane >> LOG2TW) * HWp + (p_lane & (TW - 1)) + x_shift) * 64 + lane_off);
   const unsigned y_base = lds0 + static_cast<unsigned>(2 * XP + nl * YP + p_lane * 64 + lane_off);
 
-  auto compute = [&](unsigned buf_off) __attribute__((always_inline)) {
+  auto compute = [&](unsigned buf_off, auto&& hook) __attribute__((always_inline)) {
     const unsigned xb = x_base + buf_off, yb_addr = y_base + buf_off;
     if constexpr (TAPS == 9) {
       constexpr int NCOL = LOG2TW == 5 ? 2 : 1;          // 16-pixel steps per image row
@@ -647,6 +664,7 @@ __global__ __launch_bounds__(QuadShape<TAPS>::THREADS, 1) void wgrad_bf16_quad_k
               acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[key]),
                                                                __builtin_bit_cast(bf16x8, bfr[ro]), acc[r], 0, 0, 0);
           });
+          hook(IC<c * (ROWS + 2) + key>{});   // one piece of the staging beside this row's MFMAs
 #ifndef UNETPP_WQ_EXP_NO_FENCE
           __builtin_amdgcn_sched_barrier(0);   // keep the reads of later rows out of this row's registers
 #endif
@@ -661,54 +679,80 @@ __global__ __launch_bounds__(QuadShape<TAPS>::THREADS, 1) void wgrad_bf16_quad_k
         const s16x8 afrag = lds_tr_frag(xb + (DROW * HWp + DCOL) * 64);
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afrag), __builtin_bit_cast(bf16x8, bfrag),
                                                          acc[0], 0, 0, 0);
+        hook(IC<2 * ks>{});
+        hook(IC<2 * ks + 1>{});
       });
     }
   };
 
-  // ---- tile loop: as above (registers hold tile i+1, tile i+2 requested, tile i's MFMAs; one barrier per tile) ----
+  // ---- tile loop: the registers hold tile i+1 (requested an iteration ago): all waves write it into the other LDS
+  // buffer and request tile i+2, then all run tile i's MFMAs; one barrier per tile.  In cycles a tile is 4.6 k of MFMAs
+  // per SIMD + 1.6 k of gaps around them + 2.5 k of staging in front.  Two ways of hiding the staging were built and
+  // measured on [64,64,64] -> 64 at 256 x 256 x 8 (wgrad + finish, us): this order 136-148; the first wave of every
+  // SIMD staging while the other two multiply 151; one staged item beside each MFMA row (compute(cur, hook) below)
+  // 169 -- more cycles per tile (the waits of the staging stream sit in front of MFMAs of the same wave), although the
+  // chip then holds 2.32 GHz instead of 1.93 (random operands; 2.38 on zeros: tools/wgrad_quad_clock.py) ----
   const long stride = gridDim.x;
   const long t0 = blockIdx.x;
   const long n_my = (t0 < a.n_pix_tiles) ? (a.n_pix_tiles - t0 + stride - 1) / stride : 0;
-  u32x4 stage[N_ITEMS];
   int s_ty0 = 0, s_tx0 = 0;
   if (n_my > 0) {
     set_tile(t0);
-    load_tile(stage);
-    store_tile(stage, ty0, tx0, smem);
+    static_for<N_ITEMS>([&](auto qc) { load_item(qc); });
+    static_for<N_ITEMS>([&](auto qc) { store_item(qc, ty0, tx0, smem); });
   }
   if (n_my > 1) {
     set_tile(t0 + stride);
     s_ty0 = ty0;
     s_tx0 = tx0;
-    load_tile(stage);
+    static_for<N_ITEMS>([&](auto qc) { load_item(qc); });
   }
   __syncthreads();
-  // All waves stage, then all run their MFMAs.  Letting the first wave of every SIMD stage while the other two multiply
-  // (the two halves of an iteration are independent) was measured: 151 us against 136 us for the [64,64,64] -> 64 layer
-  // at 256 x 256 x 8 -- with the matrix pipe busy the chip holds ~1.6 GHz and the phases cost what they cost in
-  // sequence or side by side, and the second copy of the staging code spills.  MFMAs alone are 3.2 us of the 5.2 us
-  // per tile (tools/wgrad_quad_ablation.sh; profiles/r3/ablation_wgrad_bf16_quad.txt).
-  // (UNETPP_WQ_EXP_*: timing experiments of that script -- wrong results, never in the shipped build)
+#ifdef UNETPP_WQ_EXP_CLOCK
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), ref0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // (UNETPP_WQ_EXP_*: timing experiments of tools/wgrad_quad_ablation.sh -- wrong results, never in the shipped build)
   for (long i = 0; i < n_my; ++i) {
     const unsigned cur = static_cast<unsigned>(i & 1) * BUF;
+    unsigned char* nbuf = smem + ((i + 1) & 1) * BUF;
+    const bool do_store = i + 1 < n_my, do_load = i + 2 < n_my;
+    auto hook = [&](auto sc) __attribute__((always_inline)) {
+      constexpr int slot = decltype(sc)::v;
+      if constexpr (slot < N_ITEMS) {
 #ifndef UNETPP_WQ_EXP_NO_STORE
-    if (i + 1 < n_my) store_tile(stage, s_ty0, s_tx0, smem + ((i + 1) & 1) * BUF);
+        if (do_store) store_item(IC<slot>{}, s_ty0, s_tx0, nbuf);
 #endif
+      } else if constexpr (slot < 2 * N_ITEMS) {
 #ifndef UNETPP_WQ_EXP_NO_LOAD
-    if (i + 2 < n_my) {
-      set_tile(t0 + (i + 2) * stride);
-      s_ty0 = ty0;
-      s_tx0 = tx0;
-      load_tile(stage);
-    }
+        if (do_load) {
+          if constexpr (slot == N_ITEMS) {
+            set_tile(t0 + (i + 2) * stride);
+            s_ty0 = ty0;
+            s_tx0 = tx0;
+          }
+          load_item(IC<slot - N_ITEMS>{});
+        }
 #endif
-#ifndef UNETPP_WQ_EXP_NO_COMPUTE
-    compute(cur);
+      }
+    };
+#ifdef UNETPP_WQ_EXP_INTERLEAVE
+    compute(cur, hook);
+#elif defined(UNETPP_WQ_EXP_NO_COMPUTE)
+    static_for<2 * N_ITEMS>(hook);
+#else
+    static_for<2 * N_ITEMS>(hook);
+    compute(cur, [](auto) {});
 #endif
 #ifndef UNETPP_WQ_EXP_NO_BARRIER
     __syncthreads();
 #endif
   }
+#ifdef UNETPP_WQ_EXP_CLOCK
+  if (tid == 0) {
+    atomicAdd(&g_wq_clock[0], __builtin_amdgcn_s_memtime() - clk0);
+    atomicAdd(&g_wq_clock[1], __builtin_amdgcn_s_memrealtime() - ref0);
+  }
+#endif
 #ifdef UNETPP_WQ_EXP_NO_SLAB
   if (a.n_pix_tiles >= 0) return;
 #endif
@@ -789,10 +833,13 @@ bool wgrad_bf16_quads(const unetpp_wgrad_desc* d) {
   const char* e = getenv("UNETPP_BF16_WGRAD_QUAD");  // read per call: the tests switch it inside one process
   if ((e != nullptr && e[0] == '0') || !(d->flags & UNETPP_GEMM_BF16)) return false;
   if (d->taps == 9 && d->n_x == 1 && d->x[0].c_len <= 4) return false;  // first layer: its own kernel
+  auto fits = [&](const unetpp_view& v) {   // buffer-resource addressing: whole tensor below 2 GB
+    return v.c_len > 0 && (v.c_len & 63) == 0 && static_cast<long>(d->N) * v.Hs * v.Ws * v.C * 2 <= 0x7fffffffL;
+  };
   for (int i = 0; i < d->n_x; ++i)
-    if (d->x[i].c_len <= 0 || (d->x[i].c_len & 63) != 0) return false;
+    if (!fits(d->x[i])) return false;
   for (int i = 0; i < d->n_dy; ++i)
-    if (d->dy[i].c_len <= 0 || (d->dy[i].c_len & 63) != 0) return false;
+    if (!fits(d->dy[i])) return false;
   return true;
 }
 
@@ -821,6 +868,8 @@ int launch_wgrad_bf16(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_til
     for (int i = 0; i < d->n_x; ++i) kq += d->x[i].c_len >> 6;
     for (int i = 0; i < d->n_dy; ++i) nq += d->dy[i].c_len >> 6;
     a.n_tiles_cols = nq;
+    for (int i = 0; i < d->n_x; ++i) a.x_bytes[i] = static_cast<unsigned>(static_cast<long>(d->N) * d->x[i].Hs * d->x[i].Ws * d->x[i].C * 2);
+    for (int i = 0; i < d->n_dy; ++i) a.dy_bytes[i] = static_cast<unsigned>(static_cast<long>(d->N) * d->dy[i].Hs * d->dy[i].Ws * d->dy[i].C * 2);
     const dim3 qgrid(static_cast<unsigned>(d->n_split), static_cast<unsigned>(kq * nq));
     if (d->taps == 9) {
       if (g.log2tw == 5) return launch_quad<9, 5>(a, qgrid, st);
@@ -843,3 +892,14 @@ int launch_wgrad_bf16(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_til
 }
 
 }  // namespace unetpp
+
+#ifdef UNETPP_WQ_EXP_CLOCK
+extern "C" int unetpp_wq_clock_read(unsigned long long* out2, int reset) {
+  if (hipMemcpyFromSymbol(out2, HIP_SYMBOL(unetpp::g_wq_clock), 16) != hipSuccess) return 1;
+  if (reset) {
+    const unsigned long long z[2] = {0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(unetpp::g_wq_clock), z, 16) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
