@@ -42,9 +42,13 @@ struct WBfArgs {
   int tiles_x, tiles_y;
   int Ktot, Ncols, n_tiles_cols;
   long n_pix_tiles;
-  unsigned x_bytes[UNETPP_MAX_VIEWS], dy_bytes[UNETPP_MAX_VIEWS];  // tensor sizes (quad kernel: buffer resources), < 2^31
 };
-constexpr unsigned kOutOfRange = 0x80000000u;  // buffer offset no view reaches
+constexpr unsigned kOutOfRange = 0x80000000u;  // buffer offset no image reaches (images are below 2 GB: launcher)
+// buffer resource over ONE image of a bf16 NHWC tensor
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t image_rsrc(const bf16_t* base, int img, int img_elems) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base + static_cast<long>(img) * img_elems), 0, img_elems * 2,
+                                           0x00020000);
+}
 
 typedef unsigned u32x4v __attribute__((vector_size(16)));  // the buffer-load builtin's own return type
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -158,24 +162,37 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_bf16_kernel(const WBfArgs 
     __syncthreads();
   }
 
-  // ---- staging.  Per-thread constants: halo / tile coordinates of every item; interior tiles (all but the image
-  // border) take their addresses as tile origin (uniform) + constant offset, without clamping. ----
-  unsigned x_rel[X_ITEMS], y_rel[DY_ITEMS];
-  auto item_hy = [&](int q) { return min((tid + q * kWThreads) >> 2, NPIX - 1) / HWp; };            // recomputed on the
-  auto item_hx = [&](int q) { return min((tid + q * kWThreads) >> 2, NPIX - 1) - item_hy(q) * HWp; };  // border tiles only
+  // ---- staging.  Both operands come through buffer resources (one per image, rebuilt in scalar registers per tile):
+  // an item's byte offset is the tile origin (scalar; "negative" for the halo of a border tile, in wrapping 32-bit
+  // arithmetic) + a per-thread constant, and an item outside the image -- or a channel octet past a narrow view -- gets
+  // an offset past the end of the image: the hardware returns zeros without touching memory.  One path for interior and
+  // border tiles (the clamped-address border path cost ~100 vector instructions per item). ----
   const int cc = (tid & 3) << 3;  // channel octet of every item of this thread (kWThreads % 4 == 0)
+  unsigned x_rel[X_ITEMS], y_rel[DY_ITEMS];
+  int x_pos[X_ITEMS];   // (halo row << 16) | halo column of the item; rows past the patch never pass the range test
 #pragma unroll
   for (int q = 0; q < X_ITEMS; ++q) {
-    x_rel[q] = (static_cast<unsigned>(item_hy(q)) * X.sy * X.Ws + static_cast<unsigned>(item_hx(q)) * X.sx) * X.C + (cc < k_cnt ? cc : 0);
+    const int hp = (tid + q * kWThreads) >> 2;
+    const int hy = hp / HWp, hx = hp - hy * HWp;
+    x_pos[q] = (hp < NPIX && cc < k_cnt) ? ((hy << 16) | hx) : (0x4000 << 16);
+    x_rel[q] = ((static_cast<unsigned>(hy) * X.sy * X.Ws + static_cast<unsigned>(hx) * X.sx) * X.C + cc) * 2u;
   }
 #pragma unroll
   for (int q = 0; q < DY_ITEMS; ++q) {
     const int p = (tid + q * kWThreads) >> 2;
-    y_rel[q] = (static_cast<unsigned>(p >> LOG2TW) * DY.sy * DY.Ws + static_cast<unsigned>(p & (TW - 1)) * DY.sx) * DY.C +
-               (cc < n_cnt ? cc : 0);
+    y_rel[q] = ((static_cast<unsigned>(p >> LOG2TW) * DY.sy * DY.Ws + static_cast<unsigned>(p & (TW - 1)) * DY.sx) * DY.C + cc) * 2u;
   }
+  const int x_img_elems = X.Hs * X.Ws * X.C, y_img_elems = DY.Hs * DY.Ws * DY.C;
+  auto x_inside = [&](int q, int y0, int x0) __attribute__((always_inline)) {
+    const int y = y0 - HALO + (x_pos[q] >> 16), x = x0 - HALO + (x_pos[q] & 0xffff);
+    return (static_cast<unsigned>(y) < static_cast<unsigned>(d.H)) & (static_cast<unsigned>(x) < static_cast<unsigned>(d.W));
+  };
+  auto y_inside = [&](int q, int y0, int x0) __attribute__((always_inline)) {
+    const int p = (tid + q * kWThreads) >> 2;
+    return (cc < n_cnt) & (y0 + (p >> LOG2TW) < d.H) & (x0 + (p & (TW - 1)) < d.W);
+  };
   int ty0 = 0, tx0 = 0, img = 0;  // tile being addressed
-  auto set_tile = [&](long tile) {  // tile < 2^31 (launcher): 32-bit divisions
+  auto set_tile = [&](long tile) __attribute__((always_inline)) {  // tile < 2^31 (launcher): 32-bit divisions
     unsigned b = static_cast<unsigned>(tile);
     const unsigned txi = b % static_cast<unsigned>(a.tiles_x);
     b /= static_cast<unsigned>(a.tiles_x);
@@ -184,32 +201,24 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_bf16_kernel(const WBfArgs 
     ty0 = static_cast<int>(tyi) * TH;
     tx0 = static_cast<int>(txi) * TW;
   };
-  auto is_interior = [&]() { return ty0 >= HALO && tx0 >= HALO && ty0 + TH + HALO <= d.H && tx0 + TW + HALO <= d.W; };
-  auto load_tile = [&](u32x4 (&stage)[N_ITEMS]) {  // branch-free loads from valid addresses; zeroing at the LDS write
-    if (is_interior()) {  // uniform
-      const bf16_t* xo = xptr + view_pixel_offset(X, img, ty0 - HALO, tx0 - HALO) + c0;
-      const bf16_t* yo = dyptr + view_pixel_offset(DY, img, ty0, tx0) + nc0;
-#pragma unroll
-      for (int q = 0; q < X_ITEMS; ++q) stage[q] = *reinterpret_cast<const u32x4*>(xo + x_rel[q]);
-#pragma unroll
-      for (int q = 0; q < DY_ITEMS; ++q) stage[X_ITEMS + q] = *reinterpret_cast<const u32x4*>(yo + y_rel[q]);
-      return;
-    }
+  auto load_tile = [&](u32x4 (&stage)[N_ITEMS]) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t xr = image_rsrc(xptr, img, x_img_elems), yr = image_rsrc(dyptr, img, y_img_elems);
+    const unsigned xorg =
+        static_cast<unsigned>((((ty0 - HALO) * X.sy + X.oy) * X.Ws + (tx0 - HALO) * X.sx + X.ox) * X.C + X.c_off + c0) * 2u;
+    const unsigned yorg = static_cast<unsigned>(((ty0 * DY.sy + DY.oy) * DY.Ws + tx0 * DY.sx + DY.ox) * DY.C + DY.c_off + nc0) * 2u;
 #pragma unroll
     for (int q = 0; q < X_ITEMS; ++q) {
-      const int y = min(max(ty0 + item_hy(q) - HALO, 0), d.H - 1), x = min(max(tx0 + item_hx(q) - HALO, 0), d.W - 1);
-      stage[q] = *reinterpret_cast<const u32x4*>(xptr + view_pixel_offset(X, img, y, x) + c0 + (cc < k_cnt ? cc : 0));
+      const unsigned off = x_inside(q, ty0, tx0) ? xorg + x_rel[q] : kOutOfRange;
+      stage[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, static_cast<int>(off), 0, 0));
     }
 #pragma unroll
     for (int q = 0; q < DY_ITEMS; ++q) {
-      const int p = (tid + q * kWThreads) >> 2;
-      const int y = min(ty0 + (p >> LOG2TW), d.H - 1), x = min(tx0 + (p & (TW - 1)), d.W - 1);
-      stage[X_ITEMS + q] = *reinterpret_cast<const u32x4*>(dyptr + view_pixel_offset(DY, img, y, x) + nc0 + (cc < n_cnt ? cc : 0));
+      const unsigned off = y_inside(q, ty0, tx0) ? yorg + y_rel[q] : kOutOfRange;
+      stage[X_ITEMS + q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(yr, static_cast<int>(off), 0, 0));
     }
   };
   // writes the tile held in `stage` (geometry s_ty0 / s_tx0) into an LDS buffer
-  auto store_tile = [&](const u32x4 (&stage)[N_ITEMS], int s_ty0, int s_tx0, unsigned char* buf) {
-    const bool interior = s_ty0 >= HALO && s_tx0 >= HALO && s_ty0 + TH + HALO <= d.H && s_tx0 + TW + HALO <= d.W;
+  auto store_tile = [&](const u32x4 (&stage)[N_ITEMS], int s_ty0, int s_tx0, unsigned char* buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < X_ITEMS; ++q) {
       const int it = tid + q * kWThreads;
@@ -226,26 +235,18 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_bf16_kernel(const WBfArgs 
           for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
         }
         v = pack8(f);
-      }
-      if (!interior) {
-        const int y = s_ty0 + item_hy(q) - HALO, x = s_tx0 + item_hx(q) - HALO;
-        const bool keep = y >= 0 && y < d.H && x >= 0 && x < d.W;
+        if (x_affine) {   // the padding is zero AFTER the transform
+          const bool keep = x_inside(q, s_ty0, s_tx0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0u;
+          for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0u;
+        }
       }
-      if (it < NPIX * 4 && cc < k_cnt) *reinterpret_cast<u32x4*>(&buf[it * 16]) = v;
+      if (it < NPIX * 4) *reinterpret_cast<u32x4*>(&buf[it * 16]) = v;
     }
 #pragma unroll
     for (int q = 0; q < DY_ITEMS; ++q) {
       const int it = tid + q * kWThreads;
-      u32x4 v = stage[X_ITEMS + q];
-      if (!interior) {
-        const int p = it >> 2;
-        const bool keep = s_ty0 + (p >> LOG2TW) < d.H && s_tx0 + (p & (TW - 1)) < d.W;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = keep ? v[e] : 0u;
-      }
-      if (cc < n_cnt) *reinterpret_cast<u32x4*>(&buf[X_BYTES + it * 16]) = v;
+      *reinterpret_cast<u32x4*>(&buf[X_BYTES + it * 16]) = stage[X_ITEMS + q];
     }
   };
 
@@ -521,10 +522,9 @@ __global__ __launch_bounds__(QuadShape<TAPS>::THREADS, 1) void wgrad_bf16_quad_k
     const int p = (tid + q * THREADS) >> 3;
     y_rel[q] = ((static_cast<unsigned>(p >> LOG2TW) * DY.sy * DY.Ws + static_cast<unsigned>(p & (TW - 1)) * DY.sx) * DY.C + ch) * 2u;
   }
-  const __amdgpu_buffer_rsrc_t x_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X.ptr), 0, static_cast<int>(a.x_bytes[xv]), 0x00020000);
-  const __amdgpu_buffer_rsrc_t y_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DY.ptr), 0, static_cast<int>(a.dy_bytes[dv]), 0x00020000);
+  // one resource per IMAGE (base = the image's first element, rebuilt in scalar registers per tile): offsets stay
+  // below 2^31 whatever the batch size
+  const int x_img_elems = X.Hs * X.Ws * X.C, y_img_elems = DY.Hs * DY.Ws * DY.C;
   // range tests of an item of the tile at (y0, x0)
   auto x_inside = [&](int q, int y0, int x0) __attribute__((always_inline)) {
     const int y = y0 - HALO + (x_pos[q] >> 16), x = x0 - HALO + (x_pos[q] & 0xffff);
@@ -550,16 +550,17 @@ __global__ __launch_bounds__(QuadShape<TAPS>::THREADS, 1) void wgrad_bf16_quad_k
   auto load_item = [&](auto qc) __attribute__((always_inline)) {
     constexpr int q = decltype(qc)::v;
     if constexpr (q < X_ITEMS) {
-      const unsigned org = static_cast<unsigned>(((img * X.Hs + (ty0 - HALO) * X.sy + X.oy) * X.Ws + (tx0 - HALO) * X.sx + X.ox) * X.C +
-                                                 X.c_off + c0) * 2u;
+      const __amdgpu_buffer_rsrc_t rsrc = image_rsrc(xptr, img, x_img_elems);
+      const unsigned org =
+          static_cast<unsigned>((((ty0 - HALO) * X.sy + X.oy) * X.Ws + (tx0 - HALO) * X.sx + X.ox) * X.C + X.c_off + c0) * 2u;
       const unsigned off = x_inside(q, ty0, tx0) ? org + x_rel[q] : kOutOfRange;
-      stage[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, static_cast<int>(off), 0, 0));
+      stage[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(off), 0, 0));
     } else {
       constexpr int qy = q - X_ITEMS;
-      const unsigned org = static_cast<unsigned>(((img * DY.Hs + ty0 * DY.sy + DY.oy) * DY.Ws + tx0 * DY.sx + DY.ox) * DY.C +
-                                                 DY.c_off + nc0) * 2u;
+      const __amdgpu_buffer_rsrc_t rsrc = image_rsrc(dyptr, img, y_img_elems);
+      const unsigned org = static_cast<unsigned>(((ty0 * DY.sy + DY.oy) * DY.Ws + tx0 * DY.sx + DY.ox) * DY.C + DY.c_off + nc0) * 2u;
       const unsigned off = y_inside(qy, ty0, tx0) ? org + y_rel[qy] : kOutOfRange;
-      stage[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, static_cast<int>(off), 0, 0));
+      stage[q] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, static_cast<int>(off), 0, 0));
     }
   };
   // bias gradient = column sums of dy: taken where every dy value passes through a thread's registers exactly once
@@ -833,9 +834,7 @@ bool wgrad_bf16_quads(const unetpp_wgrad_desc* d) {
   const char* e = getenv("UNETPP_BF16_WGRAD_QUAD");  // read per call: the tests switch it inside one process
   if ((e != nullptr && e[0] == '0') || !(d->flags & UNETPP_GEMM_BF16)) return false;
   if (d->taps == 9 && d->n_x == 1 && d->x[0].c_len <= 4) return false;  // first layer: its own kernel
-  auto fits = [&](const unetpp_view& v) {   // buffer-resource addressing: whole tensor below 2 GB
-    return v.c_len > 0 && (v.c_len & 63) == 0 && static_cast<long>(d->N) * v.Hs * v.Ws * v.C * 2 <= 0x7fffffffL;
-  };
+  auto fits = [&](const unetpp_view& v) { return v.c_len > 0 && (v.c_len & 63) == 0; };
   for (int i = 0; i < d->n_x; ++i)
     if (!fits(d->x[i])) return false;
   for (int i = 0; i < d->n_dy; ++i)
@@ -861,15 +860,15 @@ int launch_wgrad_bf16(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_til
   a.tiles_y = g.tiles_y;
   a.n_pix_tiles = static_cast<long>(d->N) * g.tiles_y * g.tiles_x;
   if (a.n_pix_tiles > 0x7fffffffL) return UNETPP_EINVAL;
-  for (int i = 0; i < d->n_x; ++i)   // 32-bit element offsets inside a tile
-    if (static_cast<long>(d->x[i].Hs) * d->x[i].Ws * d->x[i].C >= 0x7fffffffL) return UNETPP_EINVAL;
+  for (int i = 0; i < d->n_x; ++i)   // 31-bit byte offsets inside an image (buffer resources, one per image)
+    if (static_cast<long>(d->x[i].Hs) * d->x[i].Ws * d->x[i].C * 2 > 0x7fffffffL) return UNETPP_EINVAL;
+  for (int i = 0; i < d->n_dy; ++i)
+    if (static_cast<long>(d->dy[i].Hs) * d->dy[i].Ws * d->dy[i].C * 2 > 0x7fffffffL) return UNETPP_EINVAL;
   if (wgrad_bf16_quads(d)) {
     int kq = 0, nq = 0;
     for (int i = 0; i < d->n_x; ++i) kq += d->x[i].c_len >> 6;
     for (int i = 0; i < d->n_dy; ++i) nq += d->dy[i].c_len >> 6;
     a.n_tiles_cols = nq;
-    for (int i = 0; i < d->n_x; ++i) a.x_bytes[i] = static_cast<unsigned>(static_cast<long>(d->N) * d->x[i].Hs * d->x[i].Ws * d->x[i].C * 2);
-    for (int i = 0; i < d->n_dy; ++i) a.dy_bytes[i] = static_cast<unsigned>(static_cast<long>(d->N) * d->dy[i].Hs * d->dy[i].Ws * d->dy[i].C * 2);
     const dim3 qgrid(static_cast<unsigned>(d->n_split), static_cast<unsigned>(kq * nq));
     if (d->taps == 9) {
       if (g.log2tw == 5) return launch_quad<9, 5>(a, qgrid, st);
