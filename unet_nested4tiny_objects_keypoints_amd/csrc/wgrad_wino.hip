@@ -20,6 +20,8 @@
 //   * x views may carry the folded BatchNorm apply + ReLU of their producer (applied at the window read; NaN padding);
 //   * epilogue: the 4 tile groups are summed in a fixed-order tree through LDS, one slab per workgroup; db comes
 //     from the (1,1) element of A dY A^T, which is the plain sum of the 2x2 tile.
+#include <cstdlib>
+
 #include "common.h"
 #include "lds_asm.h"
 
@@ -60,6 +62,7 @@ struct WWinoArgs {
   int tiles_x, tiles_y;
   int Ktot, Ncols, n_tiles_cols;
   long n_pix_tiles;
+  int rsrc_ok;  // every view's image is below 2 GB: operands through per-image buffer resources (plain-view kernel)
 };
 
 constexpr int x_slot(int U) { return (U >> 3) * GX + (U & 7) * 32; }  // float offset of pixel slot U of the x patch
@@ -159,6 +162,51 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
     const int ty0 = tyi * kTH, tx0 = txi * kTW;
     const char* xb = reinterpret_cast<const char*>(X.ptr + view_pixel_offset(X, n, ty0 - 1, tx0 - 1) + c0);
     const char* yb = reinterpret_cast<const char*>(DY.ptr + view_pixel_offset(DY, n, ty0, tx0) + nc0);
+#ifdef UNETPP_WWINO_EXP_OLD_STAGING   // A/B builds only (tools/wino_ablation.sh)
+    constexpr bool kRsrcStaging = false;
+#else
+    constexpr bool kRsrcStaging = !XFORM;
+#endif
+    if constexpr (kRsrcStaging) {
+      {
+        // Plain views (images below 2 GB: launcher): both operands by LDS-DMA through a buffer resource over the tile's image.
+        // An item outside the image (or a channel quad past a narrow view) gets an offset past the end of the image
+        // and the DMA writes zeros -- one straight path for interior and border patches.  (The two-pass border path
+        // below -- range tests, predicated zero fills, predicated DMAs -- runs for 30 % of the patches of a 256 x 256
+        // image, 56 % at 128 x 128 and every patch at 64 x 64.)
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(X.ptr) + static_cast<long>(n) * X.Hs * X.Ws * X.C, 0, X.Hs * X.Ws * X.C * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(DY.ptr) + static_cast<long>(n) * DY.Hs * DY.Ws * DY.C, 0, DY.Hs * DY.Ws * DY.C * 4, 0x00020000);
+        const unsigned xorg =
+            static_cast<unsigned>((((ty0 - 1) * X.sy + X.oy) * X.Ws + (tx0 - 1) * X.sx + X.ox) * X.C + X.c_off + c0) * 4u;
+        const unsigned yorg = static_cast<unsigned>(((ty0 * DY.sy + DY.oy) * DY.Ws + tx0 * DY.sx + DY.ox) * DY.C + DY.c_off + nc0) * 4u;
+        const int pix = static_cast<int>(in_block(static_cast<unsigned>(tid))) >> 3;  // pixel slot of item 0; item q sits 64 slots on
+#pragma unroll
+        for (int q = 0; q < X_ITEMS; ++q) {
+          if (q * 8 + wave < XG) {  // wave uniform: the last item ends after 45 groups
+            const int hp = pix + q * (kWThreads >> 3);
+            const int hy = hp / kXRow, hx = hp - hy * kXRow;
+            const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+            const bool inside = kx_ok & (hx < kHWp) & (static_cast<unsigned>(y) < static_cast<unsigned>(d.H)) &
+                                (static_cast<unsigned>(x) < static_cast<unsigned>(d.W));
+            const unsigned off = in_block(inside ? xorg + xdelta[q] : 0x80000000u);  // produced next to its use
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lptr_t)(buf + (q * 8 + wave) * GX), 16, static_cast<int>(off), 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < DY_ITEMS; ++q) {
+          const int p = pix + q * (kWThreads >> 3);
+          const bool inside = nx_ok & (ty0 + (p >> 5) < d.H) & (tx0 + (p & 31) < d.W);
+          const unsigned off = in_block(inside ? yorg + ydelta[q] : 0x80000000u);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lptr_t)(buf + X_FLOATS + (q * 8 + wave) * GY), 16, static_cast<int>(off), 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        return;
+      }
+    }
+    if constexpr (!kRsrcStaging) {
+    // views with a folded BatchNorm apply (NaN padding, see above): interior patches straight, border patches in two passes
     const bool interior = ty0 >= 1 && tx0 >= 1 && ty0 + kTH + 1 <= d.H && tx0 + kTW + 1 <= d.W;
     const int lq = (tid & 63) * 4;  // float slot of this lane inside its 1 KB group
     if (interior) {
@@ -212,6 +260,7 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
         float* lbase = buf + X_FLOATS + (q * 8 + wave) * GY;
         if ((yin >> q) & 1u) __builtin_amdgcn_global_load_lds((gptr_t)(yb + in_block(ydelta[q])), (lptr_t)lbase, 16, 0, 0);
       }
+    }
     }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -560,6 +609,15 @@ int launch_wgrad_wino(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_til
   a.tiles_y = g.tiles_y;
   a.n_pix_tiles = static_cast<long>(d->N) * g.tiles_y * g.tiles_x;
   if (a.n_pix_tiles >= 0x7fffffffL) return 1;  // 32-bit tile indices in the kernel
+  a.rsrc_ok = 1;
+  for (int i = 0; i < d->n_x; ++i)
+    if (static_cast<long>(d->x[i].Hs) * d->x[i].Ws * d->x[i].C * 4 > 0x7fffffffL) a.rsrc_ok = 0;
+  for (int i = 0; i < d->n_dy; ++i)
+    if (static_cast<long>(d->dy[i].Hs) * d->dy[i].Ws * d->dy[i].C * 4 > 0x7fffffffL) a.rsrc_ok = 0;
+  const bool xform = d->x[0].scale != nullptr;  // all views or none (wgrad_wino_applies)
+#ifndef UNETPP_WWINO_EXP_OLD_STAGING
+  if (!xform && !a.rsrc_ok) return 1;  // plain views above 2 GB per image: the direct-sum kernels
+#endif
   const dim3 grid(static_cast<unsigned>(d->n_split), static_cast<unsigned>(static_cast<long>(k_tiles) * n_tiles_cols));
   if (d->x[0].scale != nullptr)
     hipLaunchKernelGGL(wgrad_wino_kernel<true>, grid, dim3(kWThreads), 0, st, a);
