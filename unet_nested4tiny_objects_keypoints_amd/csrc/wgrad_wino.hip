@@ -123,11 +123,13 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
   const int cc = (tid & 7) << 2;
   const bool kx_ok = cc < k_cnt, nx_ok = cc < n_cnt;
   unsigned xdelta[X_ITEMS], ydelta[DY_ITEMS];
+  unsigned x_valid = 0;  // bit q: item q is a real slot (columns 34, 35 of a row are not) of a channel quad inside the view
 #pragma unroll
   for (int q = 0; q < X_ITEMS; ++q) {
     const int hp = (tid >> 3) + q * (kWThreads >> 3);
     const int hy = hp / kXRow, hx = min(hp - hy * kXRow, kHWp - 1);  // slots 34, 35 of a row are never loaded
     xdelta[q] = static_cast<unsigned>(((hy * X.sy) * X.Ws + hx * X.sx) * X.C + cc) * 4u;
+    if (cc < k_cnt && hp - hy * kXRow < kHWp) x_valid |= 1u << q;
   }
 #pragma unroll
   for (int q = 0; q < DY_ITEMS; ++q) {
@@ -181,25 +183,43 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
         const unsigned xorg =
             static_cast<unsigned>((((ty0 - 1) * X.sy + X.oy) * X.Ws + (tx0 - 1) * X.sx + X.ox) * X.C + X.c_off + c0) * 4u;
         const unsigned yorg = static_cast<unsigned>(((ty0 * DY.sy + DY.oy) * DY.Ws + tx0 * DY.sx + DY.ox) * DY.C + DY.c_off + nc0) * 4u;
-        const int pix = static_cast<int>(in_block(static_cast<unsigned>(tid))) >> 3;  // pixel slot of item 0; item q sits 64 slots on
+        // interior patches (uniform test) skip the per-item range tests: ~15 vector instructions per item, and with
+        // ten items per wave and patch they were 5 % of the kernel (tools/wwino_ablation.sh)
+        const bool interior = ty0 >= 1 && tx0 >= 1 && ty0 + kTH + 1 <= d.H && tx0 + kTW + 1 <= d.W;
+        if (interior) {
 #pragma unroll
-        for (int q = 0; q < X_ITEMS; ++q) {
-          if (q * 8 + wave < XG) {  // wave uniform: the last item ends after 45 groups
-            const int hp = pix + q * (kWThreads >> 3);
-            const int hy = hp / kXRow, hx = hp - hy * kXRow;
-            const int y = ty0 + hy - 1, x = tx0 + hx - 1;
-            const bool inside = kx_ok & (hx < kHWp) & (static_cast<unsigned>(y) < static_cast<unsigned>(d.H)) &
-                                (static_cast<unsigned>(x) < static_cast<unsigned>(d.W));
-            const unsigned off = in_block(inside ? xorg + xdelta[q] : 0x80000000u);  // produced next to its use
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lptr_t)(buf + (q * 8 + wave) * GX), 16, static_cast<int>(off), 0, 0, 0);
+          for (int q = 0; q < X_ITEMS; ++q) {
+            if (q * 8 + wave < XG) {  // wave uniform: the last item ends after 45 groups
+              const unsigned off = in_block(((x_valid >> q) & 1u) ? xorg + xdelta[q] : 0x80000000u);
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lptr_t)(buf + (q * 8 + wave) * GX), 16, static_cast<int>(off), 0, 0, 0);
+            }
           }
-        }
 #pragma unroll
-        for (int q = 0; q < DY_ITEMS; ++q) {
-          const int p = pix + q * (kWThreads >> 3);
-          const bool inside = nx_ok & (ty0 + (p >> 5) < d.H) & (tx0 + (p & 31) < d.W);
-          const unsigned off = in_block(inside ? yorg + ydelta[q] : 0x80000000u);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lptr_t)(buf + X_FLOATS + (q * 8 + wave) * GY), 16, static_cast<int>(off), 0, 0, 0);
+          for (int q = 0; q < DY_ITEMS; ++q) {
+            const unsigned off = in_block(nx_ok ? yorg + ydelta[q] : 0x80000000u);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lptr_t)(buf + X_FLOATS + (q * 8 + wave) * GY), 16, static_cast<int>(off), 0, 0, 0);
+          }
+        } else {
+          const int pix = static_cast<int>(in_block(static_cast<unsigned>(tid))) >> 3;  // pixel slot of item 0; item q sits 64 slots on
+#pragma unroll
+          for (int q = 0; q < X_ITEMS; ++q) {
+            if (q * 8 + wave < XG) {
+              const int hp = pix + q * (kWThreads >> 3);
+              const int hy = hp / kXRow, hx = hp - hy * kXRow;
+              const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+              const bool inside = kx_ok & (hx < kHWp) & (static_cast<unsigned>(y) < static_cast<unsigned>(d.H)) &
+                                  (static_cast<unsigned>(x) < static_cast<unsigned>(d.W));
+              const unsigned off = in_block(inside ? xorg + xdelta[q] : 0x80000000u);  // produced next to its use
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lptr_t)(buf + (q * 8 + wave) * GX), 16, static_cast<int>(off), 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < DY_ITEMS; ++q) {
+            const int p = pix + q * (kWThreads >> 3);
+            const bool inside = nx_ok & (ty0 + (p >> 5) < d.H) & (tx0 + (p & 31) < d.W);
+            const unsigned off = in_block(inside ? yorg + ydelta[q] : 0x80000000u);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lptr_t)(buf + X_FLOATS + (q * 8 + wave) * GY), 16, static_cast<int>(off), 0, 0, 0);
+          }
         }
         __builtin_amdgcn_s_setprio(0);
         return;
