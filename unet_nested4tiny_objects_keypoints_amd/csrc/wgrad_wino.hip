@@ -78,7 +78,9 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
 
   const unetpp_wgrad_desc& d = a.d;
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, t16 = lane & 15, g = lane >> 4;
+  // (wave index through readfirstlane: a scalar, so that the LDS-DMA destinations and the wave-uniform tests below are
+  // scalar arithmetic -- as a vector value every DMA piece paid a v_mad + v_readfirstlane for its M0)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, t16 = lane & 15, g = lane >> 4;
   const int ch = wave & 1;                                         // channel half
   const int tg = wave >> 1;                                        // tile group: tile columns 4*tg .. 4*tg + 3
 
