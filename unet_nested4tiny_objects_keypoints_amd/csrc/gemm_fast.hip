@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : 3) : 3)) void
 
   const unetpp_gemm_desc& d = a.d;
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 31, h = lane >> 5;  // scalar: wave-uniform LDS addresses and tests stay on the scalar unit
 
   const UnitRange ur = my_unit_range(a.total_blocks);  // XCD-contiguous ranges, round-robin inside an XCD
   const long first_unit = ur.first, unit_step = ur.step, my_units = ur.count;

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_bf16_kernel(const WBfArgs 
 
   const unetpp_wgrad_desc& d = a.d;
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 31, h = lane >> 5;  // (scalar wave index)
 
   int nt = blockIdx.y % a.n_tiles_cols;
   int kt = blockIdx.y / a.n_tiles_cols;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(QuadShape<TAPS>::THREADS, 1) void wgrad_bf16_quad_k
 
   const unetpp_wgrad_desc& d = a.d;
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 31, h = lane >> 5;  // (scalar wave index)
   const int pair = wave / WPP, sub = wave - pair * WPP;  // sub = filter column (3x3) / pixel half (1x1)
   const int kl = pair >> 1, nl = pair & 1;               // (channel tile, column tile) of the pair inside the quad
 

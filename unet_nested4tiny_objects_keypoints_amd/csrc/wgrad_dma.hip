@@ -48,7 +48,7 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_dma_kernel(const WDmaArgs 
 
   const unetpp_wgrad_desc& d = a.d;
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, j = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 31, h = lane >> 5;  // scalar: wave-uniform LDS-DMA destinations and tests stay on the scalar unit
 
   int nt = blockIdx.y % a.n_tiles_cols;
   int kt = blockIdx.y / a.n_tiles_cols;
