@@ -210,6 +210,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
   };
   auto dma_chunk = [&](int in_buf, int w_buf, bool need_in, bool need_w) {
     unsigned char* in_dst = smem + in_buf * IN_BYTES;
+#ifdef UNETPP_DMA_EXP_NO_INDMA
+    need_in = false;
+#endif
     if (need_in) {  // uniform
     const unetpp_view& V = d.in[p_s];
     const __amdgpu_buffer_rsrc_t rsrc =
@@ -478,7 +481,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
             }
             out = pack8(v);
           }
+#ifdef UNETPP_DMA_EXP_STORE_LINEAR   // timing only: every store instruction writes 1 KB contiguous (wrong layout)
+          if (pix_ok && c0 < tc.n_cnt) *reinterpret_cast<u32x4*>(optr + tile_base + ((wave * 4 + mt * 2 + half) * 64 + lane) * 8) = out;
+#else
           if (pix_ok && c0 < tc.n_cnt) *reinterpret_cast<u32x4*>(optr + pbase + c0) = out;
+#endif
         }
       }
     }
@@ -523,6 +530,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
       constexpr int step = decltype(sc)::v, cs = step & 1, ns = cs ^ 1;
       if constexpr (step + 1 < TAPS * 2) issue_frag(IC<step + 1>{}, fr[ns], in_base, w_base);
       __builtin_amdgcn_sched_barrier(0);
+#ifndef UNETPP_DMA_EXP_NO_MFMA   // (UNETPP_DMA_EXP_*: timing experiments of tools/bf16_dma_ablation.sh, wrong results)
 #pragma unroll
       for (int ct = 0; ct < NT; ++ct) {
         if constexpr (STATS) {
@@ -537,6 +545,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
                                                                __builtin_bit_cast(bf16x8, fr[cs].a1), acc[ct][1], 0, 0, 0);
         }
       }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (step + 1 < TAPS * 2) wait_frag(fr[ns]);
     });
@@ -556,7 +565,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
         __syncthreads();  // the transposing epilogue uses the buffer just computed from as scratch: all waves are done with it
         epilogue_stats(smem + in_cur * IN_BYTES);
       } else {
+#ifndef UNETPP_DMA_EXP_NO_EPI
         epilogue_direct();
+#endif
       }
       step_unit(c_ug, c_index);
       c_chunk = 0;
