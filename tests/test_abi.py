@@ -75,6 +75,16 @@ def test_argument_validation_without_gpu(built_lib):
     assert lib.unetpp_gemm_pixel_blocks(0, 256, 256) == 0
     assert lib.unetpp_gemm_stats_rows(32, 256, 256) == 32 * 32 * 8 and lib.unetpp_gemm_stats_rows(1, 64, 64) == 2048
     assert lib.unetpp_wgrad_max_split(1, 8, 8) == 1
+    wd = built_lib.WgradDesc()   # which kernel a weight-gradient descriptor gets is decided on the host
+    wd.N, wd.H, wd.W, wd.taps, wd.n_x, wd.n_dy = 2, 32, 32, 9, 2, 1
+    for v, c in ((wd.x[0], 64), (wd.x[1], 128), (wd.dy[0], 64)):
+        v.C = v.c_len = c
+    assert lib.unetpp_wgrad_pairs_per_workgroup(ctypes.byref(wd)) == 1     # fp32: one tile pair per workgroup
+    wd.flags = built_lib.GEMM_BF16
+    assert lib.unetpp_wgrad_pairs_per_workgroup(ctypes.byref(wd)) == 4     # bf16, every view a multiple of 64 wide
+    wd.x[1].C = wd.x[1].c_len = 96
+    assert lib.unetpp_wgrad_pairs_per_workgroup(ctypes.byref(wd)) == 1
+    assert lib.unetpp_wgrad_pairs_per_workgroup(None) == 0
     assert lib.unetpp_head_bwd_blocks(100) == 2
     assert lib.unetpp_bn_bwd_blocks(32 * 256 * 256, 32) % 8 == 0
     d = built_lib.GemmDesc()
