@@ -23,6 +23,9 @@ from .ops import V
 
 
 USE_PACK_PLAN = os.environ.get("UNETPP_NO_PACK_PLAN") is None  # one batched weight-image launch per pass (ops.PackPlan)
+# Input gradients of the dense skips grouped by PRODUCER (one GEMM per skip tensor over the concatenated dY of all its
+# consumers, written once) instead of by consumer (every consumer read-modify-writes a slice per input view).
+USE_GROUPED_DGRAD = os.environ.get("UNETPP_NO_GROUPED_DGRAD") is None
 
 
 # ----------------------------------------------------------------------------- weight re-layouts
@@ -50,6 +53,16 @@ def pack_conv_dgrad(w):
     t = kh * kw
     return ops.WSrc(w, t, co, ci, s_t=1, s_k=ci * t, s_n=t, flip=True,
                     pack=lambda: _packed(w, t, co, ci, (co * ci, ci, 1), (1, ci * t, t), flip=True))
+
+
+def pack_conv_dgrad_slice(w, c_off, c_len):
+    """pack_conv_dgrad of the input channels [c_off, c_off + c_len) of w -- read in place (strides of the whole weight)"""
+    co, ci, kh, kw = w.shape
+    t = kh * kw
+    flat = w.reshape(-1)[c_off * t:]   # contiguous 1-D view that starts at channel c_off of output channel 0
+    return ops.WSrc(flat, t, co, c_len, s_t=1, s_k=ci * t, s_n=t, flip=True,
+                    pack=lambda: _packed(w[:, c_off:c_off + c_len].contiguous(), t, co, c_len, (co * c_len, c_len, 1),
+                                         (1, c_len * t, t), flip=True))
 
 
 def pack_deconv_fwd(w):
@@ -290,7 +303,7 @@ def _forward_impl(model, x, training: bool, save: bool):
 class _GradBook:
     """Gradient buffers of the node outputs; tracks whether a buffer already holds a contribution."""
 
-    def __init__(self, X, depth, gate_keys):
+    def __init__(self, X, depth, gate_keys, grouped=False):
         self.X = X
         self.buf: Dict[Tuple[int, int], torch.Tensor] = {}
         self.got: Dict[Tuple[int, int], int] = {}
@@ -300,7 +313,8 @@ class _GradBook:
         self.expected = {}
         for (i, j) in X:
             n = (1 if (i == 0 and j >= 1) else 0)            # its deep-supervision head
-            n += max(0, (depth - 1 - i) - j)                  # concat input of X[i][j'] for j' > j
+            consumers = max(0, (depth - 1 - i) - j)           # concat input of X[i][j'] for j' > j
+            n += min(consumers, 1) if grouped else consumers  # (grouped: ONE launch for all of them)
             n += 1 if i >= 1 else 0                           # upsampled into X[i-1][j+1]
             n += 1 if (j == 0 and i < depth - 1) else 0       # max-pooled into X[i+1][0]
             self.expected[(i, j)] = n
@@ -343,13 +357,15 @@ def _conv_wgrad(conv, xs, dys, b, h, w, grads):
 
 
 def _pair_bwd(blk, r: _PairRec, d_out, in_targets: Optional[List[V]], b, grads, pre_gated=False, pool_grad=None,
-              flush=None):
+              flush=None, in_slice: Optional[Tuple[int, int]] = None):
     """Backward of models/unet.py:150-156.  d_out (gradient of r.out) is consumed.  in_targets: output views
     for the gradient of every entry of r.ins (None = the inputs need no gradient).  pre_gated: the last
     contributor already multiplied d_out by (r.out > 0).  pool_grad = (d_pooled, pool_idx): gradient of the max-pooled
     copy of r.out that has NOT been added to d_out yet (BatchNorm nodes only: routed inside BatchNorm backward).
     flush(): reports the parameter gradients finished so far to the data-parallel averager -- called after each
-    convolution's weight gradient, so the deepest node's 3.5 MB (configs[1]) are two buckets rather than one."""
+    convolution's weight gradient, so the deepest node's 3.5 MB (configs[1]) are two buckets rather than one.
+    in_slice = (first channel, channels): in_targets cover only that slice of conv1's input channels (grouped input
+    gradients: the caller computes the rest from the returned dy1).  Returns dy1, the gradient of conv1's output."""
     conv1, conv2 = getattr(blk.conv1, "0"), getattr(blk.conv2, "0")
     h, w = r.h, r.w
     if blk.is_batchnorm:
@@ -385,8 +401,11 @@ def _pair_bwd(blk, r: _PairRec, d_out, in_targets: Optional[List[V]], b, grads, 
         if dy1.t.dtype == torch.bfloat16 and in_targets[0].t.dtype == torch.float32:
             # bf16 storage, gradient of the fp32 network input (1..4 channels): the first layer's own VALU kernel
             ops.first_layer_dgrad_bf16(dy1.t, conv1.weight.detach(), in_targets[0].t)
+        elif in_slice is not None:
+            ops.gemm_fwd(b, h, w, 9, [dy1], in_targets, pack_conv_dgrad_slice(conv1.weight.detach(), in_slice[0], in_slice[1]))
         else:
             ops.gemm_fwd(b, h, w, 9, [dy1], in_targets, pack_conv_dgrad(conv1.weight.detach()))
+    return dy1
 
 
 def _up_bwd(upmod, is_deconv, u: _UpRec, d_up, d_src, accumulate, gate, b, grads):
@@ -407,9 +426,38 @@ def _up_bwd(upmod, is_deconv, u: _UpRec, d_up, d_src, accumulate, gate, b, grads
         ops.bilinear2x_bwd(d_interp, d_src, accumulate, gate)  # (gate: bf16 storage only, see backward_impl)
 
 
+def _grouped_weights(model, refresh=False):
+    """{(i, jj): [sum of consumer widths, f_i, 3, 3]}: for every skip tensor X[i][jj] the input-channel slices that read it
+    in conv1 of its consumers (i, jj+1), (i, jj+2), ..., concatenated along the OUTPUT-channel axis -- as a convolution
+    weight its input gradient is the sum of the consumers' contributions.  Buffers are kept (stable addresses: the
+    pack plan prepacks their images with everything else) and refilled from the current parameters when `refresh`."""
+    cache = getattr(model, "_grouped_dgrad_w", None)
+    d = model.depth
+    if cache is None or refresh:
+        fresh = {}
+        for i in range(d - 1):
+            for jj in range(d - 1 - i):
+                parts = []
+                for jc in range(jj + 1, d - i):
+                    w = getattr(getattr(model, "up_concat%d%d" % (i, jc)).conv.conv1, "0").weight.detach()
+                    f = w.shape[0]
+                    parts.append(w[:, (1 + jj) * f:(2 + jj) * f])
+                old = None if cache is None else cache.get((i, jj))
+                if old is not None and old.device == parts[0].device and old.dtype == parts[0].dtype:
+                    torch.cat(parts, 0, out=old)
+                    fresh[(i, jj)] = old
+                else:
+                    fresh[(i, jj)] = torch.cat(parts, 0).contiguous()
+        cache = fresh
+        model._grouped_dgrad_w = cache
+    return cache
+
+
 def backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=None):
     """Returns (dict param -> grad, dx NHWC or None).  grad_sink(list of (param, grad)) is called each time a
     node's parameter gradients are final (used by the data-parallel bucketed all-reduce)."""
+    if USE_GROUPED_DGRAD:
+        _grouped_weights(model, refresh=True)   # before the pack plan packs this pass's weight images
     if not USE_PACK_PLAN:
         return _backward_impl(model, s, d_outs, want_input_grad, grad_sink)
     plan = _plan_of(model)
@@ -428,8 +476,10 @@ def _backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=No
     # Nodes without BatchNorm end in a plain ReLU whose mask the last gradient contributor can apply for free
     # (decoder nodes always; encoder nodes only when is_batchnorm=False -- with BN the mask lives in BN backward).
     gate_keys = {k for k in s.X if k[1] >= 1 or not model.is_batchnorm}
-    book = _GradBook(s.X, d, gate_keys)
+    grouped = USE_GROUPED_DGRAD
+    book = _GradBook(s.X, d, gate_keys, grouped)
     bf16 = s.X[(0, 0)].dtype == torch.bfloat16
+    dy1s: Dict[Tuple[int, int], V] = {}   # grouped input gradients: dY of conv1 of the decoder nodes done so far
     seen = set()
 
     def flush():
@@ -463,10 +513,26 @@ def _backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=No
             d_out, pre_gated = book.take((i, j))
             d_up = torch.empty_like(u.up)
             targets = [V(d_up)]
-            for jj in range(j):
-                t, acc, gate = book.target((i, jj), can_gate=True)
-                targets.append(V(t, accumulate=acc, gate=gate, gate_sum=True))
-            _pair_bwd(mod.conv, r, d_out, targets, b, grads, pre_gated, flush=flush)
+            if grouped:
+                # this node's own launch only makes the gradient of its upsampled input; node (i, j) is the LAST consumer
+                # of X[i][j-1] in backward order, so that tensor's whole skip gradient is due now: one GEMM over the dY of
+                # its consumers (i, j), (i, j+1), ... with the matching input-channel slices of their weights (K-concatenated
+                # in the order of _grouped_weights), written -- or added to the head / upsampling contribution -- once
+                c_up = u.up.shape[3]
+                dy1s[(i, j)] = _pair_bwd(mod.conv, r, d_out, targets, b, grads, pre_gated, flush=flush, in_slice=(0, c_up))
+                consumers = list(range(j, d - i))
+                t, acc, gate = book.target((i, j - 1), can_gate=True)
+                ops.gemm_fwd(b, r.h, r.w, 9, [dy1s[(i, jc)] for jc in consumers],
+                             [V(t, accumulate=acc, gate=gate, gate_sum=True)],
+                             pack_conv_dgrad(_grouped_weights(model)[(i, j - 1)]))
+                if j == 1:
+                    for jc in consumers:   # level i is done with its dY tensors
+                        del dy1s[(i, jc)]
+            else:
+                for jj in range(j):
+                    t, acc, gate = book.target((i, jj), can_gate=True)
+                    targets.append(V(t, accumulate=acc, gate=gate, gate_sum=True))
+                _pair_bwd(mod.conv, r, d_out, targets, b, grads, pre_gated, flush=flush)
             # the ReLU mask of a BatchNorm-less node is applied by its LAST gradient contribution: the transposed
             # convolution's input-gradient epilogue, or (bf16 storage, whose kernels take no gate on load) the bilinear
             # backward kernel
