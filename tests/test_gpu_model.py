@@ -323,6 +323,56 @@ def test_large_shape_properties(dev):
         assert rel_err(b, 2 * a) < 1e-5
 
 
+@pytest.mark.parametrize("kwargs,dtype", [
+    (dict(in_channels=1, n_classes=4, feature_scale=2), torch.float32),
+    (dict(in_channels=1, n_classes=4, feature_scale=2, is_deconv=False), torch.float32),
+    (dict(in_channels=3, n_classes=5, feature_scale=1, depth=5), torch.float32),
+    (dict(in_channels=1, n_classes=4, feature_scale=1), torch.bfloat16),
+])
+def test_grouped_and_per_consumer_input_gradients_agree(dev, kwargs, dtype):
+    """engine.USE_GROUPED_DGRAD: the skip tensors' gradients as one GEMM per producer over the dY of all its consumers
+    (default) against one launch per consumer with accumulation -- the same sums in another order; every parameter
+    gradient and the input gradient must agree to rounding, and parameter updates between the two passes must be seen
+    (the concatenated weight slices are refilled from the parameters every backward)."""
+    from unet_nested4tiny_objects_keypoints_amd import UNet_Nested, engine
+    torch.manual_seed(21)
+    depth = kwargs.get("depth", 4)
+    m = UNet_Nested(**kwargs).to(dev)
+    if dtype == torch.bfloat16:
+        m.set_activation_dtype(torch.bfloat16)
+    m.train()
+    m.drop_out.eval()
+    size = 16 * 2 ** (depth - 1)
+    x = torch.randn(2, kwargs["in_channels"], size, size, device=dev)
+    want_dx = dtype == torch.float32
+
+    def grads(grouped):
+        old = engine.USE_GROUPED_DGRAD
+        engine.USE_GROUPED_DGRAD = grouped
+        try:
+            m.zero_grad()
+            xin = x.clone().requires_grad_(want_dx)
+            outs = m(xin)
+            sum((o * (k + 1)).sum() for k, o in enumerate(outs)).backward()
+            # (a bias in front of BatchNorm has an exactly-zero gradient: both schedules hold rounding noise there)
+            return [p.grad.clone() for k, p in m.named_parameters() if not is_pre_bn_bias(k, kwargs)] + (
+                [xin.grad.clone()] if want_dx else [])
+        finally:
+            engine.USE_GROUPED_DGRAD = old
+
+    tol = 1e-5 if dtype == torch.float32 else 2e-2   # bf16 storage: the two schedules round different partial sums
+    a, b = grads(True), grads(False)
+    for ga, gb in zip(a, b):
+        assert rel_err(ga, gb) < tol
+    with torch.no_grad():   # an optimizer step through .data between two grouped passes
+        for p in m.parameters():
+            p.data.mul_(0.9)
+    c, d = grads(True), grads(False)
+    for gc, gd in zip(c, d):
+        assert rel_err(gc, gd) < tol
+    assert any(rel_err(gc, ga) > 1e-3 for gc, ga in zip(c, a))
+
+
 def test_batched_weight_images_track_parameter_updates(dev):
     """ops.PackPlan: from the second pass on every weight image of a pass is packed by one launch.  Outputs and
     gradients must equal the per-launch packing bit for bit, before and after an optimizer step, and a deep copy of the
