@@ -255,41 +255,44 @@ __global__ __launch_bounds__(kThreads) void head_fwd_bf16_kernel(const bf16_t* _
 // shifts and 32 bits; a thread's octet position is the same for all its pieces, so its class weights stay in registers
 // (the first version read 32 weights from LDS per octet); the (class, channel) pairs of the weight-gradient pass are
 // decoded once; DROP (0 none, 1 counter hash, 2 mask tensor) keeps the piece loop free of per-element branches.
-template <int LOG2CG, int DROP, int PCLS>
+constexpr int kHeadTilePixels = 256;
+template <int LOG2CG, int DROP, int PCLS>  // PCLS = classes padded to 4 or 8: the class loops carry no n_cls branches
 __global__ __launch_bounds__(kThreads) void head_bwd_bf16_kernel(const float* __restrict__ d_out, const float* __restrict__ outp,
                                                                  const bf16_t* __restrict__ x, const float* __restrict__ weight,
                                                                  unsigned pixels, unsigned HW, int n_cls, float keep_scale,
                                                                  uint32_t thr16, uint64_t seed, const uint8_t* __restrict__ mask,
                                                                  bf16_t* __restrict__ dx, int accumulate, int gate_x,
                                                                  float* __restrict__ partial) {
+  // 256-pixel tiles (four items in flight per thread at 32 channels): dlogit = d_out * out * (1 - out) of the tile goes through LDS (the NCHW class planes are read
+  // coalesced along the pixels), then every thread takes (pixel, channel octet) items: dx = keep * scale * (W^T dlogit)
+  // (+ old dx, ReLU gate of x) and the weight gradient of ITS octet, dlogit_k * (x * keep * scale), summed in registers
+  // over all its items of the launch.  (Until round 3 the weight gradient went through LDS per tile -- x * keep * scale
+  // written back, a third barrier and a 64-step loop of two LDS reads per (class, channel) pair: most of the kernel.)
+  // One reduction at the end: lanes that share an octet by xor-shuffles, the four waves through LDS, fixed order.
   extern __shared__ float hsm[];
-  constexpr int CG = 1 << LOG2CG, C = 8 * CG, XS = C + 1;
-  constexpr int ITEMS = (64 * CG + kThreads - 1) / kThreads;
-  float* xs = hsm;           // [64][C+1]
-  float* dl = xs + 64 * XS;  // [64][8]
-  const int tid = threadIdx.x;
+  constexpr int CG = 1 << LOG2CG, C = 8 * CG, TP = CG <= 8 ? kHeadTilePixels : 8 * kThreads / CG;  // <= 8 items per thread
+  constexpr int ITEMS = (TP * CG + kThreads - 1) / kThreads;
+  float* dl = hsm;                     // [TP][8]
+  float* red = dl + TP * kHeadMaxCls;  // [4 waves][PCLS * C + PCLS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cg = tid & (CG - 1);
-  float wq[PCLS][8];  // class weights of this thread's octet (zero rows past n_cls)
+  float wq[PCLS][8], wacc[PCLS][8], bacc[PCLS];
 #pragma unroll
-  for (int k = 0; k < PCLS; ++k)
+  for (int k = 0; k < PCLS; ++k) {
+    bacc[k] = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) wq[k][e] = (k < n_cls) ? weight[k * C + cg * 8 + e] : 0.f;
-  float wacc[4] = {0.f, 0.f, 0.f, 0.f};  // dW entries tid, tid+256, ... (n_cls*C <= 1024)
-  int pair_k[4], pair_c[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int idx = tid + q * kThreads;
-    pair_k[q] = idx >> (LOG2CG + 3);
-    pair_c[q] = idx & (C - 1);
+    for (int e = 0; e < 8; ++e) {
+      wq[k][e] = (k < n_cls) ? weight[k * C + cg * 8 + e] : 0.f;
+      wacc[k][e] = 0.f;
+    }
   }
-  float bacc = 0.f;
-  for (int i = tid; i < 64 * kHeadMaxCls; i += kThreads) dl[i] = 0.f;  // classes past n_cls are never written again
-  const unsigned n_tiles = (pixels + 63) / 64;
+  for (int i = tid; i < TP * kHeadMaxCls; i += kThreads) dl[i] = 0.f;  // classes past n_cls are never written again
+  const unsigned n_tiles = (pixels + TP - 1) / TP;  // (blocks past the tiles write zero rows: the caller sums them all)
   for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const unsigned p0 = tile * 64;
+    const unsigned p0 = tile * TP;
     __syncthreads();
-    for (int it = tid; it < 64 * n_cls; it += kThreads) {  // dlogit = d_out * out * (1 - out)
-      const int pl = it & 63, k = it >> 6;
+    for (int it = tid; it < TP * n_cls; it += kThreads) {  // dlogit = d_out * out * (1 - out)
+      const int pl = it & (TP - 1), k = it / TP;
       const unsigned p = p0 + pl;
       float v = 0.f;
       if (p < pixels) {
@@ -301,82 +304,95 @@ __global__ __launch_bounds__(kThreads) void head_bwd_bf16_kernel(const float* __
       dl[pl * kHeadMaxCls + k] = v;
     }
     __syncthreads();
-    // one pass over x in octets: keep mask, x*keep*scale -> LDS, dx = keep*scale * (W^T dlogit) (+ old dx, gate)
 #pragma unroll
     for (int u = 0; u < ITEMS; ++u) {
       const int it = tid + u * kThreads;
-      if (ITEMS * kThreads != 64 * CG && it >= 64 * CG) break;
+      if (ITEMS * kThreads != TP * CG && it >= TP * CG) break;
       const int pl = it >> LOG2CG;
       const unsigned p = p0 + pl;
-      float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ks[8];
+      if (p >= pixels) continue;
+      const long oct = (static_cast<long>(p) << LOG2CG) + cg;
+      float raw[8], ks[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) ks[e] = 1.f;
-      if (p < pixels) {
-        const long oct = (static_cast<long>(p) << LOG2CG) + cg;
-        float raw[8];
-        unpack8(reinterpret_cast<const u32x4*>(x)[oct], raw);
-        if constexpr (DROP == 1) {
+      unpack8(reinterpret_cast<const u32x4*>(x)[oct], raw);
+      if constexpr (DROP == 1) {
 #pragma unroll
-          for (int half = 0; half < 2; ++half) {
-            const uint64_t bits = keep_bits(seed, p, 2 * CG, 2 * cg + half);
+        for (int half = 0; half < 2; ++half) {
+          const uint64_t bits = keep_bits(seed, p, 2 * CG, 2 * cg + half);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ks[4 * half + q] = keep_one(bits, q, thr16) ? keep_scale : 0.f;
-          }
-        } else if constexpr (DROP == 2) {
-          const uint2 m8 = *reinterpret_cast<const uint2*>(mask + oct * 8);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ks[e] = (((e < 4 ? m8.x : m8.y) >> (8 * (e & 3))) & 0xffu) != 0 ? keep_scale : 0.f;
+          for (int q = 0; q < 4; ++q) ks[4 * half + q] = keep_one(bits, q, thr16) ? keep_scale : 0.f;
         }
-        float dk[PCLS];  // (rows past n_cls of dl are zero: written by the dlogit pass below n_cls only, cleared once)
+      } else if constexpr (DROP == 2) {
+        const uint2 m8 = *reinterpret_cast<const uint2*>(mask + oct * 8);
 #pragma unroll
-        for (int k = 0; k < PCLS; ++k) dk[k] = dl[pl * kHeadMaxCls + k];
-        float o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          f[e] = raw[e] * ks[e];
-          float sum = 0.f;
-#pragma unroll
-          for (int k = 0; k < PCLS; ++k) sum = fmaf(wq[k][e], dk[k], sum);
-          o[e] = sum * ks[e];
-        }
-        if (accumulate) {
-          float old[8];
-          unpack8(reinterpret_cast<const u32x4*>(dx)[oct], old);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] += old[e];
-        }
-        if (gate_x) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (raw[e] > 0.f) ? o[e] : 0.f;
-        }
-        reinterpret_cast<u32x4*>(dx)[oct] = pack8(o);
+        for (int e = 0; e < 8; ++e) ks[e] = (((e < 4 ? m8.x : m8.y) >> (8 * (e & 3))) & 0xffu) != 0 ? keep_scale : 0.f;
       }
+      float dk[PCLS];  // (rows past n_cls of dl are zero: written by the dlogit pass below n_cls only, cleared once)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xs[pl * XS + cg * 8 + e] = f[e];
-    }
-    __syncthreads();
+      for (int k = 0; k < PCLS; ++k) dk[k] = dl[pl * kHeadMaxCls + k];
+      float o[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {  // dW[k, c] += sum_p dlogit[p, k] * xs[p, c]
-      if (tid + q * kThreads < n_cls * C) {
-        const int k = pair_k[q], c = pair_c[q];
+      for (int e = 0; e < 8; ++e) {
         float sum = 0.f;
-        for (int pl = 0; pl < 64; ++pl) sum = fmaf(dl[pl * kHeadMaxCls + k], xs[pl * XS + c], sum);
-        wacc[q] += sum;
+#pragma unroll
+        for (int k = 0; k < PCLS; ++k) sum = fmaf(wq[k][e], dk[k], sum);
+        o[e] = sum * ks[e];
+      }
+      if (accumulate) {
+        float old[8];
+        unpack8(reinterpret_cast<const u32x4*>(dx)[oct], old);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] += old[e];
+      }
+      if (gate_x) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (raw[e] > 0.f) ? o[e] : 0.f;
+      }
+      reinterpret_cast<u32x4*>(dx)[oct] = pack8(o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xd = raw[e] * ks[e];
+#pragma unroll
+        for (int k = 0; k < PCLS; ++k) wacc[k][e] = fmaf(dk[k], xd, wacc[k][e]);
+      }
+      if (cg == 0) {
+#pragma unroll
+        for (int k = 0; k < PCLS; ++k) bacc[k] += dk[k];
       }
     }
-    if (tid < n_cls) {
-      float sum = 0.f;
-      for (int pl = 0; pl < 64; ++pl) sum += dl[pl * kHeadMaxCls + tid];
-      bacc += sum;
+  }
+  // ---- lanes of a wave that share an octet (lane bits >= LOG2CG), then the four waves: fixed order, reproducible ----
+#pragma unroll
+  for (int k = 0; k < PCLS; ++k) {
+#pragma unroll
+    for (int m = CG; m < 64; m <<= 1) bacc[k] += __shfl_xor(bacc[k], m);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = wacc[k][e];
+#pragma unroll
+      for (int m = CG; m < 64; m <<= 1) v += __shfl_xor(v, m);
+      wacc[k][e] = v;
     }
   }
-  float* dst = partial + static_cast<long>(blockIdx.x) * (n_cls * C + n_cls);
+  __syncthreads();
+  constexpr int ROW = PCLS * C + PCLS;
+  if (lane < CG) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int idx = tid + q * kThreads;
-    if (idx < n_cls * C) dst[idx] = wacc[q];
+    for (int k = 0; k < PCLS; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wave * ROW + k * C + cg * 8 + e] = wacc[k][e];
   }
-  if (tid < n_cls) dst[n_cls * C + tid] = bacc;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < PCLS; ++k) red[wave * ROW + PCLS * C + k] = bacc[k];
+  }
+  __syncthreads();
+  const int NW = n_cls * C;
+  float* dst = partial + static_cast<long>(blockIdx.x) * (NW + n_cls);
+  for (int i = tid; i < NW; i += kThreads) dst[i] = (red[i] + red[ROW + i]) + (red[2 * ROW + i] + red[3 * ROW + i]);
+  if (tid < n_cls)
+    dst[NW + tid] = (red[PCLS * C + tid] + red[ROW + PCLS * C + tid]) + (red[2 * ROW + PCLS * C + tid] + red[3 * ROW + PCLS * C + tid]);
 }
 
 inline bool octets_ok(int C) {  // C = 8 * CG, CG a power of two <= 256 (a thread keeps its octet across a grid stride)
@@ -642,7 +658,7 @@ extern "C" int unetpp_head_bwd_bf16(const float* d_out_nchw, const float* out_nc
   const long pixels = static_cast<long>(N) * H * W;
   if (pixels >= 0x7fffffffL) return UNETPP_EINVAL;
   const long tiles = (pixels + 63) / 64;
-  const size_t lds = (64 * (C + 1) + 64 * kHeadMaxCls) * sizeof(float);
+  const size_t lds = (kHeadTilePixels * kHeadMaxCls + 4 * (kHeadMaxCls * C + kHeadMaxCls)) * sizeof(float);  // dlogit tile + 4 wave rows
   const dim3 grid(static_cast<unsigned>(tiles < 4096 ? tiles : 4096));
   const int drop = p_drop > 0.f ? (mask == nullptr ? 1 : 2) : 0;
   if (drop == 2 && (reinterpret_cast<uintptr_t>(mask) & 7) != 0) return UNETPP_EINVAL;  // mask octets are read as 8 bytes
