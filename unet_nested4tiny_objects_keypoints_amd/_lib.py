@@ -186,10 +186,14 @@ def build_library(force: bool = False, verbose: bool = False, out_path: str = No
     for obj, cmd, proc in jobs:
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + [j[0] for j in jobs]
+    # link inside the object directory and move the result: the offload bundler drops its temporaries beside the
+    # output file, and an interrupted link once left 32 of them in the package directory
+    staged = os.path.join(obj_dir, os.path.basename(lib_path) + ".link")
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", staged] + [j[0] for j in jobs]
     if verbose:
         print(" ".join(link))
     subprocess.run(link, check=True)
+    os.replace(staged, lib_path)
     if out_path is None:
         global _LIB
         _LIB = None
