@@ -28,6 +28,9 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 next to `traffic_algorithmic` (every operand read/written once) and their ratio.
   roofline_x00  the X_0,0 conv block forward (1.2457 GFLOP and 42.2 MB algorithmic per image):
                 frac = max(compute floor, HBM floor) / measured block time.
+  other_configs the default run (the headline workload) then times BASELINE configs[3] (512x512, bf16 storage, batch 8) and
+                configs[4] (depth 5, base 64, 3 -> 5 channels, 384x384, bf16 storage, batch 4) for >= 20 steps each with
+                the same bracket, and attaches value / ms_per_step / roofline / top kernels per configuration.
   cpu_baseline  the CPU oracle (oracle/, a PyTorch restatement of the reference proven equal to it on golden
                 fixtures) timed on this host's cores on a bounded sample of the same workload (batch 4).
 """
@@ -64,6 +67,10 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed CPU-oracle steps (BASELINE.md section 4: >= 3)")
     ap.add_argument("--prewarm", type=int, default=10, help="untimed steps before the W warm-up steps (see main)")
     ap.add_argument("--no-launch-timing", action="store_true", help="skip per-launch HIP events (roofline = null)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the bf16 configurations (BASELINE configs[3], configs[4]) the default run times after the "
+                         "headline and attaches under `other_configs`")
+    ap.add_argument("--other-steps", type=int, default=30, help="timed steps of each `other_configs` entry (>= 20)")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="multi-process plumbing only, on the CPU over gloo, with synthetic gradients and NO kernels: "
                          "self-spawn, rendezvous, broadcast, bucketed all-reduce, optimizer, max-over-ranks timing, "
@@ -263,44 +270,52 @@ def rehearse_cpu(args):
     dist.destroy_process_group()
 
 
-def main():
-    args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return spawn_ranks(args)
-    if args.rehearse_cpu:
-        return rehearse_cpu(args)
-    import torch
-    import torch.distributed as dist
+# BASELINE.json configs[3] / configs[4] as single-GPU geometries (per-GPU batch stated in the workload string): timed by
+# the default run after the headline and attached under `other_configs`
+OTHER_CONFIGS = (
+    ("configs[3]: deep supervision, 512x512, bf16",
+     dict(dtype="bf16", size=512, batch=8, feature_scale=1, depth=4, in_channels=1, n_classes=4)),
+    ("configs[4]: 3-channel 384x384, 5 key-point maps, depth 5, base 64, bf16",
+     dict(dtype="bf16", size=384, batch=4, feature_scale=0.5, depth=5, in_channels=3, n_classes=5)),
+)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if args.gpus != world and rank == 0 and distributed:
-        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # Rehearsal knobs for a 1-GPU box (never set by the driver): every rank on cuda:0 and gloo instead of RCCL,
-    # which exercises the whole multi-process path (broadcast, bucketed all-reduce on the side stream, barriers).
-    one_dev = os.environ.get("UNETPP_BENCH_SINGLE_DEVICE") == "1"
-    backend = os.environ.get("UNETPP_BENCH_BACKEND", "nccl")
-    dev_index = 0 if one_dev else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if distributed:
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
 
-    import __graft_entry__ as entry
-    if rank == 0:
-        entry.build()
-    if distributed:
-        dist.barrier()
+def is_headline(args):
+    """the default workload (configs[1]); runs with other shapes asked for on the command line stay single-config"""
+    return (args.dtype, args.size, args.batch, float(args.feature_scale), args.depth, args.in_channels, args.n_classes) == \
+        ("f32", 256, 32, 1.0, 4, 1, 4)
+
+
+def workload_name(args):
+    return ("UNet_Nested(in=%d,n_classes=%d,base=%d,depth=%d) %dx%d train step, batch %d/GPU, "
+            "FocalLoss_BCE_2d on %d heads, Adam, dropout p=0.4 active, %s"
+            % (args.in_channels, args.n_classes, int(32 / args.feature_scale), args.depth, args.size, args.size,
+               args.batch, args.depth - 1,
+               "fp32" if args.dtype == "f32" else "bf16 activation storage / fp32 accumulation and parameters"))
+
+
+def other_entry(name, o, r, world):
+    """one `other_configs` element: the same keys as the headline, trimmed to what a reader needs per configuration"""
+    roof = r["roofline"]
+    if roof is not None:
+        roof = {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_algorithmic",
+                                      "traffic_over_algorithmic", "mfma_busy_pmc", "avg_launch_ms", "launches_per_step",
+                                      "floor_hbm_ms", "floor_mfma_ms") if k in roof}
+    kern = r["kernels"]
+    if kern is not None:  # the five kernels with the most device time
+        kern = dict(sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])[:5])
+    return {"config": name, "workload": workload_name(o), "dtype": o.dtype, "value": round(r["value"], 2),
+            "unit": "images/sec", "n_gpus": world, "steps": o.steps, "warmup": o.warmup, "prewarm_steps": o.prewarm,
+            "ms_per_step": round(r["ms_per_step"], 3), "fwd_ms_per_img": round(r["fwd_ms_per_img"], 4),
+            "per_gpu_batch": o.batch, "global_batch": world * o.batch, "roofline": roof, "kernels": kern,
+            "replicas_bit_identical": r["replicas_identical"]}
+
+
+def measure(args, ctx):
+    """Times `args.steps` train steps of ONE configuration (after prewarm + warmup untimed ones) under the contract's
+    barrier / synchronize bracket and returns rank 0's result pieces (None on the other ranks)."""
+    torch, dist, dev = ctx["torch"], ctx["dist"], ctx["dev"]
+    world, rank, distributed = ctx["world"], ctx["rank"], ctx["distributed"]
     from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, UNet_Nested, dp, ops, train_step
 
     n_cls = args.n_classes
@@ -317,7 +332,8 @@ def main():
         # bucketed RCCL all-reduce on the side stream, delivery into p.grad -- to price what it costs beside the kernels
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29544")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         averager = dp.make_data_parallel(model, always_reduce=True)
     torch.manual_seed(1000 + rank)  # every rank its own shard of synthetic data
     x = torch.randn(args.batch, args.in_channels, args.size, args.size, device=dev)
@@ -383,11 +399,13 @@ def main():
         fwd_ms_per_img = 1e3 * (time.perf_counter() - t1) / (reps * args.batch)
     model.train()
 
+    dp_info = None if averager is None else {"grad_allreduce_buckets": len(averager.buckets_last_step),
+                                             "grad_bucket_bytes": averager.bucket_bytes,
+                                             "gradient_bytes": 4 * averager.flat.numel()}
+    del opt, x, target, model, averager  # the next configuration needs the memory
+    torch.cuda.empty_cache()
     if rank != 0:
-        if distributed:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+        return None
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * args.batch * args.steps / elapsed
@@ -451,6 +469,77 @@ def main():
                             "us_per_img": round(t_img_us, 2), "floor_compute_us": round(floor_c, 2),
                             "floor_hbm_us": round(floor_h, 2), "bound": "mfma" if floor_c >= floor_h else "hbm",
                             "frac": round(max(floor_c, floor_h) / t_img_us, 4)}
+    return {"value": value, "ms_per_step": ms_per_step, "fwd_ms_per_img": fwd_ms_per_img, "roofline": roofline,
+            "roofline_x00": roofline_x00, "kernels": kernels, "dp": dp_info,
+            "replicas_identical": replicas_identical, "n_cls": n_cls, "fs": fs}
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
+    if args.rehearse_cpu:
+        return rehearse_cpu(args)
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus != world and rank == 0 and distributed:
+        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # Rehearsal knobs for a 1-GPU box (never set by the driver): every rank on cuda:0 and gloo instead of RCCL,
+    # which exercises the whole multi-process path (broadcast, bucketed all-reduce on the side stream, barriers).
+    one_dev = os.environ.get("UNETPP_BENCH_SINGLE_DEVICE") == "1"
+    backend = os.environ.get("UNETPP_BENCH_BACKEND", "nccl")
+    dev_index = 0 if one_dev else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if distributed:
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if distributed:
+        dist.barrier()
+
+    ctx = {"torch": torch, "dist": dist, "dev": dev, "world": world, "rank": rank, "distributed": distributed}
+    res = measure(args, ctx)
+    # BASELINE configs[3] and configs[4] (bf16 storage) in the same run, attached to the same line: every rank takes part
+    # (they are data-parallel steps like the headline), a failure there must not cost the headline line
+    others = None
+    if not args.no_other_configs and is_headline(args):
+        others = []
+        for name, over in OTHER_CONFIGS:
+            o = argparse.Namespace(**dict(vars(args), **over))
+            o.steps, o.warmup, o.prewarm = max(20, args.other_steps), 10, 15
+            try:
+                r = measure(o, ctx)
+                entry_ = None if r is None else other_entry(name, o, r, world)
+            except Exception as exc:
+                if distributed:
+                    raise  # ranks would fall out of step: better no line than a hung job
+                entry_ = {"config": name, "error": "%s: %s" % (type(exc).__name__, exc)}
+            if entry_ is not None:
+                others.append(entry_)
+    if rank != 0:
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    value, ms_per_step, fwd_ms_per_img = res["value"], res["ms_per_step"], res["fwd_ms_per_img"]
+    roofline, roofline_x00, kernels = res["roofline"], res["roofline_x00"], res["kernels"]
+    dp_info, replicas_identical, n_cls = res["dp"] or {}, res["replicas_identical"], res["n_cls"]
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, n_cls)
@@ -468,24 +557,21 @@ def main():
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
-        "config": {"workload": "UNet_Nested(in=%d,n_classes=%d,base=%d,depth=%d) %dx%d train step, batch %d/GPU, "
-                               "FocalLoss_BCE_2d on %d heads, Adam, dropout p=0.4 active, %s"
-                               % (args.in_channels, n_cls, int(32 / args.feature_scale), args.depth, args.size, args.size,
-                                  args.batch, args.depth - 1,
-                                  "fp32" if args.dtype == "f32" else "bf16 activation storage / fp32 accumulation and parameters"),
+        "config": {"workload": workload_name(args),
                    "global_batch": world * args.batch, "per_gpu_batch": args.batch,
                    "parallelism": "dp%d" % world if distributed else "single",
                    "world_size": dist.get_world_size() if distributed else 1,
                    "backend": dist.get_backend() if distributed else None,
-                   "grad_allreduce_buckets": None if averager is None else len(averager.buckets_last_step),
-                   "grad_bucket_bytes": None if averager is None else averager.bucket_bytes,
-                   "gradient_bytes": None if averager is None else 4 * averager.flat.numel(),
+                   "grad_allreduce_buckets": dp_info.get("grad_allreduce_buckets"),
+                   "grad_bucket_bytes": dp_info.get("grad_bucket_bytes"),
+                   "gradient_bytes": dp_info.get("gradient_bytes"),
                    "replicas_bit_identical": replicas_identical},
         "fwd_ms_per_img": round(fwd_ms_per_img, 4),
         "roofline": roofline,
         "roofline_x00": roofline_x00,
         "kernels": kernels,
         "cpu_baseline": cpu,
+        "other_configs": others,
     }
     if cpu is not None:
         line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
