@@ -205,7 +205,8 @@ int unetpp_bn_eval_coeffs(const float* gamma, const float* beta, const float* ru
                           void* stream);
 /* act = relu?(y*scale + shift) (scale may be NULL = identity);  optional fused nn.MaxPool2d(2)
  * (models/unet.py:219): pooled [N,H/2,W/2,C] and pool_idx (uint8 window index 0..3, first max wins).
- * act may be NULL when only the pooled output is wanted.  Odd H or W: the window grid is floor(H/2) x floor(W/2) as in
+ * act may be NULL when only the pooled output is wanted; pool_idx may be NULL when the winners are not (forward-only
+ * callers; backward needs them).  Odd H or W: the window grid is floor(H/2) x floor(W/2) as in
  * nn.MaxPool2d (the last row / column is in no window; act still covers every pixel). */
 int unetpp_affine_relu_pool(const float* y, const float* scale, const float* shift, int32_t relu,
                             int32_t N, int32_t H, int32_t W, int32_t C,

@@ -501,6 +501,9 @@ def test_maxpool_bwd_bf16(dev, b, h, w, c):
 
 
 # ---------------------------------------------------------------------------------- whole network
+BF16_GRAD_VS_FP32_ORACLE_ROUTED = 0.10   # relative L2 of any parameter gradient (stated bf16 tolerance, see the test below)
+
+
 def _bf16_vs_oracle(dev, ctor, b, h, w, seed, probe=False):
     """One train step (dropout off) of the HIP model with bf16 activation storage against (a) the fp32 CPU oracle and
     (b) the same oracle evaluated with the bf16 path's roundings (oracle/bf16_sim.py, float64), on the same fp32
@@ -543,7 +546,18 @@ def _bf16_vs_oracle(dev, ctor, b, h, w, seed, probe=False):
     sl = loss_cpu(so, target)
     sl.backward()
     gsim = {k: p.grad.double().clone() for k, p in ref.named_parameters()}
-    res = {"out_max": 0.0, "out_mean": 0.0, "sim_out_max": 0.0, "sim_out_mean": 0.0,
+    # (c) the PINNED fp32 oracle itself (float64, no roundings anywhere) whose backward takes the HIP forward's ReLU gates
+    # and pool winners, exactly as the fp32 parity tests do (tests/helpers.install_hip_gates): what is left between the
+    # two gradients is the VALUE error of bf16 storage, not the routing it selects
+    from tests.helpers import install_hip_gates
+    routed = UNetNestedOracle(**ctor)
+    routed.load_state_dict(state)
+    routed = routed.double().train()
+    routed.drop_out.eval()
+    install_hip_gates(routed, m._debug_saved)
+    loss_cpu(routed(x.double()), target.double()).backward()
+    grouted = {k: p.grad.double().clone() for k, p in routed.named_parameters()}
+    res = {"routed_grad_l2": {}, "out_max": 0.0, "out_mean": 0.0, "sim_out_max": 0.0, "sim_out_mean": 0.0,
            "loss_rel": abs(float(loss.detach()) - float(rl.detach())) / abs(float(rl.detach())),
            "sim_loss_rel": abs(float(loss.detach()) - float(sl.detach())) / abs(float(sl.detach())),
            "grad_l2": {}, "sim_grad_l2": {}, "cos": {}}
@@ -560,6 +574,7 @@ def _bf16_vs_oracle(dev, ctor, b, h, w, seed, probe=False):
         gd = p.grad.double().cpu().flatten()
         res["grad_l2"][k] = float((gd - g32[k].flatten()).norm() / g32[k].norm())
         res["sim_grad_l2"][k] = float((gd - gsim[k].flatten()).norm() / gsim[k].norm())
+        res["routed_grad_l2"][k] = float((gd - grouted[k].flatten()).norm() / grouted[k].norm())
         res["cos"][k] = float(torch.dot(gd, gsim[k].flatten()) / (gd.norm() * gsim[k].norm()))
     res["flips"] = flips
     res["bn_rel"] = max([float((bh.cpu() - bufs32[k]).abs().max() / bufs32[k].abs().max())
@@ -599,10 +614,11 @@ def test_bf16_train_step_vs_oracles(dev, ctor, b, h, w):
     res = _bf16_vs_oracle(dev, ctor, b, h, w, 51)
     worst = max(res["sim_grad_l2"].items(), key=lambda kv: kv[1])
     worst32 = max(res["grad_l2"].items(), key=lambda kv: kv[1])
+    worst_routed = max(res["routed_grad_l2"].items(), key=lambda kv: kv[1])
     line = {"case": str(sorted(ctor.items())), "out_max": res["out_max"], "out_mean": res["out_mean"], "loss_rel": res["loss_rel"],
             "sim_out_max": res["sim_out_max"], "sim_out_mean": res["sim_out_mean"], "sim_loss_rel": res["sim_loss_rel"],
             "bn_rel": res["bn_rel"], "routing_differences": res["flips"], "worst_grad_l2_vs_bf16_sim": worst, "min_cos_vs_bf16_sim": min(res["cos"].values()),
-            "worst_grad_l2_vs_fp32_oracle": worst32}
+            "worst_grad_l2_vs_fp32_oracle": worst32, "worst_grad_l2_vs_fp32_oracle_with_hip_routing": worst_routed}
     print("bf16 vs oracles:", json.dumps(line))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out):
@@ -612,6 +628,12 @@ def test_bf16_train_step_vs_oracles(dev, ctor, b, h, w):
     assert res["loss_rel"] <= 2e-3, line
     assert res["bn_rel"] <= 1e-2, line
     assert worst[1] <= 0.06 and min(res["cos"].values()) >= 0.998, line
+    # every parameter gradient against the PINNED fp32 oracle, once its backward takes the routing (ReLU gates, pool
+    # winners) of the bf16 forward.  Without the routing the distance is 0.3-0.45 on the deep encoder, and it is the
+    # routing alone: the float64 oracle with nothing but the bf16 forward's gates sits at the same 0.33, rounding ONLY the
+    # weights to bf16 gives 0.22, and keeping the encoder's pre-BatchNorm outputs -- or the whole encoder -- in fp32
+    # leaves 0.27 / 0.22 (tests/bf16_gap_experiment.py, CPU, no HIP code)
+    assert worst_routed[1] <= BF16_GRAD_VS_FP32_ORACLE_ROUTED, line
 
 
 def test_bf16_training_tracks_fp32(dev):

@@ -6,10 +6,12 @@ import torch
 from unet_nested4tiny_objects_keypoints_amd import UNet_Nested, FocalLoss_BCE_2d, train_step
 B = int(os.environ.get("B", "32")); S = int(os.environ.get("S", "256"))
 torch.manual_seed(0)
-m = UNet_Nested(1, 4, feature_scale=1).cuda().train()
+FS = float(os.environ.get("FS", "1")); FS = int(FS) if FS.is_integer() else FS
+CIN, NCLS, DEPTH = int(os.environ.get("CIN", "1")), int(os.environ.get("NCLS", "4")), int(os.environ.get("DEPTH", "4"))
+m = UNet_Nested(CIN, NCLS, feature_scale=FS, depth=DEPTH).cuda().train()
 if os.environ.get("DTYPE") == "bf16":
     m.set_activation_dtype(torch.bfloat16)
-x = torch.randn(B, 1, S, S, device="cuda"); t = torch.rand(B, 4, S, S, device="cuda")
+x = torch.randn(B, CIN, S, S, device="cuda"); t = torch.rand(B, NCLS, S, S, device="cuda")
 opt = torch.optim.Adam(m.parameters(), lr=1e-3, fused=True); crit = FocalLoss_BCE_2d(3, size_average=False)
 for _ in range(3): train_step(m, opt, crit, x, t)
 torch.cuda.synchronize()

@@ -106,6 +106,19 @@ __device__ __forceinline__ f32x4 view_load4(const unetpp_view& v, long off, int 
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? UNETPP_OK : UNETPP_ELAUNCH; }
 
+// CUs of the current device, queried once per device (every persistent-grid launcher sizes its grid from it: ~100
+// launches per step); 0 when the runtime cannot tell
+inline int device_cu_count() {
+  static int cached[64] = {};   // (benign race: every writer stores the same value)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
+  if (dev < 64 && cached[dev] > 0) return cached[dev];
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0;
+  if (dev < 64) cached[dev] = cus;
+  return cus;
+}
+
 // remembers the kernel a dispatch chose (unetpp_last_kernel_name); defined in gemm_pix.hip
 void note_kernel(const char* name);
 // a launcher tells unetpp_gemm_fwd how many rows of BatchNorm partial sums its kernel wrote (bn_fused.h: one per

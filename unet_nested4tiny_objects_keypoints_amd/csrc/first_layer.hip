@@ -372,10 +372,8 @@ int launch_small_cin_fwd(const unetpp_gemm_desc* d, hipStream_t st) {
   a.COUT = Y.c_len;
   a.yC = Y.C;
   a.relu = Y.relu;
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-    return UNETPP_ELAUNCH;
+  const int cus = device_cu_count();
+  if (cus <= 0) return UNETPP_ELAUNCH;
   // persistent grid: as many workgroups as are resident at once (<= 128 registers up to three input channels, 156
   // with four: four / three one-wave-per-SIMD workgroups per CU)
   long workers = static_cast<long>(cus) * (X.C == 4 ? 3 : 4);

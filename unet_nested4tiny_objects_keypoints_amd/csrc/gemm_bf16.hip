@@ -619,10 +619,8 @@ int launch_gemm_bf16(const unetpp_gemm_desc* d, hipStream_t st) {
   FastArgs a;
   if (!bf16_gemm_args(d, a) || d->weight_image == nullptr) return UNETPP_EINVAL;
   if (d->stats_partial != nullptr && d->n_out != 1) return UNETPP_EINVAL;
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-    return UNETPP_ELAUNCH;
+  const int cus = device_cu_count();
+  if (cus <= 0) return UNETPP_ELAUNCH;
   // = the kernels' launch bounds (four workgroups per CU for the pointwise GEMMs: 128 VGPRs, spills, 2x slower)
   long workers = ((d->taps == 9 && a.nt_unit == 2 ? 2L : 3L) * cus) & ~7L;
   if (workers < 8) workers = 8;

@@ -608,10 +608,8 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
   const bool all = getenv("UNETPP_BF16_DMA_ALL") != nullptr;
   const bool stats = d->stats_partial != nullptr;
   int form = 4;
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-    return UNETPP_ELAUNCH;
+  const int cus = device_cu_count();
+  if (cus <= 0) return UNETPP_ELAUNCH;
   // (the 8-wave form only when its 512-pixel units still cover the chip: the deepest layers of a small image do not)
   const long units8 = static_cast<long>(d->N) * ((d->H + 15) / 16) * a.tiles_x * ((a.n_tiles % 2 == 0) ? a.n_tiles / 2 : a.n_tiles);
   if (d->taps == 9 && !stats && a.log2tw == 5 && (a.n_chunks > 1 || a.n_tiles > 1) && units8 >= 2L * cus) form = 8;

@@ -394,10 +394,8 @@ int launch_gemm_fast(const unetpp_gemm_desc* d, hipStream_t st) {
   if (!fast_args(d, a, KC) || d->weight_image == nullptr) return UNETPP_EINVAL;
   if (d->stats_partial != nullptr && d->n_out != 1) return UNETPP_EINVAL;
   // persistent grid: at most 3 workgroups per CU (the kernel's LDS/VGPR budget), a multiple of 8
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-    return UNETPP_ELAUNCH;
+  const int cus = device_cu_count();
+  if (cus <= 0) return UNETPP_ELAUNCH;
   const long per_cu = (d->taps == 1 && a.nt_unit == 1) ? 4 : 3;  // = the kernel's launch bounds
   long workers = (per_cu * cus) & ~7L;
   if (workers < 8) workers = 8;

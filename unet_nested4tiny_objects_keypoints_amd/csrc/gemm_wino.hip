@@ -809,10 +809,8 @@ int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
   FastArgs a;
   if (!wino_applies(d) || !fast_args(d, a, WKC, WNC) || d->weight_image == nullptr) return UNETPP_EINVAL;
   if (d->stats_partial != nullptr && d->n_out != 1) return UNETPP_EINVAL;
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-    return UNETPP_ELAUNCH;
+  const int cus = device_cu_count();
+  if (cus <= 0) return UNETPP_ELAUNCH;
   long workers = (2L * cus) & ~7L;  // persistent grid: two workgroups per CU (= the kernel's launch bounds)
 #if defined(UNETPP_WINO_STAMPS) || defined(UNETPP_WINO_EXP)
   if (const char* e = getenv("UNETPP_WINO_ONE_PER_CU"); e != nullptr && e[0] == '1') workers = cus & ~7L;  // waves alone on their SIMD

@@ -1196,7 +1196,7 @@ extern "C" int unetpp_affine_relu_pool(const float* y, const float* scale, const
     }
     return launch_status();
   }
-  if (H < 2 || W < 2 || !pool_idx) return UNETPP_EINVAL;
+  if (H < 2 || W < 2) return UNETPP_EINVAL;  // (pool_idx may be NULL: forward-only callers need no winners)
   if ((H & 1) || (W & 1)) {
     // nn.MaxPool2d(2) floors (the classic UNet on sizes that are not multiples of 16, models/unet.py:40-46): the last
     // odd row / column is in no window, but the activation is wanted for ALL pixels -- apply pass over the whole

@@ -276,6 +276,15 @@ __global__ __launch_bounds__(kThreads) void head_bwd_bf16_kernel(const float* __
   float* red = dl + TP * kHeadMaxCls;  // [4 waves][PCLS * C + PCLS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cg = tid & (CG - 1);
+  const unsigned n_tiles = (pixels + TP - 1) / TP;
+  if (blockIdx.x >= n_tiles) {
+    // The grid and the partial rows are sized from 64-pixel tiles (unetpp_head_bwd_blocks, shared with the fp32 kernel);
+    // below 4096 * TP pixels some blocks own no tile of this kernel: a zero row (the caller sums every row) and out,
+    // before the weight registers, the shuffles and the LDS reduction
+    float* dst = partial + static_cast<long>(blockIdx.x) * (n_cls * C + n_cls);
+    for (int i = tid; i < n_cls * C + n_cls; i += kThreads) dst[i] = 0.f;
+    return;
+  }
   float wq[PCLS][8], wacc[PCLS][8], bacc[PCLS];
 #pragma unroll
   for (int k = 0; k < PCLS; ++k) {
@@ -287,7 +296,6 @@ __global__ __launch_bounds__(kThreads) void head_bwd_bf16_kernel(const float* __
     }
   }
   for (int i = tid; i < TP * kHeadMaxCls; i += kThreads) dl[i] = 0.f;  // classes past n_cls are never written again
-  const unsigned n_tiles = (pixels + TP - 1) / TP;  // (blocks past the tiles write zero rows: the caller sums them all)
   for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const unsigned p0 = tile * TP;
     __syncthreads();
