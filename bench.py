@@ -258,6 +258,16 @@ def rehearse_cpu(args):
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     same = replicas_bit_identical(model, dist)
+    # the all-reduces of a step must tile the flat gradient vector, each ending where a reported group ends (a bucket
+    # never cuts a convolution's gradients in two: the engine reports them together)
+    edges, acc = set(), 0
+    for grp in groups:
+        acc += sum(p.numel() for p in grp)
+        edges.add(acc)
+    spans = list(averager.buckets_last_step)
+    tiled = bool(spans) and spans[0][0] == 0 and spans[-1][1] == averager.flat.numel() and \
+        all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    on_edges = all(e in edges for _, e in spans)
     if rank == 0:
         print(json.dumps({
             "metric": "REHEARSAL of the multi-process protocol (no kernels, CPU, gloo) -- not a measurement",
@@ -265,6 +275,8 @@ def rehearse_cpu(args):
             "ms_per_step": round(1e3 * float(t.item()) / max(1, args.steps), 3), "data": "synthetic gradients",
             "config": {"world_size": world, "backend": dist.get_backend(), "gradient_bytes": 4 * averager.flat.numel(),
                        "bucket_bytes": averager.bucket_bytes, "grad_allreduce_buckets": len(averager.buckets_last_step),
+                       "bucket_bytes_each": [4 * (e - b) for b, e in spans], "buckets_tile_the_gradient": tiled,
+                       "bucket_ends_on_reported_groups": on_edges, "reported_groups": len(groups),
                        "replicas_bit_identical": same}}))
     dist.barrier()
     dist.destroy_process_group()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UNETPP_ABI_VERSION 7
+#define UNETPP_ABI_VERSION 8
 #define UNETPP_MAX_VIEWS 8
 
 #define UNETPP_OK 0
@@ -132,6 +132,16 @@ const char* unetpp_build_arch(void); /* "gfx950" */
  * (profiling labels; equals the rocprofv3 kernel name up to template arguments).  Static string, "" before the
  * first call.  Diagnostic only: it is the one piece of (thread-local) state the library keeps. */
 const char* unetpp_last_kernel_name(void);
+
+/* Data-parallel co-scheduling knob (v8).  Every hot kernel is a persistent launch sized to fill all CUs at 2-3 workgroups
+ * per CU, so a collective kernel (RCCL all-reduce of a gradient bucket on a side stream, trainer/trainer.py:338's
+ * replicas replaced by one process per GPU) only gets waves when a compute kernel ends.  n > 0 makes the persistent
+ * grids leave n CUs' worth of workgroups unlaunched (a caller of unetpp_wgrad sizes n_split itself and should aim at
+ * CUs - n workgroups, as the Python layer does); 0 (default,
+ * or the UNETPP_RESERVED_CUS environment variable read at the first call) = use every CU.  Process-wide, takes effect
+ * at the next launch; results do not depend on it.  Returns the value now in force (n clamped to [0, CUs - 8]);
+ * unetpp_set_reserved_cus(-1) only reads it. */
+int32_t unetpp_set_reserved_cus(int32_t n);
 
 /* ---- multi-view pixel GEMM on MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32) ------ */
 int64_t unetpp_gemm_pixel_blocks(int32_t N, int32_t H, int32_t W);

@@ -158,10 +158,18 @@ def _run_bench(*extra, env=None):
     return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
 
 
+C4_NET = ["--feature-scale", "0.5", "--depth", "5", "--in-channels", "3", "--n-classes", "5"]   # configs[4]: base 64, D5
+
+
 @pytest.mark.parametrize("world,extra,grad_bytes", [
     (4, ["--feature-scale", "1"], 8828976),                                                     # configs[2]'s network
     (3, ["--feature-scale", "4", "--depth", "5", "--in-channels", "3", "--n-classes", "5"], None),  # odd world, depth 5
-])
+    # the REAL world size of configs[2] and of the data-parallel half of configs[4] (trainer/trainer.py:281-287,336-340
+    # runs whatever torch.cuda.device_count() gives: 8 on the target node), the real networks, the real gradient volumes:
+    # 8.8 MB in ~0.74 MB buckets and 145 MB (36 167 124 parameters) in ~12 MiB buckets
+    (8, ["--feature-scale", "1"], 8828976),
+    (8, C4_NET, 36167124 * 4),
+], ids=["world4-configs2", "world3-depth5", "world8-configs2", "world8-configs4"])
 def test_bench_self_spawn_and_replica_check(world, extra, grad_bytes):
     code, line, err = _run_bench("--gpus", str(world), *extra)
     assert code == 0, err
@@ -169,9 +177,50 @@ def test_bench_self_spawn_and_replica_check(world, extra, grad_bytes):
     assert cfg["world_size"] == world and cfg["backend"] == "gloo"
     assert cfg["replicas_bit_identical"] is True
     assert line["value"] is None and "REHEARSAL" in line["metric"]      # cannot be mistaken for a measurement
+    assert cfg["buckets_tile_the_gradient"] is True and cfg["bucket_ends_on_reported_groups"] is True, cfg
+    assert sum(cfg["bucket_bytes_each"]) == cfg["gradient_bytes"]
     if grad_bytes is not None:
         assert cfg["gradient_bytes"] == grad_bytes                        # 2 207 244 parameters x 4 B
         assert 6 <= cfg["grad_allreduce_buckets"] <= 16, cfg              # auto bucket size: about a dozen per step
+        assert cfg["bucket_bytes"] == dp.auto_bucket_bytes(grad_bytes)
+        # every bucket but the tail reaches the target size, and none is more than one reported group above it
+        assert all(b >= cfg["bucket_bytes"] for b in cfg["bucket_bytes_each"][:-1]), cfg
+
+
+def test_depth5_bucket_boundaries_follow_the_ready_groups():
+    """configs[4]'s network (depth 5, base 64: 145 MB of gradients) in a world of one: the flat vector is laid out in
+    dp.ready_groups() order, the engine's reports advance a contiguous frontier, and every all-reduce starts where the
+    last one ended and ends on a group boundary -- 12 MiB buckets, about a dozen of them."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        model = UNet_Nested(in_channels=3, n_classes=5, feature_scale=0.5, depth=5)
+        avg = dp.make_data_parallel(model, always_reduce=True)
+        groups = dp.ready_groups(model)
+        assert len(groups) == 1 + 3 * 10 + 2 * 5          # heads; conv2, conv1, up per decoder node; conv2, conv1 per encoder node
+        assert avg.flat.numel() == 36167124 and avg.bucket_bytes == dp.auto_bucket_bytes(4 * 36167124)
+        off = 0
+        for grp in groups:                                # flat layout = report order, group by group
+            for p in grp:
+                assert avg.offset[id(p)] == off
+                off += p.numel()
+        for grp in groups:
+            model._grad_sink([(p, model._grad_alloc(p).fill_(1.0)) for p in grp])
+        assert model._grad_done() is True
+        spans = avg.buckets_last_step
+        edges, acc = set(), 0
+        for grp in groups:
+            acc += sum(p.numel() for p in grp)
+            edges.add(acc)
+        assert spans[0][0] == 0 and spans[-1][1] == avg.flat.numel()
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert all(e in edges for _, e in spans)
+        assert 6 <= len(spans) <= 16, spans
+        assert all(e - b >= avg.bucket_elems for b, e in spans[:-1])
+        assert all(float(p.grad.min()) == 1.0 and float(p.grad.max()) == 1.0 for p in model.parameters())
+    finally:
+        dist.destroy_process_group()
 
 
 def test_bench_self_spawn_reports_a_failing_rank():

@@ -175,3 +175,38 @@ def test_rccl_backend_collective_path_world_of_one(tmp_path):
         assert torch.equal(r["plain_zeroed"][k], r["rccl_zeroed"][k]), k
     k = "final_3.weight"
     assert float((r["rccl_acc"][k] - 3 * r["rccl_zeroed"][k]).abs().max()) < 1e-5 * float(r["rccl_acc"][k].abs().max())
+
+
+def test_reserved_cus_knob_changes_grids_not_results():
+    """unetpp_set_reserved_cus (ABI v8): with 64 of the CUs left to a concurrent collective the
+    persistent grids and weight-gradient splits shrink; a train step gives the same outputs and gradients up to the
+    partition of fp32 sums (BatchNorm partial rows per workgroup, weight-gradient slabs)."""
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, UNet_Nested, _lib
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    assert lib.unetpp_set_reserved_cus(-1) == 0
+    torch.manual_seed(5)
+    m = UNet_Nested(in_channels=1, n_classes=4, feature_scale=2).to(dev).train()
+    m.drop_out.eval()
+    x, t = torch.randn(4, 1, 128, 128, device=dev), torch.rand(4, 4, 128, 128, device=dev)
+    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+
+    def run():
+        m.zero_grad()
+        outs = m(x)
+        (sum(crit(o, t) for o in outs) / len(outs)).backward()
+        return [o.detach().clone() for o in outs], {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    o0, g0 = run()
+    try:
+        assert lib.unetpp_set_reserved_cus(64) == 64
+        assert lib.unetpp_set_reserved_cus(100000) >= 64      # clamped to CUs - 8
+        assert lib.unetpp_set_reserved_cus(64) == 64
+        o1, g1 = run()
+    finally:
+        assert lib.unetpp_set_reserved_cus(0) == 0
+    for a, b in zip(o0, o1):
+        assert float((a - b).abs().max()) <= 2e-6
+    for k in g0:
+        scale = float(g0[k].abs().max())
+        assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * scale + 1e-12, k

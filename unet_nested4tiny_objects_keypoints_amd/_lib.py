@@ -18,7 +18,7 @@ INCLUDE = os.path.join(_REPO, "include")
 SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_wino.hip", "gemm_bf16.hip", "gemm_bf16_dma.hip", "wgrad_bf16.hip", "pointwise_bf16.hip", "keypoints.hip", "weight_image.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "wgrad_wino.hip", "first_layer.hip", "pointwise.hip", "caller.hip")
 HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h", "lds_asm.h", "bf16_common.h", "dropout.h", "bn_fused.h")
 MAX_VIEWS = 8
-ABI_VERSION = 7
+ABI_VERSION = 8
 # packed-f32 VALU (SLP-vectorised add pairs) costs issue slots beside MFMAs: keep the Winograd transforms scalar
 EXTRA_FLAGS = {"gemm_wino.hip": ("-fno-slp-vectorize",), "wgrad_wino.hip": ("-fno-slp-vectorize",)}
 GEMM_DIRECT = 1  # unetpp_gemm_desc.flags: direct summation only (no Winograd)
@@ -96,6 +96,7 @@ SIGNATURES = {
     "unetpp_abi_version": (C.c_int, []),
     "unetpp_build_arch": (C.c_char_p, []),
     "unetpp_last_kernel_name": (C.c_char_p, []),
+    "unetpp_set_reserved_cus": (_I32, [_I32]),
     "unetpp_gemm_pixel_blocks": (_I64, [_I32, _I32, _I32]),
     "unetpp_gemm_stats_rows": (_I64, [_I32, _I32, _I32]),
     "unetpp_gemm_fwd": (C.c_int, [C.POINTER(GemmDesc), _P]),

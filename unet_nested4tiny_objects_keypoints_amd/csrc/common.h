@@ -108,7 +108,8 @@ inline int launch_status() { return hipGetLastError() == hipSuccess ? UNETPP_OK 
 
 // CUs of the current device, queried once per device (every persistent-grid launcher sizes its grid from it: ~100
 // launches per step); 0 when the runtime cannot tell
-inline int device_cu_count() {
+int reserved_cus();  // unetpp_set_reserved_cus (gemm_pix.hip): CUs the persistent grids leave to a concurrent collective
+inline int physical_cu_count() {
   static int cached[64] = {};   // (benign race: every writer stores the same value)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
@@ -117,6 +118,12 @@ inline int device_cu_count() {
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0;
   if (dev < 64) cached[dev] = cus;
   return cus;
+}
+inline int device_cu_count() {  // what a persistent grid may fill
+  const int cus = physical_cu_count();
+  if (cus <= 0) return 0;
+  const int left = cus - reserved_cus();
+  return left < 8 ? (cus < 8 ? cus : 8) : left;
 }
 
 // remembers the kernel a dispatch chose (unetpp_last_kernel_name); defined in gemm_pix.hip

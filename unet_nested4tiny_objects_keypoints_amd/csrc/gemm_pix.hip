@@ -16,6 +16,9 @@
 // D reg r of lane l = row (r&3)+8*(r>>2)+4*(l>>5), col l&31.  Rows are pixels, columns are
 // output channels, so one stored register is 32 consecutive floats of one pixel (a full 128-B line).
 #include "bn_fused.h"
+#include <atomic>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace unetpp {
@@ -189,6 +192,17 @@ namespace {
 thread_local const char* g_last_kernel = "";
 }
 thread_local long g_bn_rows = 0;
+std::atomic<int> g_reserved_cus{-1};  // -1: not set yet (the environment decides at the first read)
+int reserved_cus() {
+  int v = g_reserved_cus.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("UNETPP_RESERVED_CUS");
+    v = (e != nullptr) ? atoi(e) : 0;
+    if (v < 0) v = 0;
+    g_reserved_cus.store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
 void note_kernel(const char* name) { g_last_kernel = name; }
 void note_bn_rows(long rows) { g_bn_rows = rows; }
 }  // namespace unetpp
@@ -196,6 +210,15 @@ void note_bn_rows(long rows) { g_bn_rows = rows; }
 using namespace unetpp;
 
 extern "C" const char* unetpp_last_kernel_name(void) { return g_last_kernel; }
+
+extern "C" int32_t unetpp_set_reserved_cus(int32_t n) {
+  if (n >= 0) {
+    const int cus = physical_cu_count();
+    const int cap = cus > 8 ? cus - 8 : 0;
+    g_reserved_cus.store(n > cap ? cap : n, std::memory_order_relaxed);
+  }
+  return reserved_cus();
+}
 
 extern "C" int64_t unetpp_gemm_pixel_blocks(int32_t N, int32_t H, int32_t W) {
   if (N <= 0 || H <= 0 || W <= 0) return 0;

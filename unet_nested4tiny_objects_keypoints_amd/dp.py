@@ -31,6 +31,8 @@ never fire on this path (delivery does not go through AccumulateGrad), so regist
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -235,7 +237,17 @@ def broadcast_parameters(model, src: int = 0, process_group=None) -> None:
 
 
 def make_data_parallel(model, process_group=None, bucket_bytes: Optional[int] = None,
-                       always_reduce: bool = False) -> GradientAverager:
-    """Broadcast rank 0's parameters/buffers, then hook the gradient averager into the model's backward."""
+                       always_reduce: bool = False, reserved_cus: Optional[int] = None) -> GradientAverager:
+    """Broadcast rank 0's parameters/buffers, then hook the gradient averager into the model's backward.
+
+    reserved_cus (or the UNETPP_DP_RESERVED_CUS environment variable): CUs the persistent compute grids leave free for
+    the RCCL kernels of the side stream (include/unetpp_hip.h, unetpp_set_reserved_cus).  Default: none -- the knob
+    exists because the overlap of a bucket's all-reduce with the remaining backward is per kernel boundary otherwise
+    (DESIGN.md section 6); it has not been measured on a multi-GPU node, so it is not switched on blindly."""
+    if reserved_cus is None and os.environ.get("UNETPP_DP_RESERVED_CUS"):
+        reserved_cus = int(os.environ["UNETPP_DP_RESERVED_CUS"])
+    if reserved_cus is not None and next(model.parameters()).is_cuda:
+        from . import _lib
+        _lib.lib().unetpp_set_reserved_cus(int(reserved_cus))
     broadcast_parameters(model, 0, process_group)
     return GradientAverager(ready_order(model), process_group, bucket_bytes, always_reduce).attach(model)
