@@ -255,15 +255,17 @@ int unetpp_bn_bwd_apply_pool(const float* d_act, const float* y, const float* sc
 /* ---- deep-supervision head: sigmoid(Conv1x1(Dropout(x))) (models/unet.py:242-244,254,283-286) ---- */
 /* x NHWC [P, C]; weight [n_cls, C]; out NCHW [N, n_cls, H, W].  Dropout: keep mask regenerated from
  * (seed, element index) with keep probability 1-p_drop, or read from `mask` (uint8 NHWC) when not NULL;
- * p_drop = 0 disables it. */
+ * p_drop = 0 disables it.  seed_dev (v8, may be NULL): one uint64 in device memory that is ADDED to `seed` when the
+ * kernel runs -- a launch captured in a HIP graph bakes `seed` in, so a replayed training step keeps the varying part
+ * of its seed there (forward and backward of a step must see the same value). */
 int unetpp_head_fwd(const float* x, const float* weight, const float* bias, int32_t N, int32_t H, int32_t W,
-                    int32_t C, int32_t n_cls, float p_drop, uint64_t seed, const uint8_t* mask,
+                    int32_t C, int32_t n_cls, float p_drop, uint64_t seed, const uint8_t* mask, const uint64_t* seed_dev,
                     float* out_nchw, void* stream);
 int64_t unetpp_head_bwd_blocks(int64_t pixels);
 /* d_out, out: NCHW.  dx (NHWC) is written (accumulate = 0) or added to; partial [blocks][n_cls*C + n_cls]. */
 int unetpp_head_bwd(const float* d_out_nchw, const float* out_nchw, const float* x, const float* weight,
                     int32_t N, int32_t H, int32_t W, int32_t C, int32_t n_cls, float p_drop, uint64_t seed,
-                    const uint8_t* mask, float* dx, int32_t accumulate, int32_t gate_x, float* partial,
+                    const uint8_t* mask, const uint64_t* seed_dev, float* dx, int32_t accumulate, int32_t gate_x, float* partial,
                     void* stream); /* gate_x: after the (optional) accumulate, dx *= (x > 0) -- the ReLU mask of x */
 /* out[i] = sum_b partial[b][i], i < len (used for head dW/db) */
 int unetpp_sum_partials(const float* partial, int64_t n_blocks, int64_t len, float* out, void* stream);
@@ -310,12 +312,12 @@ int unetpp_bn_bwd_apply_bf16(const void* d_act, const void* y, const float* scal
                              const float* dbeta, const void* d_pooled, const uint8_t* pool_idx,
                              int32_t N, int32_t H, int32_t W, int32_t C, void* dy, void* stream);
 int unetpp_head_fwd_bf16(const void* x, const float* weight, const float* bias, int32_t N, int32_t H, int32_t W,
-                         int32_t C, int32_t n_cls, float p_drop, uint64_t seed, const uint8_t* mask,
+                         int32_t C, int32_t n_cls, float p_drop, uint64_t seed, const uint8_t* mask, const uint64_t* seed_dev,
                          float* out_nchw, void* stream);
 /* partial: unetpp_head_bwd_blocks(N*H*W) rows of [n_cls*C + n_cls], finished by unetpp_sum_partials */
 int unetpp_head_bwd_bf16(const float* d_out_nchw, const float* out_nchw, const void* x, const float* weight,
                          int32_t N, int32_t H, int32_t W, int32_t C, int32_t n_cls, float p_drop, uint64_t seed,
-                         const uint8_t* mask, void* dx, int32_t accumulate, int32_t gate_x, float* partial,
+                         const uint8_t* mask, const uint64_t* seed_dev, void* dx, int32_t accumulate, int32_t gate_x, float* partial,
                          void* stream);
 
 /* is_batchnorm=False in bf16: d_act += d_pooled at the window argmax (unetpp_affine_relu_pool_bf16's pool_idx), then,

@@ -95,7 +95,7 @@ def test_argument_validation_without_gpu(built_lib):
     w = built_lib.WgradDesc()
     assert lib.unetpp_wgrad(ctypes.byref(w), None) == -1
     assert lib.unetpp_pack_weight(None, None, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, None) == -1
-    assert lib.unetpp_head_fwd(None, None, None, 1, 8, 8, 32, 4, 0.4, 0, None, None, None) == -1
+    assert lib.unetpp_head_fwd(None, None, None, 1, 8, 8, 32, 4, 0.4, 0, None, None, None, None) == -1
 
 
 def test_no_cpu_fallback():

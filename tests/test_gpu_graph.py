@@ -1,0 +1,142 @@
+"""The whole training step replayed from a HIP graph (graph.GraphedTrainStep) against the eager step (step.train_step,
+the reference's loop body trainer/trainer.py:114-136): same kernels, same order, same arguments -- bit-identical
+parameters, losses and BatchNorm buffers step after step; dropout varies from replay to replay through the device-side
+seed word (unetpp_head_fwd / unetpp_head_bwd ``seed_dev``, ABI v8)."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _make(dev, ctor, bf16, p_drop):
+    from unet_nested4tiny_objects_keypoints_amd import UNet_Nested
+    torch.manual_seed(81)
+    m = UNet_Nested(**ctor).to(dev).train()
+    if bf16:
+        m.set_activation_dtype(BF)
+    m.drop_out.p = p_drop
+    return m
+
+
+def _opt(kind, params):
+    if kind == "sgd":
+        return torch.optim.SGD(params, lr=2e-3, momentum=0.9)
+    if kind == "adam-capturable":
+        return torch.optim.Adam(params, lr=1e-3, fused=True, capturable=True)
+    return torch.optim.Adam(params, lr=1e-3, fused=True)
+
+
+@pytest.mark.parametrize("ctor,bf16,opt_kind,capture_opt", [
+    (dict(in_channels=1, n_classes=4, feature_scale=4), False, "sgd", True),
+    (dict(in_channels=1, n_classes=4, feature_scale=4), False, "adam-capturable", True),
+    (dict(in_channels=1, n_classes=4, feature_scale=4), False, "adam", False),                 # eager optimizer on static grads
+    (dict(in_channels=3, n_classes=5, feature_scale=4, depth=5), True, "adam-capturable", True),  # configs[4] topology, bf16
+    (dict(in_channels=1, n_classes=4, feature_scale=2, is_deconv=False), True, "sgd", False),
+], ids=["f32-sgd", "f32-adam-captured", "f32-adam-eager", "bf16-d5-adam-captured", "bf16-bilinear-sgd-eager"])
+def test_graphed_step_is_bit_identical_to_eager(dev, ctor, bf16, opt_kind, capture_opt):
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, GraphedTrainStep, train_step
+    a = _make(dev, ctor, bf16, 0.0)                      # dropout off: the two paths draw different seeds by design
+    b = copy.deepcopy(a)
+    before = {k: v.clone() for k, v in a.state_dict().items()}
+    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+    oa, ob = _opt(opt_kind, a.parameters()), _opt(opt_kind, b.parameters())
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(2, ctor["in_channels"], 64, 64, generator=g).to(dev) for _ in range(4)]
+    ts = [torch.rand(2, ctor["n_classes"], 64, 64, generator=g).to(dev) for _ in range(4)]
+    step = GraphedTrainStep(a, oa, crit, xs[0], ts[0], capture_optimizer=capture_opt)
+    # the warm-up steps left no trace: parameters and buffers are the initial ones
+    for k, v in a.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    for x, t in zip(xs, ts):
+        outs_g, loss_g = step(x, t)
+        outs_e, loss_e = train_step(b, ob, crit, x, t)
+        assert float(loss_g) == float(loss_e)
+        for p, q in zip(outs_g, outs_e):
+            assert torch.equal(p, q)
+        for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+            assert torch.equal(p, q), k
+            assert p.grad is not None and torch.equal(p.grad, q.grad), k
+        for (k, p), (_, q) in zip(a.named_buffers(), b.named_buffers()):
+            assert torch.equal(p, q), k
+
+
+def test_graphed_step_dropout_varies_and_trains(dev):
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, GraphedTrainStep
+    ctor = dict(in_channels=1, n_classes=4, feature_scale=4)
+    m = _make(dev, ctor, False, 0.4)
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)         # lr 0: only the dropout mask differs between replays
+    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+    x, t = torch.randn(2, 1, 64, 64, device=dev), torch.rand(2, 4, 64, 64, device=dev)
+    step = GraphedTrainStep(m, opt, crit, x, t, capture_optimizer=True)
+    o1 = [o.clone() for o in step(x, t)[0]]
+    g1 = m.final_1.weight.grad.clone()
+    o2 = [o.clone() for o in step(x, t)[0]]
+    assert not torch.equal(o1[0], o2[0]) and not torch.equal(g1, m.final_1.weight.grad)
+    assert getattr(m, "_dropout_seed_dev", None) is None     # eager passes draw their own seeds again
+    m.eval()
+    with torch.no_grad():
+        e1, e2 = m(x), m(x)
+    assert all(torch.equal(p, q) for p, q in zip(e1, e2))
+    m.train()
+    # and it trains: a real learning rate, forty replays
+    m2 = _make(dev, ctor, False, 0.4)
+    opt2 = torch.optim.Adam(m2.parameters(), lr=2e-3, fused=True, capturable=True)
+    step2 = GraphedTrainStep(m2, opt2, crit, x, t, capture_optimizer=True)
+    losses = [float(step2(x, t)[1]) for _ in range(40)]
+    assert losses[-1] < 0.8 * losses[0], losses
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+def test_seed_dev_adds_to_the_seed(dev, bf16):
+    """unetpp_head_fwd / unetpp_head_bwd: seed + *seed_dev, bit for bit the launch with the sum passed by value -- in the
+    forward AND in the backward kernel (a captured step regenerates the mask in backward from the same word)."""
+    from unet_nested4tiny_objects_keypoints_amd import ops
+    torch.manual_seed(3)
+    b, h, w, c, ncls = 2, 16, 24, 32, 4
+    x = torch.randn(b, h, w, c, device=dev).relu()
+    if bf16:
+        x = x.to(BF)
+    wt, bias = torch.randn(ncls, c, device=dev) * 0.2, torch.randn(ncls, device=dev) * 0.1
+    word = torch.tensor([987654321], dtype=torch.int64, device=dev)
+    out_a, out_b, out_c = (torch.empty(b, ncls, h, w, device=dev) for _ in range(3))
+    ops.head_fwd(x, wt, bias, 0.4, 1000 + 987654321, None, out_a)
+    ops.head_fwd(x, wt, bias, 0.4, 1000, None, out_b, seed_dev=word)
+    ops.head_fwd(x, wt, bias, 0.4, 1000, None, out_c)
+    assert torch.equal(out_a, out_b) and not torch.equal(out_a, out_c)
+    d_out = torch.randn(b, ncls, h, w, device=dev)
+    dx_a, dx_b = torch.empty_like(x), torch.empty_like(x)
+    dw_a, db_a = ops.head_bwd(d_out, out_a, x, wt, 0.4, 1000 + 987654321, None, dx_a, False)
+    dw_b, db_b = ops.head_bwd(d_out, out_a, x, wt, 0.4, 1000, None, dx_b, False, seed_dev=word)
+    assert torch.equal(dx_a, dx_b) and torch.equal(dw_a, dw_b) and torch.equal(db_a, db_b)
+
+
+def test_graphed_step_refuses_what_it_cannot_capture(dev):
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, GraphedTrainStep
+    ctor = dict(in_channels=1, n_classes=4, feature_scale=8)
+    m = _make(dev, ctor, False, 0.0)
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+    x, t = torch.randn(1, 1, 32, 32, device=dev), torch.rand(1, 4, 32, 32, device=dev)
+    with pytest.raises(RuntimeError, match="GPU"):
+        GraphedTrainStep(m, opt, crit, x.cpu(), t.cpu())
+    m.eval()
+    with pytest.raises(RuntimeError, match="TRAINING"):
+        GraphedTrainStep(m, opt, crit, x, t)
+    m.train()
+    step = GraphedTrainStep(m, opt, crit, x, t)
+    with pytest.raises(ValueError, match="captured for inputs"):
+        step(torch.randn(2, 1, 32, 32, device=dev), t)
+    m.eval()
+    with pytest.raises(RuntimeError, match="eval"):
+        step(x, t)

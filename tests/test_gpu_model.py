@@ -216,6 +216,43 @@ def test_train_step_vs_oracle(dev, case):
             assert rel_err(bh.cpu(), br) < TOL, k
 
 
+def test_benchmarked_batch32_forward_vs_float64_oracle(dev):
+    """The BENCHMARKED configuration end to end, once: BASELINE configs[1] (base 32, 256 x 256) at batch 32 -- 2.1e6
+    values per BatchNorm channel at level 0, 8192 patches per launch, the persistent kernels' per-workgroup statistics
+    rows over the full batch.  Train-mode forward (dropout off), loss and the BatchNorm running statistics of all eight
+    encoder layers against the pinned oracle evaluated in float64 (forward only: its backward at this size takes
+    minutes; gradients are covered at batch 4 above and, for the X_0,0 block, at batch 32 in test_gpu_x00_block.py).
+    models/unet.py:255-300."""
+    from oracle.step_oracle import focal_bce_2d_oracle
+    from oracle.unet_nested_oracle import UNetNestedOracle
+    ctor, b, h, w = dict(in_channels=1, n_classes=4, feature_scale=1), 32, 256, 256
+    torch.manual_seed(13)
+    ref = UNetNestedOracle(**ctor).train()
+    ref.drop_out.eval()
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    m = _hip_model(ctor, state, dev).train()
+    m.drop_out.eval()
+    x, target = torch.randn(b, 1, h, w), torch.rand(b, 4, h, w)
+    with torch.no_grad():
+        outs = m(x.to(dev))
+        loss = float(_loss(outs, target.to(dev)))
+        torch.cuda.synchronize()
+        ref = ref.double()
+        ro = ref(x.double())
+        rl = float(sum(focal_bce_2d_oracle(o, target.double()) for o in ro) / len(ro))
+    assert len(outs) == len(ro) == 3
+    for o, r in zip(outs, ro):
+        assert tuple(o.shape) == (b, 4, h, w)
+        assert rel_err(o.cpu(), r) < TOL
+    assert abs(loss - rl) <= 1e-5 * abs(rl), (loss, rl)
+    n_stats = 0
+    for (k, bh), (_, br) in zip(m.named_buffers(), ref.named_buffers()):
+        if bh.dtype.is_floating_point:
+            assert rel_err(bh.cpu(), br) < 1e-5, k
+            n_stats += 1
+    assert n_stats == 16
+
+
 def test_dropout_path_vs_oracle_with_shared_mask(dev):
     """Train-mode dropout (models/unet.py:254,283-286) with an explicit keep mask on both sides."""
     from oracle.step_oracle import focal_bce_2d_oracle

@@ -42,5 +42,12 @@ for f in dbs:
                 gaps.append(max(0, s - prev_end))
                 prev_end = max(prev_end, e)
         gaps.sort()
+        last = steps[take[-1]]
+        prev_end, big = steps[take[-1] - 1][-1][2], []
+        for k, (name, s0, e0) in enumerate(last):
+            big.append((s0 - prev_end, k, last[k - 1][0][:60] if k else "(previous step)", name[:60]))
+            prev_end = max(prev_end, e0)
+        for g, k, before, after in sorted(big, reverse=True)[:6]:
+            print("      gap %7.1f us before launch %3d: %s -> %s" % (g / 1e3, k, before, after))
         print("  %4d launches/step x %3d steps: span %.3f ms, kernels %.3f ms, idle %.3f ms; gap median %.1f us, p90 %.1f us, max %.1f us"
               % (n, len(idx), span, busy, span - busy, gaps[len(gaps) // 2] / 1e3, gaps[int(len(gaps) * 0.9)] / 1e3, gaps[-1] / 1e3))

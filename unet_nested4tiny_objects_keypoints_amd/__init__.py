@@ -16,6 +16,7 @@ from .step import train_step  # noqa: F401
 from .targets import create_heatmap  # noqa: F401
 from .keypoints import Heatmap  # noqa: F401
 from .serving import GraphedForward  # noqa: F401
+from .graph import GraphedTrainStep  # noqa: F401
 
 __all__ = ["UNet_Nested", "UNet", "count_param", "FocalLoss_BCE_2d", "train_step", "create_heatmap", "Heatmap",
-           "GraphedForward"]
+           "GraphedForward", "GraphedTrainStep"]

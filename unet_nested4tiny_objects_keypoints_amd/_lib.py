@@ -121,9 +121,9 @@ SIGNATURES = {
     "unetpp_bn_bwd_pool_ok": (C.c_int, [_I32, _I32, _I32, _I32]),
     "unetpp_bn_bwd_reduce_pool": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "unetpp_bn_bwd_apply_pool": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
-    "unetpp_head_fwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _P]),
+    "unetpp_head_fwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _P, _P]),
     "unetpp_head_bwd_blocks": (_I64, [_I64]),
-    "unetpp_head_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _I32, _I32, _P, _P]),
+    "unetpp_head_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _P, _I32, _I32, _P, _P]),
     "unetpp_sum_partials": (C.c_int, [_P, _I64, _I64, _P, _P]),
     "unetpp_focal_bce_blocks": (_I64, [_I64]),
     "unetpp_focal_bce": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _P]),
@@ -138,7 +138,7 @@ SIGNATURES = {
     "unetpp_bn_bwd_blocks_bf16": (_I64, [_I64, _I32]),
     "unetpp_bn_bwd_reduce_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "unetpp_bn_bwd_apply_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P]),
-    "unetpp_head_fwd_bf16": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _P]),
+    "unetpp_head_fwd_bf16": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _P, _P]),
     "unetpp_first_layer_dgrad_bf16": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "unetpp_maxpool_bwd_bf16": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "unetpp_bilinear2x_fwd_bf16": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P]),
@@ -148,7 +148,7 @@ SIGNATURES = {
     "unetpp_heatmap_pattern": (C.c_int, [_P, _I32, _I32, _P, _P, _I32, _I32, _I32, _F, _P, _P, _P]),
     "unetpp_keypoints_workspace_bytes": (_I64, [_I32, _I32, _I32, _I32]),
     "unetpp_keypoints_extract": (C.c_int, [_I32, _P, _I32, _I32, _I32, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P]),
-    "unetpp_head_bwd_bf16": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _I32, _I32, _P, _P]),
+    "unetpp_head_bwd_bf16": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _U64, _P, _P, _P, _I32, _I32, _P, _P]),
 }
 
 _LIB = None

@@ -482,8 +482,9 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_pool_kernel(
 __global__ __launch_bounds__(kThreads) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ weight,
                                                             const float* __restrict__ bias, long pixels, int HW, int C,
                                                             int n_cls, float keep_scale, uint32_t thr16, uint64_t seed,
-                                                            const uint8_t* __restrict__ mask, int use_drop,
+                                                            const uint8_t* __restrict__ mask, const uint64_t* __restrict__ seed_dev, int use_drop,
                                                             float* __restrict__ out) {
+  if (seed_dev != nullptr) seed += *seed_dev;  // graph-captured steps: the varying part of the seed lives in device memory
   __shared__ float wsm[kHeadMaxCls * kHeadMaxC];
   for (int i = threadIdx.x; i < n_cls * C; i += kThreads) wsm[i] = weight[i];
   __syncthreads();
@@ -524,8 +525,9 @@ __global__ __launch_bounds__(kThreads) void head_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(64) void head_fwd_tiled_kernel(const float* __restrict__ x, const float* __restrict__ weight,
                                                             const float* __restrict__ bias, long pixels, int HW, int C,
                                                             int n_cls, float keep_scale, uint32_t thr16, uint64_t seed,
-                                                            const uint8_t* __restrict__ mask, int use_drop,
+                                                            const uint8_t* __restrict__ mask, const uint64_t* __restrict__ seed_dev, int use_drop,
                                                             float* __restrict__ out) {
+  if (seed_dev != nullptr) seed += *seed_dev;  // graph-captured steps: the varying part of the seed lives in device memory
   extern __shared__ __attribute__((aligned(16))) float xs[];  // 64 * (C + 1) floats (sized by the launcher)
   const int lane = threadIdx.x;
   const int XS = C + 1, g4n = C >> 2;  // launcher guarantees C % 4 == 0
@@ -587,7 +589,8 @@ template <int LOG2G, int P, int DROP>  // P = classes padded to a power of two (
 __global__ __launch_bounds__(kThreads) void head_fwd_stream_kernel(const float* __restrict__ x, const float* __restrict__ weight,
                                                                    const float* __restrict__ bias, unsigned pixels, unsigned HW,
                                                                    int n_cls, float keep_scale, uint32_t thr16, uint64_t seed,
-                                                                   const uint8_t* __restrict__ mask, float* __restrict__ out) {
+                                                                   const uint8_t* __restrict__ mask, const uint64_t* __restrict__ seed_dev, float* __restrict__ out) {
+  if (seed_dev != nullptr) seed += *seed_dev;  // graph-captured steps: the varying part of the seed lives in device memory
   constexpr int G = 1 << LOG2G;  // lanes (channel quads) per pixel
   const int gq = threadIdx.x & (G - 1);
   f32x4 wq[P];
@@ -674,9 +677,10 @@ __global__ __launch_bounds__(kThreads) void head_fwd_stream_kernel(const float* 
 __global__ __launch_bounds__(kThreads) void head_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ outp,
                                                             const float* __restrict__ x, const float* __restrict__ weight,
                                                             long pixels, int HW, int C, int n_cls, float keep_scale,
-                                                            uint32_t thr16, uint64_t seed, const uint8_t* __restrict__ mask,
+                                                            uint32_t thr16, uint64_t seed, const uint8_t* __restrict__ mask, const uint64_t* __restrict__ seed_dev,
                                                             int use_drop, float* __restrict__ dx, int accumulate, int gate_x,
                                                             float* __restrict__ partial) {
+  if (seed_dev != nullptr) seed += *seed_dev;  // graph-captured steps: the varying part of the seed lives in device memory
   __shared__ float xs[64 * (kHeadMaxC + 1)];
   __shared__ float dl[64 * kHeadMaxCls];
   __shared__ float wsm[kHeadMaxCls * kHeadMaxC];
@@ -777,9 +781,10 @@ __global__ __launch_bounds__(kThreads, 4) void head_bwd_vec_kernel(const float* 
                                                                 const float* __restrict__ x,
                                                                 const float* __restrict__ weight, long pixels, int HW,
                                                                 int C, int n_cls, float keep_scale, uint32_t thr16,
-                                                                uint64_t seed, const uint8_t* __restrict__ mask,
+                                                                uint64_t seed, const uint8_t* __restrict__ mask, const uint64_t* __restrict__ seed_dev,
                                                                 int use_drop, float* __restrict__ dx, int accumulate,
                                                                 int gate_x, float* __restrict__ partial) {
+  if (seed_dev != nullptr) seed += *seed_dev;  // graph-captured steps: the varying part of the seed lives in device memory
   extern __shared__ __attribute__((aligned(16))) float hsm[];
   const int XS = C + 1, g4n = C >> 2, NW = n_cls * C;
   float* xs = hsm;
@@ -891,9 +896,10 @@ __global__ __launch_bounds__(kThreads, 4) void head_bwd_pow2_kernel(const float*
                                                                  const float* __restrict__ x,
                                                                  const float* __restrict__ weight, unsigned pixels,
                                                                  unsigned HW, int n_cls, float keep_scale, uint32_t thr16,
-                                                                 uint64_t seed, const uint8_t* __restrict__ mask,
+                                                                 uint64_t seed, const uint8_t* __restrict__ mask, const uint64_t* __restrict__ seed_dev,
                                                                  float* __restrict__ dx, int accumulate, int gate_x,
                                                                  float* __restrict__ partial) {
+  if (seed_dev != nullptr) seed += *seed_dev;  // graph-captured steps: the varying part of the seed lives in device memory
   extern __shared__ __attribute__((aligned(16))) float hsm[];
   constexpr int G = 1 << LOG2G, C = 4 * G, XS = C + 1;
   constexpr int ITEMS = (64 * G + kThreads - 1) / kThreads;  // 16-byte pieces of a 64-pixel tile per thread
@@ -1404,7 +1410,7 @@ inline bool head_args_ok(int N, int H, int W, int C, int n_cls, float p_drop) {
 }  // namespace
 
 extern "C" int unetpp_head_fwd(const float* x, const float* weight, const float* bias, int32_t N, int32_t H, int32_t W,
-                               int32_t C, int32_t n_cls, float p_drop, uint64_t seed, const uint8_t* mask,
+                               int32_t C, int32_t n_cls, float p_drop, uint64_t seed, const uint8_t* mask, const uint64_t* seed_dev,
                                float* out_nchw, void* stream) {
   if (!x || !weight || !bias || !out_nchw || !head_args_ok(N, H, W, C, n_cls, p_drop)) return UNETPP_EINVAL;
   const long pixels = static_cast<long>(N) * H * W;
@@ -1419,7 +1425,7 @@ extern "C" int unetpp_head_fwd(const float* x, const float* weight, const float*
 #define UNETPP_HEAD_STREAM_D(L, PC, D)                                                                              \
   hipLaunchKernelGGL((head_fwd_stream_kernel<L, PC, D>), grid, dim3(kThreads), 0, ST(stream), x, weight, bias,         \
                      static_cast<unsigned>(pixels), static_cast<unsigned>(H * W), n_cls, 1.0f / (1.0f - p_drop),        \
-                     keep_threshold(p_drop), seed, mask, out_nchw)
+                     keep_threshold(p_drop), seed, mask, seed_dev, out_nchw)
 #define UNETPP_HEAD_STREAM(L, PC)                              \
   do {                                                         \
     if (!use_drop) UNETPP_HEAD_STREAM_D(L, PC, 0);             \
@@ -1449,11 +1455,11 @@ extern "C" int unetpp_head_fwd(const float* x, const float* weight, const float*
     const unsigned blocks = static_cast<unsigned>(tiles < 256 * 16 ? tiles : 256 * 16);
     hipLaunchKernelGGL(head_fwd_tiled_kernel, dim3(blocks), dim3(64), 64 * (C + 1) * sizeof(float), ST(stream), x, weight,
                        bias, pixels, H * W, C,
-                       n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, use_drop, out_nchw);
+                       n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, seed_dev, use_drop, out_nchw);
     return launch_status();
   }
   hipLaunchKernelGGL(head_fwd_kernel, dim3(grid_for(pixels)), dim3(kThreads), 0, ST(stream), x, weight, bias, pixels,
-                     H * W, C, n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, use_drop, out_nchw);
+                     H * W, C, n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, seed_dev, use_drop, out_nchw);
   return launch_status();
 }
 
@@ -1465,7 +1471,7 @@ extern "C" int64_t unetpp_head_bwd_blocks(int64_t pixels) {
 
 extern "C" int unetpp_head_bwd(const float* d_out_nchw, const float* out_nchw, const float* x, const float* weight,
                                int32_t N, int32_t H, int32_t W, int32_t C, int32_t n_cls, float p_drop, uint64_t seed,
-                               const uint8_t* mask, float* dx, int32_t accumulate, int32_t gate_x, float* partial,
+                               const uint8_t* mask, const uint64_t* seed_dev, float* dx, int32_t accumulate, int32_t gate_x, float* partial,
                                void* stream) {
   if (!d_out_nchw || !out_nchw || !x || !weight || !dx || !partial || !head_args_ok(N, H, W, C, n_cls, p_drop))
     return UNETPP_EINVAL;
@@ -1485,7 +1491,7 @@ extern "C" int unetpp_head_bwd(const float* d_out_nchw, const float* out_nchw, c
 #define UNETPP_HEAD_BWD_P(L, D, PC)                                                                                 \
   hipLaunchKernelGGL((head_bwd_pow2_kernel<L, D, PC>), grid, dim3(kThreads), lds, ST(stream), d_out_nchw, out_nchw, x, \
                      weight, static_cast<unsigned>(pixels), static_cast<unsigned>(H * W), n_cls, 1.0f / (1.0f - p_drop), \
-                     keep_threshold(p_drop), seed, mask, dx, accumulate, gate_x, partial)
+                     keep_threshold(p_drop), seed, mask, seed_dev, dx, accumulate, gate_x, partial)
 #define UNETPP_HEAD_BWD_L(L)              \
   do {                                    \
     if (drop == 0) UNETPP_HEAD_BWD(L, 0); \
@@ -1508,12 +1514,12 @@ extern "C" int unetpp_head_bwd(const float* d_out_nchw, const float* out_nchw, c
     const size_t lds = (64 * (C + 1) + 64 * kHeadMaxCls + kHeadMaxCls * C + 2 * n_cls * C) * sizeof(float);
     hipLaunchKernelGGL(head_bwd_vec_kernel, dim3(static_cast<unsigned>(unetpp_head_bwd_blocks(pixels))), dim3(kThreads),
                        lds, ST(stream), d_out_nchw, out_nchw, x, weight, pixels, H * W, C, n_cls, 1.0f / (1.0f - p_drop),
-                       keep_threshold(p_drop), seed, mask, use_drop, dx, accumulate, gate_x, partial);
+                       keep_threshold(p_drop), seed, mask, seed_dev, use_drop, dx, accumulate, gate_x, partial);
     return launch_status();
   }
   hipLaunchKernelGGL(head_bwd_kernel, dim3(static_cast<unsigned>(unetpp_head_bwd_blocks(pixels))), dim3(kThreads), 0,
                      ST(stream), d_out_nchw, out_nchw, x, weight, pixels, H * W, C, n_cls, 1.0f / (1.0f - p_drop),
-                     keep_threshold(p_drop), seed, mask, use_drop, dx, accumulate, gate_x, partial);
+                     keep_threshold(p_drop), seed, mask, seed_dev, use_drop, dx, accumulate, gate_x, partial);
   return launch_status();
 }
 

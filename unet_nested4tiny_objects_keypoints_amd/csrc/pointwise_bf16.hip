@@ -205,8 +205,9 @@ template <int LOG2CG, int DROP, int PCLS>  // PCLS = classes padded to 4 or 8: t
 __global__ __launch_bounds__(kThreads) void head_fwd_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ weight,
                                                                  const float* __restrict__ bias, long pixels, int HW,
                                                                  int n_cls, float keep_scale, uint32_t thr16,
-                                                                 uint64_t seed, const uint8_t* __restrict__ mask,
+                                                                 uint64_t seed, const uint8_t* __restrict__ mask, const uint64_t* __restrict__ seed_dev,
                                                                  float* __restrict__ out) {
+  if (seed_dev != nullptr) seed += *seed_dev;  // graph-captured steps: the varying part of the seed lives in device memory
   constexpr int CG = 1 << LOG2CG, C = 8 * CG;
   __shared__ float wsm[PCLS * C];  // zero rows past n_cls (the class weights in registers ran 1.2x slower, twice measured)
   for (int i = threadIdx.x; i < PCLS * C; i += kThreads) wsm[i] = i < n_cls * C ? weight[i] : 0.f;
@@ -260,9 +261,10 @@ template <int LOG2CG, int DROP, int PCLS>  // PCLS = classes padded to 4 or 8: t
 __global__ __launch_bounds__(kThreads) void head_bwd_bf16_kernel(const float* __restrict__ d_out, const float* __restrict__ outp,
                                                                  const bf16_t* __restrict__ x, const float* __restrict__ weight,
                                                                  unsigned pixels, unsigned HW, int n_cls, float keep_scale,
-                                                                 uint32_t thr16, uint64_t seed, const uint8_t* __restrict__ mask,
+                                                                 uint32_t thr16, uint64_t seed, const uint8_t* __restrict__ mask, const uint64_t* __restrict__ seed_dev,
                                                                  bf16_t* __restrict__ dx, int accumulate, int gate_x,
                                                                  float* __restrict__ partial) {
+  if (seed_dev != nullptr) seed += *seed_dev;  // graph-captured steps: the varying part of the seed lives in device memory
   // 256-pixel tiles (four items in flight per thread at 32 channels): dlogit = d_out * out * (1 - out) of the tile goes through LDS (the NCHW class planes are read
   // coalesced along the pixels), then every thread takes (pixel, channel octet) items: dx = keep * scale * (W^T dlogit)
   // (+ old dx, ReLU gate of x) and the weight gradient of ITS octet, dlogit_k * (x * keep * scale), summed in registers
@@ -618,7 +620,7 @@ static bool head_bf16_ok(int N, int H, int W, int C, int n_cls, float p_drop) {
 }
 
 extern "C" int unetpp_head_fwd_bf16(const void* x, const float* weight, const float* bias, int32_t N, int32_t H, int32_t W,
-                                    int32_t C, int32_t n_cls, float p_drop, uint64_t seed, const uint8_t* mask,
+                                    int32_t C, int32_t n_cls, float p_drop, uint64_t seed, const uint8_t* mask, const uint64_t* seed_dev,
                                     float* out_nchw, void* stream) {
   if (!x || !weight || !bias || !out_nchw || !a16(x) || !head_bf16_ok(N, H, W, C, n_cls, p_drop)) return UNETPP_EINVAL;
   const long pixels = static_cast<long>(N) * H * W;
@@ -630,7 +632,7 @@ extern "C" int unetpp_head_fwd_bf16(const void* x, const float* weight, const fl
   if (drop == 2 && (reinterpret_cast<uintptr_t>(mask) & 7) != 0) return UNETPP_EINVAL;  // mask octets are read as 8 bytes
 #define UNETPP_HEAD_BF(L, D, PC)                                                                                          \
   hipLaunchKernelGGL((head_fwd_bf16_kernel<L, D, PC>), grid, dim3(kThreads), 0, ST(stream), static_cast<const bf16_t*>(x), \
-                     weight, bias, pixels, H * W, n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask,       \
+                     weight, bias, pixels, H * W, n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, seed_dev,       \
                      out_nchw)
 #define UNETPP_HEAD_BF_D(L, D)            \
   do {                                    \
@@ -658,7 +660,7 @@ extern "C" int unetpp_head_fwd_bf16(const void* x, const float* weight, const fl
 
 extern "C" int unetpp_head_bwd_bf16(const float* d_out_nchw, const float* out_nchw, const void* x, const float* weight,
                                     int32_t N, int32_t H, int32_t W, int32_t C, int32_t n_cls, float p_drop, uint64_t seed,
-                                    const uint8_t* mask, void* dx, int32_t accumulate, int32_t gate_x, float* partial,
+                                    const uint8_t* mask, const uint64_t* seed_dev, void* dx, int32_t accumulate, int32_t gate_x, float* partial,
                                     void* stream) {
   if (!d_out_nchw || !out_nchw || !x || !weight || !dx || !partial || !a16(x) || !a16(dx) ||
       !head_bf16_ok(N, H, W, C, n_cls, p_drop))
@@ -678,7 +680,7 @@ extern "C" int unetpp_head_bwd_bf16(const float* d_out_nchw, const float* out_nc
 #define UNETPP_HEAD_BWD_BF_P(L, D, PC)                                                                                 \
   hipLaunchKernelGGL((head_bwd_bf16_kernel<L, D, PC>), grid, dim3(kThreads), lds, ST(stream), d_out_nchw, out_nchw,     \
                      static_cast<const bf16_t*>(x), weight, static_cast<unsigned>(pixels), static_cast<unsigned>(H * W), \
-                     n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, static_cast<bf16_t*>(dx),       \
+                     n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, seed_dev, static_cast<bf16_t*>(dx),       \
                      accumulate, gate_x, partial)
 #define UNETPP_HEAD_BWD_BF_L(L)              \
   do {                                       \

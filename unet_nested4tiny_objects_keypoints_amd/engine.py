@@ -228,9 +228,12 @@ def _dropout_config(model, training):
     masks = model.dropout_masks if p > 0.0 else None
     if masks is not None and len(masks) != heads:
         raise ValueError("dropout_masks needs one mask per head")
-    base = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p > 0.0 and masks is None) else 0
+    # A captured training step (graph.GraphedTrainStep) bakes the launch arguments in: the varying part of the seed then
+    # lives in a device word that the step's owner rewrites before every replay, and the by-value part stays fixed
+    seed_dev = getattr(model, "_dropout_seed_dev", None) if (p > 0.0 and masks is None) else None
+    base = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p > 0.0 and masks is None and seed_dev is None) else 0
     seeds = [(base + 0x632BE59BD9B4E019 * (j + 1)) & 0xFFFFFFFFFFFFFFFF for j in range(heads)]
-    return p, seeds, masks
+    return p, seeds, masks, seed_dev
 
 
 def forward_impl(model, x, training: bool, save: bool):
@@ -282,19 +285,19 @@ def _forward_impl(model, x, training: bool, save: bool):
             ins = [V(u.up)] + [V(X[(i, jj)]) for jj in range(j)]  # up first, then X_i0.. (:198-202)
             r = _pair_fwd(mod.conv, ins, b, hi, wi, training, pool=False, adt=adt)
             ups[(i, j)], pairs[(i, j)], X[(i, j)] = u, r, r.out
-    p_drop, seeds, masks = _dropout_config(model, training)
+    p_drop, seeds, masks, seed_dev = _dropout_config(model, training)
     outs = []
     for j in range(1, d):  # heads (:283-286)
         head = getattr(model, "final_%d" % j)
         o = torch.empty((b, model.n_classes, h0, w0), dtype=torch.float32, device=x.device)
         ops.head_fwd(X[(0, j)], head.weight.detach().view(model.n_classes, -1), head.bias.detach(), p_drop,
-                     seeds[j - 1], None if masks is None else masks[j - 1], o)
+                     seeds[j - 1], None if masks is None else masks[j - 1], o, seed_dev=seed_dev)
         outs.append(o)
     if not save:
         return outs, None
     s = _Saved()
     s.x_nhwc, s.X, s.pairs, s.ups, s.outs = x_nhwc, X, pairs, ups, outs
-    s.p_drop, s.seeds, s.masks = p_drop, seeds, masks
+    s.p_drop, s.seeds, s.masks, s.seed_dev = p_drop, seeds, masks, seed_dev
     s.shape = (b, h0, w0)
     return outs, s
 
@@ -498,7 +501,7 @@ def _backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=No
         dx, acc, gate = book.target((0, j), can_gate=True)
         dw, db = ops.head_bwd(go, s.outs[j - 1], s.X[(0, j)], head.weight.detach().view(model.n_classes, -1), s.p_drop,
                               s.seeds[j - 1], None if s.masks is None else s.masks[j - 1], dx, acc,
-                              gate_x=gate is not None)
+                              gate_x=gate is not None, seed_dev=s.seed_dev)
         if _ALLOC[0] is not None:
             gw, gb = _new_grad(head.weight), _new_grad(head.bias)
             gw.copy_(dw)

@@ -573,15 +573,16 @@ def bn_backward(d_act, y, scale, shift, mean, invstd, gamma, dy_out, dgamma=None
     return dgamma, dbeta
 
 
-def head_fwd(x, weight, bias, p_drop, seed, mask, out_nchw):
+def head_fwd(x, weight, bias, p_drop, seed, mask, out_nchw, seed_dev=None):
+    """seed_dev: optional one-element int64 device tensor added to `seed` when the kernel runs (graph-captured steps)"""
     n, h, w, c = x.shape
     n_cls = weight.shape[0]
     fn = _lib.lib().unetpp_head_fwd_bf16 if _is_bf16(x) else _lib.lib().unetpp_head_fwd
     check(fn(_ptr(x), _ptr(weight), _ptr(bias), n, h, w, c, n_cls, float(p_drop), C.c_uint64(seed), _ptr(mask),
-             _ptr(out_nchw), _stream()), "unetpp_head_fwd")
+             _ptr(seed_dev), _ptr(out_nchw), _stream()), "unetpp_head_fwd")
 
 
-def head_bwd(d_out, out, x, weight, p_drop, seed, mask, dx, accumulate, gate_x=False):
+def head_bwd(d_out, out, x, weight, p_drop, seed, mask, dx, accumulate, gate_x=False, seed_dev=None):
     """Returns (dW [n_cls, C, 1, 1], db [n_cls]); dx is written or accumulated in place."""
     lib = _lib.lib()
     n, h, w, c = x.shape
@@ -593,7 +594,7 @@ def head_bwd(d_out, out, x, weight, p_drop, seed, mask, dx, accumulate, gate_x=F
     st = _stream()
     fn = lib.unetpp_head_bwd_bf16 if _is_bf16(x) else lib.unetpp_head_bwd
     check(fn(_ptr(d_out), _ptr(out), _ptr(x), _ptr(weight), n, h, w, c, n_cls, float(p_drop), C.c_uint64(seed), _ptr(mask),
-             _ptr(dx), int(accumulate), int(gate_x), _ptr(partial), st), "unetpp_head_bwd")
+             _ptr(seed_dev), _ptr(dx), int(accumulate), int(gate_x), _ptr(partial), st), "unetpp_head_bwd")
     check(lib.unetpp_sum_partials(_ptr(partial), blocks, ln, _ptr(sums), st), "unetpp_sum_partials")
     return sums[:n_cls * c].view(n_cls, c, 1, 1), sums[n_cls * c:]
 
