@@ -1277,6 +1277,21 @@ inline long bn_bwd_blocks_for(long pixels, int C, bool vec) {
 }
 }  // namespace
 
+namespace {
+// Unused rows of a partial-sum workspace are zeroed by a KERNEL, not by hipMemsetAsync: inside a captured training step
+// (graph.GraphedTrainStep) a memset node of ROCm 7.2's hipGraph was not reliably ordered against the kernel nodes around
+// it -- the BatchNorm-backward finalize summed rows the memset had not cleared yet, whenever a replay started on an idle
+// device (tools/probes/dbg_graph4.py: encoder gradients of 1e19 .. inf from the second replay on).
+__global__ __launch_bounds__(kThreads) void zero_rows_kernel(float* __restrict__ p, long n) {
+  for (long i = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; i < n; i += static_cast<long>(gridDim.x) * kThreads)
+    p[i] = 0.f;
+}
+inline void zero_rows(float* p, long n, hipStream_t st) {
+  const long want = (n + kThreads - 1) / kThreads;
+  hipLaunchKernelGGL(zero_rows_kernel, dim3(static_cast<unsigned>(want < 1024 ? want : 1024)), dim3(kThreads), 0, st, p, n);
+}
+}  // namespace
+
 extern "C" int64_t unetpp_bn_bwd_blocks(int64_t pixels, int32_t C) {
   if (pixels < 1 || C < 1) return 0;
   // upper bound over both code paths (vector / scalar) so one workspace size serves either
@@ -1293,10 +1308,7 @@ extern "C" int unetpp_bn_bwd_reduce(const float* d_act, const float* y, const fl
   // the partial buffer always has unetpp_bn_bwd_blocks() rows; rows beyond this launch's grid are zeroed
   const long rows = unetpp_bn_bwd_blocks(pixels, C);
   const long blocks = bn_bwd_blocks_for(pixels, C, vec);
-  if (blocks < rows) {
-    if (hipMemsetAsync(partial + blocks * C * 2, 0, sizeof(float) * (rows - blocks) * C * 2, ST(stream)) != hipSuccess)
-      return UNETPP_ELAUNCH;
-  }
+  if (blocks < rows) zero_rows(partial + blocks * C * 2, (rows - blocks) * C * 2, ST(stream));
   if (vec)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, ST(stream),
                        d_act, y, scale, shift, mean, invstd, pixels * (C / 4), C / 4, partial);
@@ -1364,9 +1376,7 @@ extern "C" int unetpp_bn_bwd_reduce_pool(const float* d_act, const float* y, con
   const long rows_buf = unetpp_bn_bwd_blocks(pixels, C);  // rows of the partial buffer; unused ones are zeroed
   const long img_rows = static_cast<long>(N) * H;
   const long grid = img_rows < rows_buf ? img_rows : rows_buf;
-  if (grid < rows_buf &&
-      hipMemsetAsync(partial + grid * C * 2, 0, sizeof(float) * (rows_buf - grid) * C * 2, ST(stream)) != hipSuccess)
-    return UNETPP_ELAUNCH;
+  if (grid < rows_buf) zero_rows(partial + grid * C * 2, (rows_buf - grid) * C * 2, ST(stream));
   hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(static_cast<unsigned>(grid)), dim3(kThreads), 0, ST(stream),
                      reinterpret_cast<const f32x4*>(d_act), reinterpret_cast<const f32x4*>(y),
                      reinterpret_cast<const f32x4*>(scale), reinterpret_cast<const f32x4*>(shift),

@@ -24,6 +24,11 @@ The warm-up passes that size the allocator pools and record the weight-image job
 example batch; by default their effect is undone (parameters, buffers and optimizer state are restored in place,
 optimizer state created during warm-up is zeroed) so that the first replay is the first step of the run.
 
+Two properties of hipGraph on ROCm 7.2 shaped this file and csrc/ (both found with tools/probes/dbg_graph*.py, both silent):
+launches captured from a second thread (PyTorch's autograd worker) leave the graph with a tail the launch stream does
+not wait for -- backward is therefore captured with single-threaded autograd; and memset NODES are not reliably ordered
+against neighbouring kernel nodes -- the library zeroes workspace rows with a kernel (pointwise.hip, zero_rows).
+
 Not supported: a model with a data-parallel averager attached (the gradient all-reduce runs on a side stream with its
 own events: use ``train_step`` there), CPU tensors (this path has no CPU fallback).
 """
@@ -61,7 +66,13 @@ class GraphedTrainStep:
                      {id(t): t.detach().clone() for t in self._optimizer_tensors()})
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
+        # Backward must be captured from THIS thread.  PyTorch runs the backward of device tensors on a per-device worker
+        # thread; launches that another thread puts into a capturing stream do end up in the graph, but on ROCm 7.2 a
+        # graph whose last nodes were captured from the second thread completes -- as far as the launch stream can tell
+        # -- before those nodes have run: `stream.synchronize()` returned while the last weight-gradient kernels were
+        # still writing (19 of 20 replays, tools/probes/dbg_graph3.py), and whatever the stream did next raced with them.
+        # Single-threaded autograd keeps every captured launch on one thread and the graph a plain chain.
+        with torch.cuda.stream(side), torch.autograd.set_multithreading_enabled(False):
             for _ in range(max(1, warmup)):   # records the weight-image jobs, sizes the pools, creates optimizer state
                 self._new_seed()
                 self._body(True)
@@ -72,7 +83,7 @@ class GraphedTrainStep:
         if self._plan is not None:
             self._plan.pin()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(self._graph):
             outs, loss = self._body(self.capture_optimizer)
         # eager passes of the model (evaluation, instrumented steps) must draw their own seeds again: the captured head
         # launches hold the address of the device word themselves
