@@ -71,6 +71,10 @@ def parse():
                     help="skip the bf16 configurations (BASELINE configs[3], configs[4]) the default run times after the "
                          "headline and attaches under `other_configs`")
     ap.add_argument("--other-steps", type=int, default=30, help="timed steps of each `other_configs` entry (>= 20)")
+    ap.add_argument("--graphed", action="store_true",
+                    help="replay the step from a HIP graph (GraphedTrainStep; single GPU).  The default run uses it for "
+                         "`other_configs` only; with this flag also for the configuration named on the command line "
+                         "(launch events then move behind the timed region)")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="multi-process plumbing only, on the CPU over gloo, with synthetic gradients and NO kernels: "
                          "self-spawn, rendezvous, broadcast, bucketed all-reduce, optimizer, max-over-ranks timing, "
@@ -318,7 +322,7 @@ def other_entry(name, o, r, world):
         kern = dict(sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])[:5])
     return {"config": name, "workload": workload_name(o), "dtype": o.dtype, "value": round(r["value"], 2),
             "unit": "images/sec", "n_gpus": world, "steps": o.steps, "warmup": o.warmup, "prewarm_steps": o.prewarm,
-            "ms_per_step": round(r["ms_per_step"], 3), "host_enqueue_ms_median": r["host_enqueue_ms"], "fwd_ms_per_img": round(r["fwd_ms_per_img"], 4),
+            "step_runner": r["step_runner"], "ms_per_step": round(r["ms_per_step"], 3), "host_enqueue_ms_median": r["host_enqueue_ms"], "fwd_ms_per_img": round(r["fwd_ms_per_img"], 4),
             "per_gpu_batch": o.batch, "global_batch": world * o.batch, "roofline": roof, "kernels": kern,
             "replicas_bit_identical": r["replicas_identical"]}
 
@@ -350,17 +354,28 @@ def measure(args, ctx):
     torch.manual_seed(1000 + rank)  # every rank its own shard of synthetic data
     x = torch.randn(args.batch, args.in_channels, args.size, args.size, device=dev)
     target = torch.rand(args.batch, n_cls, args.size, args.size, device=dev)
+    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+    # `other_configs` on one GPU: the same step replayed from a HIP graph (graph.GraphedTrainStep: the launches, their
+    # order and their arguments are train_step's; the dropout seed varies through a device word).  These bf16 steps take
+    # 7-11 ms on the device and 4.5-7 ms of host time to enqueue; eager, the device idles 0.5-0.7 ms per step where the
+    # host falls behind (profiles/r4/step_gaps_rocprofv3.txt).  The headline stays eager.  UNETPP_BENCH_NO_GRAPH=1: eager.
+    graphed = (getattr(args, "graphed", False) and not distributed and averager is None
+               and os.environ.get("UNETPP_BENCH_NO_GRAPH") != "1")
     try:  # same Adam, one fused device kernel: 0.13 ms of host time per step instead of 2.6 ms (foreach, 90 tensors)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=graphed)
     except (TypeError, RuntimeError):
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+    run_step = train_step
+    if graphed:
+        from unet_nested4tiny_objects_keypoints_amd import GraphedTrainStep
+        replay = GraphedTrainStep(model, opt, crit, x, target, capture_optimizer=True, restore_state=False)
+        run_step = lambda m, o, c, xx, tt: replay(xx, tt)   # noqa: E731
 
     # W untimed warm-up steps as the contract says, after `--prewarm` more untimed steps (printed as `prewarm_steps`):
     # the first ~10 steps of a process run up to 10 % slower (allocator growth, code-object loading, clock ramp),
     # whatever W the caller picks.
     for _ in range(args.prewarm + args.warmup):
-        train_step(model, opt, crit, x, target)
+        run_step(model, opt, crit, x, target)
 
     # Per-launch HIP events (for the roofline object) on every 10th timed step only: an event pair around each of the
     # 77 MFMA launches of a step costs the stream ~6 us each (0.9 ms per instrumented step; every 4th step still took
@@ -374,7 +389,7 @@ def measure(args, ctx):
     # (every rank runs those steps: they carry the gradient all-reduce): in a process that has already timed another
     # configuration an instrumented step of these short-kernel bf16 steps costs ~15 ms of stream time instead of ~1
     # (903 vs 1083 img/s at configs[3] with identical per-kernel times, profiles/r4/launch_event_cost.txt).
-    events_inside = not getattr(args, "events_after", False)
+    events_inside = not (getattr(args, "events_after", False) or getattr(args, "graphed", False))
     host_ms = []  # host time to ENQUEUE a step (no sync inside): when it nears ms_per_step the run is launch-bound
     if distributed:
         dist.barrier()
@@ -390,7 +405,7 @@ def measure(args, ctx):
         ops.set_timer(timer if (sample or sample_regions) else None)
         sampled_steps += int(sample)
         h0 = time.perf_counter()
-        train_step(model, opt, crit, x, target)
+        run_step(model, opt, crit, x, target)
         host_ms.append(1e3 * (time.perf_counter() - h0))
     ops.set_timer(None)
     torch.cuda.synchronize()
@@ -502,7 +517,7 @@ def measure(args, ctx):
                             "us_per_img": round(t_img_us, 2), "floor_compute_us": round(floor_c, 2),
                             "floor_hbm_us": round(floor_h, 2), "bound": "mfma" if floor_c >= floor_h else "hbm",
                             "frac": round(max(floor_c, floor_h) / t_img_us, 4)}
-    return {"host_enqueue_ms": round(sorted(host_ms)[len(host_ms) // 2], 3), "value": value, "ms_per_step": ms_per_step, "fwd_ms_per_img": fwd_ms_per_img, "roofline": roofline,
+    return {"step_runner": "hip_graph" if graphed else "eager", "host_enqueue_ms": round(sorted(host_ms)[len(host_ms) // 2], 3), "value": value, "ms_per_step": ms_per_step, "fwd_ms_per_img": fwd_ms_per_img, "roofline": roofline,
             "roofline_x00": roofline_x00, "kernels": kernels, "dp": dp_info,
             "replicas_identical": replicas_identical, "n_cls": n_cls, "fs": fs}
 
@@ -556,7 +571,7 @@ def main():
         others = []
         for name, over in OTHER_CONFIGS:
             o = argparse.Namespace(**dict(vars(args), **over))
-            o.steps, o.warmup, o.prewarm, o.events_after = max(20, args.other_steps), 10, 15, True
+            o.steps, o.warmup, o.prewarm, o.events_after, o.graphed = max(20, args.other_steps), 10, 15, True, True
             try:
                 r = measure(o, ctx)
                 entry_ = None if r is None else other_entry(name, o, r, world)
@@ -589,6 +604,7 @@ def main():
         "prewarm_steps": args.prewarm,
         "ms_per_step": round(ms_per_step, 3),
         "host_enqueue_ms_median": res["host_enqueue_ms"],
+        "step_runner": res["step_runner"],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

@@ -207,6 +207,9 @@ def test_reserved_cus_knob_changes_grids_not_results():
         assert lib.unetpp_set_reserved_cus(0) == 0
     for a, b in zip(o0, o1):
         assert float((a - b).abs().max()) <= 2e-6
+    from tests.helpers import is_pre_bn_bias
     for k in g0:
+        if is_pre_bn_bias(k, {}):   # analytically zero (the batch mean removes them): rounding noise on both sides
+            continue
         scale = float(g0[k].abs().max())
         assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * scale + 1e-12, k

@@ -16,12 +16,17 @@ for v in ${VARIANTS:-BASE NO_MFMA NO_EPI NO_INDMA NO_MFMA_NO_EPI STORE_LINEAR}; 
     NO_MFMA_NO_EPI) D="-DUNETPP_DMA_EXP_NO_MFMA -DUNETPP_DMA_EXP_NO_EPI";;
     STORE_LINEAR) D="-DUNETPP_DMA_EXP_STORE_LINEAR";;
     STORE_LINEAR_NO_MFMA) D="-DUNETPP_DMA_EXP_STORE_LINEAR -DUNETPP_DMA_EXP_NO_MFMA";;
+    DEEP) D="-DUNETPP_DMA_EXP_DEEP";;
+    DEEP_NO_EPI) D="-DUNETPP_DMA_EXP_DEEP -DUNETPP_DMA_EXP_NO_EPI";;
+    DEEP_NO_MFMA_NO_EPI) D="-DUNETPP_DMA_EXP_DEEP -DUNETPP_DMA_EXP_NO_MFMA -DUNETPP_DMA_EXP_NO_EPI";;
   esac
   $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include -I unet_nested4tiny_objects_keypoints_amd/csrc $D -c unet_nested4tiny_objects_keypoints_amd/csrc/gemm_bf16_dma.hip -o build/exp/gemm_bf16_dma_$v.o
   $HIPCC --offload-arch=gfx950 -shared -fPIC -o build/exp/libunetpp_dma_$v.so $OBJS build/exp/gemm_bf16_dma_$v.o
 done
-export REPS=20 DTYPE=bf16 B=8 SIZE=512
+export REPS=20 DTYPE=bf16 B=${B:-8} SIZE=${SIZE:-512}
+# SHAPES: layer-name filter of tools/bench_kernels.py (default: the level-0 shapes of configs[3]); with BASE=64 FULL=1
+# DEPTH=4 B=4 SIZE=384 in the environment the table is that of configs[4]
 for v in ${VARIANTS:-BASE NO_MFMA NO_EPI NO_INDMA NO_MFMA_NO_EPI STORE_LINEAR} BASE; do
   echo "== $v"
-  UNETPP_LIB=$R/build/exp/libunetpp_dma_$v.so timeout -k 10 120 python tools/bench_kernels.py X03 2>&1 | grep "X03"
+  UNETPP_LIB=$R/build/exp/libunetpp_dma_$v.so timeout -k 10 120 python tools/bench_kernels.py ${SHAPES:-X03} 2>&1 | grep "${SHAPES:-X03}"
 done
