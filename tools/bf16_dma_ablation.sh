@@ -16,9 +16,10 @@ for v in ${VARIANTS:-BASE NO_MFMA NO_EPI NO_INDMA NO_MFMA_NO_EPI STORE_LINEAR}; 
     NO_MFMA_NO_EPI) D="-DUNETPP_DMA_EXP_NO_MFMA -DUNETPP_DMA_EXP_NO_EPI";;
     STORE_LINEAR) D="-DUNETPP_DMA_EXP_STORE_LINEAR";;
     STORE_LINEAR_NO_MFMA) D="-DUNETPP_DMA_EXP_STORE_LINEAR -DUNETPP_DMA_EXP_NO_MFMA";;
-    DEEP) D="-DUNETPP_DMA_EXP_DEEP";;
-    DEEP_NO_EPI) D="-DUNETPP_DMA_EXP_DEEP -DUNETPP_DMA_EXP_NO_EPI";;
-    DEEP_NO_MFMA_NO_EPI) D="-DUNETPP_DMA_EXP_DEEP -DUNETPP_DMA_EXP_NO_MFMA -DUNETPP_DMA_EXP_NO_EPI";;
+
+
+
+
   esac
   $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include -I unet_nested4tiny_objects_keypoints_amd/csrc $D -c unet_nested4tiny_objects_keypoints_amd/csrc/gemm_bf16_dma.hip -o build/exp/gemm_bf16_dma_$v.o
   $HIPCC --offload-arch=gfx950 -shared -fPIC -o build/exp/libunetpp_dma_$v.so $OBJS build/exp/gemm_bf16_dma_$v.o

@@ -9,9 +9,9 @@
 //     registers, no VALU): the buffer resource's range check returns ZEROS for out-of-image halo pixels (their offset is
 //     simply out of range), so border patches take the same path as interior ones -- no clamps, masks or selects;
 //   * an LDS-DMA instruction writes its 64 lanes' 16 bytes lane-linearly, so the padded 80-byte pixel pitch of
-//     gemm_bf16.hip is not available; instead the SOURCE side is permuted (round 4: lds_item below): a 1 KB block holds 16
-//     consecutive halo pixels, a lane quad fetches one pixel's 64 bytes (its four channel octets, in an order XORed with
-//     bits 2-3 of the pixel index), and the 16 lanes of a ds_read_b128 phase hit all 64 banks once: conflict free;
+//     gemm_bf16.hip is not available; instead the SOURCE side is permuted: a 1 KB block holds 16 consecutive halo
+//     pixels x 4 channel octets as [octet][pixel], i.e. lane L fetches pixel 16*block + (L & 15), octet L >> 4.  The 16
+//     lanes of a ds_read_b128 phase then read 16 consecutive pixels of one octet = 256 contiguous bytes: conflict free;
 //   * all input views of a launch share one geometry (C, Hs, Ws, strides: the dense-skip concatenation of tensors of one
 //     level, the four phases of a transposed convolution), so a thread's offsets depend on the pixel patch only; view,
 //     phase origin and channel chunk go into the scalar offset / the resource;
@@ -30,6 +30,18 @@
 // nor issuing the next DMA and the next unit's epilogue operands BEFORE a unit's stores (counted vmcnt, two operand
 // sets; 76 us at 228 registers) changes that.  The level-0 bf16 layers are bound by the CU's memory pipeline at about
 // 0.45-0.5 of the HBM floor with 8 x 32 patches (1.33x halo); what is left is bytes per pixel (larger patches), not issue.
+//
+// Round 4, measured on ONE box with alternating libraries (tools/dma_ab.sh; boxes of the pool differ by up to 30 % on these
+// store-heavy launches, which is how the first of these looked like a 3-7 % gain when it was timed on another box):
+//   * a quad-coalesced patch image (a lane quad fetches one pixel's 64 contiguous bytes, XOR-swizzled so that the
+//     fragment reads stay conflict free) instead of the [octet][pixel] blocks: +-1 %, 11 more registers.  Not kept;
+//   * the ten DMA pieces of a chunk issued one behind each MFMA step instead of as a block in front of them: -1 % on the
+//     forward GEMMs of configs[4], 0 / +2 % elsewhere, 256 registers + scratch.  Not kept;
+//   * a second chunk of DMA in flight (experiment build): no change; non-temporal output stores: 5-30 % slower.
+// tools/dma_stamps.py (stamped build): per 32-channel chunk of [64 x 5] -> 64 at 384 x 384 x 4 wave 0 spends 600 cycles in
+// the cursor, 1 860 issuing its ten DMA pieces, 2 650 in LDS reads + MFMAs, 435 in the epilogue (per-chunk average) and
+// 2 450 in the barrier, most of which is the second wave of its SIMD running ITS MFMAs; without the epilogue the barrier
+// share halves -- the unit's 64 KB of output stores delay the next chunk's DMA in the CU's memory pipeline by ~9 us.
 #include <cstdlib>
 
 #include "bf16_common.h"
@@ -70,25 +82,6 @@ struct DmaArgs {
   int img_pitch;    // bytes per image / 1 (Hs * Ws * C * 2), < 2^31
   int view_bytes;   // size of an input tensor in bytes
   int wimg_bytes;   // size of the launch's weight image in bytes (n_tiles * n_chunks * IMG)
-};
-
-// LDS image of an input patch (round 4).  A halo pixel's 32-channel chunk is 64 contiguous bytes in the tensor: the four
-// lanes of a QUAD fetch them (one 64-byte request per quad; the round-3 image took the 16 pixels of a block by 16 adjacent
-// lanes -- 64 different cache lines per wave instruction, and the address unit, not HBM, set the pace of the patch
-// reads at ~20 GB/s per CU).  An LDS-DMA writes lane-linearly, so position 4 * pixel + s of the image belongs to lane
-// 4 * pixel + s; WHICH octet that lane fetches is free: octet s ^ f(pixel), f = (pixel >> 2) & 3.  A ds_read_b128 phase
-// serves 16 lanes = 16 consecutive pixels (mod 16) of ONE octet: slot 4 * (p & 3) + (o ^ f(p)) is a bijection of p mod 16,
-// i.e. the 16 reads cover all 64 banks once -- conflict free, as the [octet][pixel] blocks were.
-__device__ __forceinline__ int lds_item(int hp, int octet) { return hp * 64 + ((octet ^ ((hp >> 2) & 3)) << 4); }
-
-// scalars of one chunk's DMA (dma_setup / dma_piece in the kernel).  At NAMESPACE scope on purpose: with a struct declared
-// inside the __global__ template, hipcc's host pass silently emits no launch stub for any instantiation (the library then
-// fails to load with an undefined __device_stub__ symbol)
-struct DmaCtx {
-  const float* in_ptr;
-  unsigned char *in_dst, *w_dst;
-  int soff, wchunk;
-  bool need_in, need_w;
 };
 
 // WAVES = 4: 256-pixel patches (8 x 32), two workgroups per CU (2 x 80 KB).  WAVES = 8: 512-pixel patches (16 x 32:
@@ -178,7 +171,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int hp = (py + (TAPS == 9 ? tap / 3 : 0)) * HWp + px + (TAPS == 9 ? tap % 3 : 0);
-      a_off[mt][tap] = lds_item(hp, h);  // octet h of the chunk half g = 0; g = 1: ^ 32 (octets 2 + h)
+      a_off[mt][tap] = (hp >> 4) * 1024 + h * 256 + (hp & 15) * 16;  // + g * 512
     }
   }
   const int wb = (j * 2 + h) * 16;
@@ -196,7 +189,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int blk = (wave + WAVES * q < NBLK) ? wave + WAVES * q : wave;  // (see dma_chunk: a block past the patch repeats block `wave`)
-    const int hp = blk * 16 + (lane >> 2);  // a quad = one pixel's four octets (lds_item)
+    const int hp = blk * 16 + (lane & 15);
     item_hy[q] = hp / HWp;
     item_hx[q] = hp - item_hy[q] * HWp;
     if (hp >= NPIX) item_hy[q] = -0x10000;  // past the patch: always out of range (zeros)
@@ -219,8 +212,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
       // bitwise on purpose (a short-circuit becomes a divergent branch that drags the scalar cursor into vector registers)
       const bool inside = (static_cast<unsigned>(y) < static_cast<unsigned>(d.H)) & (static_cast<unsigned>(x) < static_cast<unsigned>(d.W));
       const unsigned off = img0 + static_cast<unsigned>(y) * static_cast<unsigned>(da.row_pitch) +
-                           static_cast<unsigned>(x) * static_cast<unsigned>(da.col_pitch) +
-                           static_cast<unsigned>((lane & 3) ^ ((lane >> 4) & 3)) * 16u;  // octet s ^ f(pixel), f = (hp >> 2) & 3
+                           static_cast<unsigned>(x) * static_cast<unsigned>(da.col_pitch) + static_cast<unsigned>(lane >> 4) * 16u;
       voff[q] = inside ? off : kDmaOutOfRange;
     }
   };
@@ -262,58 +254,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
     }
     if (need_w) dma_weights(w_buf, p_wimg, p_chunk);
   };
-  // The same DMA, one wave instruction at a time (round 4).  Issued as a block in front of the MFMAs, the ten pieces of a
-  // chunk cost a wave ~2 k cycles of scalar work (descriptor loads, destination M0, offsets: ~200 cycles per piece,
-  // tools/dma_stamps.py) during which it issues no MFMA -- and the second wave of its SIMD is in the same block at the same
-  // time, so the matrix pipe idles for a quarter of every chunk.  The main loop therefore sets the scalars up once
-  // (dma_setup) and issues piece `step` right behind the MFMAs of step `step`, in their shadow.
-  auto dma_setup = [&](int in_buf, int w_buf, bool need_in, bool need_w) __attribute__((always_inline)) -> DmaCtx {
-    DmaCtx c;
-#ifdef UNETPP_DMA_EXP_NO_INDMA
-    need_in = false;
-#endif
-    c.need_in = need_in;
-    c.need_w = need_w;
-    c.in_dst = smem + in_buf * IN_BYTES;
-    c.w_dst = smem + 2 * IN_BYTES + w_buf * W_BYTES;
-    const unetpp_view& V = d.in[need_in ? p_s : 0];
-    c.in_ptr = V.ptr;
-    c.soff = ((V.oy * V.Ws + V.ox) * V.C + V.c_off + p_c0) * 2;  // phase origin, channel slice, chunk (bytes)
-    c.wchunk = p_wimg + p_chunk * IMG;
-    return c;
-  };
-  auto dma_piece = [&](auto qc, const DmaCtx& c) __attribute__((always_inline)) {
-    constexpr int q = decltype(qc)::v;
-    if constexpr (q < NQ) {
-      if (c.need_in) {  // uniform
-        const int blk = (wave + WAVES * q < NBLK) ? wave + WAVES * q : wave;  // uniform
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c.in_ptr), 0, da.view_bytes, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (dma_lptr_t)(c.in_dst + blk * 1024), 16, static_cast<int>(voff[q]),
-                                                 c.soff, 0, 0);
-      }
-    } else if constexpr (q < NQ + NWQ) {
-      if (c.need_w) {  // uniform
-        constexpr int qw = q - NQ;
-        const int blk = (wave + WAVES * qw < WBLK) ? wave + WAVES * qw : wave;  // 1 KB block of the NT images (uniform)
-        const int t = blk / (IMG / 1024), r = blk - t * (IMG / 1024);
-        const __amdgpu_buffer_rsrc_t wrsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.weight_image), 0, da.wimg_bytes, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (dma_lptr_t)(c.w_dst + blk * 1024), 16, lane16,
-                                                 c.wchunk + t * a.n_chunks * IMG + r * 1024, 0, 0);
-      }
-    }
-  };
-  // MEASURED AND SWITCHED OFF (-DUNETPP_DMA_SHADOW_ISSUE builds it): the 3x3 GEMMs of configs[4] 2.662 -> 2.632 ms forward,
-  // those of configs[3] 1.351 -> 1.365 ms, input gradients 1.456 -> 1.486 ms, and the two-tile instantiation goes to 256
-  // registers with 60 bytes of scratch.  The ~200 cycles per piece are not scalar work that MFMAs could hide: they are
-  // the CU's vector-memory path accepting one 1 KB LDS-DMA per ~100 cycles (80 pieces per chunk and CU, ~12 B/clk/CU --
-  // the same wall the round-3 ablations found); issued later, the pieces stall the wave in front of its next MFMAs instead.
-#ifdef UNETPP_DMA_SHADOW_ISSUE
-  constexpr bool SHADOW = (TAPS * 2 >= NQ + NWQ);  // enough MFMA steps to carry the pieces (the pointwise GEMM has two)
-#else
-  constexpr bool SHADOW = false;
-#endif
   // next chunk of the unit, or chunk 0 of the next unit; false when nothing is left
   auto advance = [&]() -> bool {
     if (p_chunk + 1 < a.n_chunks) {
@@ -352,10 +292,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
       if (t == 0) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.b[0]) : "v"(wa), "n"(step * DSTEP));
       else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.b[NT - 1]) : "v"(wa), "n"(IMG + step * DSTEP));
     }
-    // octets 2g + h: bit 1 of the octet is bit 5 of the address, and it is XORed with bit 1 of f(pixel)
-    const unsigned aa0 = in_base + (static_cast<unsigned>(a_off[0][tap]) ^ (g * 32u)), aa1 = in_base + (static_cast<unsigned>(a_off[1][tap]) ^ (g * 32u));
-    asm volatile("ds_read_b128 %0, %1" : "=v"(f.a0) : "v"(aa0));
-    asm volatile("ds_read_b128 %0, %1" : "=v"(f.a1) : "v"(aa1));
+    const unsigned aa0 = in_base + static_cast<unsigned>(a_off[0][tap]), aa1 = in_base + static_cast<unsigned>(a_off[1][tap]);
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.a0) : "v"(aa0), "n"(g * 512));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.a1) : "v"(aa1), "n"(g * 512));
   };
   auto wait_frag = [&](Frag& f) {
     if constexpr (NT == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.b[0]), "+v"(f.a0), "+v"(f.a1));
@@ -599,9 +538,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
   dma_chunk(0, 0, true, !w_resident);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-#ifdef UNETPP_DMA_EXP_DEEP   // timing only (wrong results): one MORE chunk of DMA in flight at all times
-  dma_chunk(1, 1, true, !w_resident);
-#endif
 
   int c_chunk = 0, in_cur = 0, w_cur = 0;
   bool more = advance();
@@ -613,9 +549,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
   while (true) {
     DMA_STAMP(0);  // 0: cursor advance (end of the previous iteration)
     const bool need_in = more && !(in_reuse && p_same_patch), need_w = more && !w_resident;
-    DmaCtx dctx;
-    if constexpr (SHADOW) dctx = dma_setup(in_cur ^ 1, w_cur ^ 1, need_in, need_w);
-    else if (more) dma_chunk(in_cur ^ 1, w_cur ^ 1, need_in, need_w);
+    if (more) dma_chunk(in_cur ^ 1, w_cur ^ 1, need_in, need_w);
     if constexpr (!STATS) {
       if (c_chunk + 1 == a.n_chunks) fetch_epilogue_operands();  // uniform
     }
@@ -648,10 +582,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (SHADOW && step < NQ + NWQ) {  // one piece of the next chunk's DMA in the shadow of this step's MFMAs
-        dma_piece(IC<step>{}, dctx);
-        __builtin_amdgcn_sched_barrier(0);
-      }
       if constexpr (step + 1 < TAPS * 2) wait_frag(fr[ns]);
     });
     DMA_STAMP(2);  // 2: LDS fragment reads + MFMAs
@@ -659,16 +589,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
     if constexpr (STATS) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
-#ifdef UNETPP_DMA_EXP_DEEP
-      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-#else
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(eo.b4[t][0]), "+v"(eo.b4[t][1]), "+v"(eo.b4[t][2]), "+v"(eo.b4[t][3])::"memory");
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(eo.gate_raw[t][0][0]), "+v"(eo.gate_raw[t][0][1]), "+v"(eo.gate_raw[t][1][0]), "+v"(eo.gate_raw[t][1][1])::"memory");
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(eo.old_raw[t][0][0]), "+v"(eo.old_raw[t][0][1]), "+v"(eo.old_raw[t][1][0]), "+v"(eo.old_raw[t][1][1])::"memory");
       }
-#endif
     }
     DMA_STAMP(3);  // 3: wait for the DMA (and whatever is older: the previous unit's stores)
 #ifdef UNETPP_DMA_STAMPS
@@ -697,7 +623,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    DMA_STAMP(5);  // 5: barrier
+    DMA_STAMP(5);  // 5: barrier (= the MFMA phase of the other wave of this SIMD, mostly)
     if (need_in) in_cur ^= 1;
     if (need_w) w_cur ^= 1;
     more = advance();
