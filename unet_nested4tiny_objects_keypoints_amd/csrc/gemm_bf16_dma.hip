@@ -680,7 +680,17 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
     if (want == 0) return 1;
     if (want == 4 || (want == 8 && d->taps == 9 && !stats && a.log2tw == 5)) form = want;
   }
-  if (!all && form == 4 && (d->taps != 9 || a.n_tiles != 1 || stats)) return 1;
+  // Round 4: plain 3x3 launches too small for the 8-wave form (the deep levels: 24 x 24 .. 96 x 96 images) take the 4-wave
+  // form as well instead of falling back to the register kernel: its 256-pixel x 32-column units are the finest the
+  // library has, and at these sizes the number of units per CU is what counts (288 / 144 / 80 units of the 8-wave shape
+  // for 256 CUs at levels 2-4 of configs[4]).  UNETPP_BF16_DMA_SMALL=0 restores the round-3 choice (A/B runs).
+  static const bool small_too = [] { const char* e = getenv("UNETPP_BF16_DMA_SMALL"); return e == nullptr || e[0] != '0'; }();
+  const bool small3x3 = small_too && d->taps == 9 && !stats && form == 4 && a.n_tiles > 1;
+  // BatchNorm-statistics launches with plain inputs (conv1 of the encoder levels >= 1) through the 4-wave statistics
+  // instantiation: +0.3 % on the configs[4] step, nothing at configs[3] (same box, alternating); =0 switches it off
+  static const bool stats_too = [] { const char* e = getenv("UNETPP_BF16_DMA_STATS"); return e == nullptr || e[0] != '0'; }();
+  const bool stats3x3 = stats_too && d->taps == 9 && stats && form == 4 && d->n_out == 1;
+  if (!all && !small3x3 && !stats3x3 && form == 4 && (d->taps != 9 || a.n_tiles != 1 || stats)) return 1;
   const unetpp_view& V0 = d->in[0];
   for (int i = 0; i < d->n_in; ++i) {
     const unetpp_view& v = d->in[i];
