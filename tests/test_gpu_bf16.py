@@ -115,6 +115,10 @@ def _both_kernels(fn, forms=(4, 0)):
     (2, 40, 64, (128,), 32),           # four chunks into one tile: the 8-wave form keeps the whole weight image in LDS
     (1, 24, 96, (64,), 64),            # two chunks x two tiles: resident, two tiles per staged patch
     (1, 50, 40, (32, 32, 32), 96),     # three tiles (one per unit), ragged 16-row patches
+    # more 512-pixel units than CUs, not a multiple of them: the 8-wave launch keeps its whole rounds and hands the
+    # patch rows behind them to a second launch of the 4-wave form (round 4, launch_gemm_bf16_dma; UNETPP_BF16_DMA_SPLIT=1)
+    (4, 192, 192, (32,), 64),          # 288 units: 252 stay, 6 patch rows -> 144 units of the 4-wave form
+    (2, 192, 256, (64, 64), 128),      # 384 units in two column groups: 256 stay, 8 patch rows -> 512 units
 ])
 @pytest.mark.parametrize("mode", ["relu", "stats", "dgrad"])
 def test_bf16_dma_and_register_kernels_agree(dev, b, h, w, cins, cout, mode):
@@ -151,7 +155,12 @@ def test_bf16_dma_and_register_kernels_agree(dev, b, h, w, cins, cout, mode):
                 part = torch.zeros(ops.gemm_pixel_blocks(b, h, w) * cout * 2, device=dev)
             ops.gemm_fwd(b, h, w, 9, [V(x) for x in xs], [V(y, relu=(mode == "relu"))], engine.pack_conv_fwd(wt), bias, part)
             return [y] + ([part] if part is not None else [])
-    (dma8, name8), (dma, dma_name), (reg, reg_name) = _both_kernels(run, forms=(8, 4, 0))
+    import os
+    os.environ["UNETPP_BF16_DMA_SPLIT"] = "1"    # (an experiment that is off by default; it only acts on the two large shapes)
+    try:
+        (dma8, name8), (dma, dma_name), (reg, reg_name) = _both_kernels(run, forms=(8, 4, 0))
+    finally:
+        os.environ.pop("UNETPP_BF16_DMA_SPLIT", None)
     assert name8 == dma_name == b"gemm_bf16_dma_kernel<9>" and reg_name == b"gemm_bf16_kernel<9>"
     bits = lambda t: t.view(torch.int16) if t.dtype == BF else t   # noqa: E731
     for a8, a_, b_ in zip(dma8, dma, reg):

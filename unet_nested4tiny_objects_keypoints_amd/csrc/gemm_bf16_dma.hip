@@ -82,6 +82,7 @@ struct DmaArgs {
   int img_pitch;    // bytes per image / 1 (Hs * Ws * C * 2), < 2^31
   int view_bytes;   // size of an input tensor in bytes
   int wimg_bytes;   // size of the launch's weight image in bytes (n_tiles * n_chunks * IMG)
+  int unit_base;    // first unit of this launch in the enumeration of its form (split launches: launch_gemm_bf16_dma)
 };
 
 // WAVES = 4: 256-pixel patches (8 x 32), two workgroups per CU (2 x 80 KB).  WAVES = 8: 512-pixel patches (16 x 32:
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, j = lane & 31, h = lane >> 5;
 
   constexpr bool CONTIG = TAPS == 9;  // (pointwise units are short and write strided phase views: round robin inside an XCD)
-  const UnitRange ur = CONTIG ? my_contiguous_unit_range(a.total_blocks) : my_unit_range(a.total_blocks);
+  UnitRange ur = CONTIG ? my_contiguous_unit_range(a.total_blocks) : my_unit_range(a.total_blocks);
+  ur.first += da.unit_base;
   const int my_units = __builtin_amdgcn_readfirstlane(static_cast<int>(ur.count));
   if (my_units == 0) return;
   long p_index = ur.first, c_index = ur.first;
@@ -674,7 +676,8 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
   if (cus <= 0) return UNETPP_ELAUNCH;
   // (the 8-wave form only when its 512-pixel units still cover the chip: the deepest layers of a small image do not)
   const long units8 = static_cast<long>(d->N) * ((d->H + 15) / 16) * a.tiles_x * ((a.n_tiles % 2 == 0) ? a.n_tiles / 2 : a.n_tiles);
-  if (d->taps == 9 && !stats && a.log2tw == 5 && (a.n_chunks > 1 || a.n_tiles > 1) && units8 >= 2L * cus) form = 8;
+  static const long min8 = [] { const char* e = getenv("UNETPP_BF16_DMA_MIN8"); return e != nullptr ? atol(e) : 2L; }();  // (A/B knob)
+  if (d->taps == 9 && !stats && a.log2tw == 5 && (a.n_chunks > 1 || a.n_tiles > 1) && units8 >= min8 * cus) form = 8;
   if (const char* e = getenv("UNETPP_BF16_DMA_FORM"); e != nullptr) {
     const int want = atoi(e);
     if (want == 0) return 1;
@@ -709,6 +712,7 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
   const long wimg_bytes = static_cast<long>(a.n_tiles) * a.n_chunks * (d->taps * 2 * DSTEP);
   if (wimg_bytes > 0x7fffffffL) return 1;
   da.wimg_bytes = static_cast<int>(wimg_bytes);
+  da.unit_base = 0;
   if (form == 8) {
     // 16 x 32 patches; two column tiles per unit when the launch has an even number of them
     const int nt = (a.n_tiles % 2 == 0) ? 2 : 1;
@@ -718,9 +722,52 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
     a.total_blocks = static_cast<long>(d->N) * a.tiles_y * a.tiles_x * a.n_groups;
     long workers = static_cast<long>(cus) & ~7L;  // one 8-wave workgroup per CU
     if (workers < 8) workers = 8;
-    const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(512);
-    if (nt == 2) hipLaunchKernelGGL((gemm_bf16_dma_kernel<9, 5, 2, false, 8>), grid, block, 0, st, da);
-    else hipLaunchKernelGGL((gemm_bf16_dma_kernel<9, 5, 1, false, 8>), grid, block, 0, st, da);
+    // Round 4: the tail.  Units are equal, every workgroup walks ceil(units / workers) of them, so 1152 units on 256 CUs
+    // (level 0 of configs[4]: 384 = 3 * 128) cost 5 rounds for 4.5 rounds of work, 576 units 3 for 2.25.  The whole rounds
+    // stay here; the patch ROWS behind them go to a second launch of the 4-wave form, whose 256-pixel x 32-column units are
+    // a quarter of the work each (a 16-row patch row here = two 8-row patch rows there, so the remainder is a contiguous
+    // unit range of that form as long as the split sits on a patch-row boundary and H is a multiple of 16).
+    // MEASURED AND LEFT OFF (UNETPP_BF16_DMA_SPLIT=1 turns it on; read per launch: the tests run it): configs[4] 10.41 ->
+    // 10.53 ms per step on one box, alternating.  Half (level 0) or a quarter (level 1) of the workgroups carry the extra
+    // unit, the others idle for ~10 % / ~25 % of the launch -- but the second launch's gap, prologue and weight re-staging
+    // cost more than that idle time gives back.
+    const char* split_env = getenv("UNETPP_BF16_DMA_SPLIT");
+    const bool split_tail = split_env != nullptr && split_env[0] == '1';
+    long units_here = a.total_blocks;
+    const long row8 = static_cast<long>(a.tiles_x) * a.n_groups;            // units of one 16-row patch row
+    if (split_tail && (d->H % 16) == 0 && a.total_blocks > workers) {
+      const long whole = (a.total_blocks / workers) * workers;
+      const long rows_here = whole / row8;
+      const long rest8 = a.total_blocks - rows_here * row8;                  // units of this form that move
+      const long units4 = rest8 / a.n_groups * 2 * a.n_tiles;                // two 8-row patches per patch, one tile per unit
+      const long workers4 = (2L * cus) & ~7L;
+      // cost in rounds of THIS form's unit time; a unit of the other form is a quarter of the work, priced at 0.35
+      const double now = static_cast<double>((a.total_blocks + workers - 1) / workers);
+      const double split = static_cast<double>((rows_here * row8 + workers - 1) / workers) +
+                           0.35 * static_cast<double>((units4 + workers4 - 1) / workers4);
+      if (rows_here > 0 && rest8 > 0 && split < 0.95 * now) units_here = rows_here * row8;
+    }
+    const long all_units = a.total_blocks;
+    a.total_blocks = units_here;
+    {
+      const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(512);
+      if (nt == 2) hipLaunchKernelGGL((gemm_bf16_dma_kernel<9, 5, 2, false, 8>), grid, block, 0, st, da);
+      else hipLaunchKernelGGL((gemm_bf16_dma_kernel<9, 5, 1, false, 8>), grid, block, 0, st, da);
+    }
+    if (units_here < all_units) {  // the tail: 8-row patches from patch row 2 * rows_here on, one column tile per unit
+      const long rows_here = units_here / row8;
+      a.nt_unit = 1;
+      a.n_groups = a.n_tiles;
+      a.tiles_y = (d->H + 7) / 8;
+      const long row4 = static_cast<long>(a.tiles_x) * a.n_groups;
+      const long total4 = static_cast<long>(d->N) * a.tiles_y * row4;
+      da.unit_base = static_cast<int>(2 * rows_here * row4);
+      a.total_blocks = total4 - da.unit_base;
+      long workers4 = (2L * cus) & ~7L;
+      if (workers4 < 8) workers4 = 8;
+      const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers4 ? a.total_blocks : workers4)), block(kThreads);
+      hipLaunchKernelGGL((gemm_bf16_dma_kernel<9, 5, 1, false>), grid, block, 0, st, da);
+    }
     note_kernel("gemm_bf16_dma_kernel<9>");
     return launch_status();
   }
