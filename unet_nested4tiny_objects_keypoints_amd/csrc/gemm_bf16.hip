@@ -42,6 +42,9 @@ __device__ unsigned long long g_gbf_stamps[16];
 #ifndef UNETPP_BF16_WGS
 #define UNETPP_BF16_WGS(TAPS, NT) (((NT) == 2 && (TAPS) == 9) ? 2 : 3)
 #endif
+#ifndef UNETPP_BF16_STATS_WGS   // workgroups per CU of the BatchNorm-statistics instantiations (3: 168 registers, 8-23 spilled)
+#define UNETPP_BF16_STATS_WGS 3
+#endif
 constexpr int BKC = 32;        // channels per K chunk
 constexpr int BPIX = 80;       // LDS bytes per staged pixel (64 + 16 pad)
 constexpr int BSTEP = 1024;    // bytes of one (tap, g) weight step: 32 columns x 16 k x 2 B
@@ -53,7 +56,7 @@ constexpr int BSTEP = 1024;    // bytes of one (tap, g) weight step: 32 columns 
 // v_permlane32_swap per register pair pairs the groups of lanes (j, 0) and (j, 1) into 8 consecutive channels, and
 // the tile leaves as two 16-byte stores per lane straight from registers -- no LDS round trip, no wave barriers.
 template <int TAPS, int LOG2TW, int NT, bool STATS>
-__global__ __launch_bounds__(kThreads, UNETPP_BF16_WGS(TAPS, NT)) void gemm_bf16_kernel(const FastArgs a) {
+__global__ __launch_bounds__(kThreads, STATS ? UNETPP_BF16_STATS_WGS : UNETPP_BF16_WGS(TAPS, NT)) void gemm_bf16_kernel(const FastArgs a) {
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
   constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;
   constexpr int HWp = TW + 2 * HALO, HHp = TH + 2 * HALO;
@@ -623,6 +626,7 @@ int launch_gemm_bf16(const unetpp_gemm_desc* d, hipStream_t st) {
   if (cus <= 0) return UNETPP_ELAUNCH;
   // = the kernels' launch bounds (four workgroups per CU for the pointwise GEMMs: 128 VGPRs, spills, 2x slower)
   long workers = ((d->taps == 9 && a.nt_unit == 2 ? 2L : 3L) * cus) & ~7L;
+  if (d->stats_partial != nullptr) workers = (static_cast<long>(UNETPP_BF16_STATS_WGS) * cus) & ~7L;
   if (workers < 8) workers = 8;
   const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(kThreads);
 #define UNETPP_LAUNCH_BF16(T, NTU, ST)                                                                    \

@@ -693,7 +693,11 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
   // instantiation: +0.3 % on the configs[4] step, nothing at configs[3] (same box, alternating); =0 switches it off
   static const bool stats_too = [] { const char* e = getenv("UNETPP_BF16_DMA_STATS"); return e == nullptr || e[0] != '0'; }();
   const bool stats3x3 = stats_too && d->taps == 9 && stats && form == 4 && d->n_out == 1;
-  if (!all && !small3x3 && !stats3x3 && form == 4 && (d->taps != 9 || a.n_tiles != 1 || stats)) return 1;
+  // the transposed-convolution GEMMs (pointwise, four phase views) through this kernel as well: +1 % on the configs[3]
+  // step, nothing at configs[4] (same box, alternating); UNETPP_BF16_DMA_POINTWISE=0 keeps them on the register kernel
+  const char* pw_env = getenv("UNETPP_BF16_DMA_POINTWISE");
+  const bool pointwise = !(pw_env != nullptr && pw_env[0] == '0') && d->taps == 1 && !stats;
+  if (!all && !small3x3 && !stats3x3 && !pointwise && form == 4 && (d->taps != 9 || a.n_tiles != 1 || stats)) return 1;
   const unetpp_view& V0 = d->in[0];
   for (int i = 0; i < d->n_in; ++i) {
     const unetpp_view& v = d->in[i];
