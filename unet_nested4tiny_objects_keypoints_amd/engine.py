@@ -26,6 +26,10 @@ USE_PACK_PLAN = os.environ.get("UNETPP_NO_PACK_PLAN") is None  # one batched wei
 # Input gradients of the dense skips grouped by PRODUCER (one GEMM per skip tensor over the concatenated dY of all its
 # consumers, written once) instead of by consumer (every consumer read-modify-writes a slice per input view).
 USE_GROUPED_DGRAD = os.environ.get("UNETPP_NO_GROUPED_DGRAD") is None
+# bf16 storage: encoder blocks whose first-stage tensor is at most this large write a1 = relu(bn(y1)) instead of folding it
+# into conv2's load (see _pair_fwd); 0 = never.  Same box, alternating: configs[4] 11.16 -> 10.98 ms per step at 80 MB (11.02
+# at 20-40 MB), configs[3] 7.37 -> 7.34-7.35 ms at 20-200 MB
+_A1_MATERIALIZE_BYTES = int(float(os.environ.get("UNETPP_BF16_A1_MAX_MB", "80")) * (1 << 20))
 
 
 # ----------------------------------------------------------------------------- weight re-layouts
@@ -158,9 +162,17 @@ def _pair_fwd(blk, ins: List[V], b, h, w, training, pool, adt=torch.float32) -> 
         r.y1 = new()
         r.bn1 = _conv_bn_fwd(ins, conv1, bn1, r.y1, b, h, w, training)
         # BatchNorm-apply + ReLU of the first stage is folded into the second convolution's operand load: the
-        # normalised activation a1 = relu(y1*scale + shift) is never written (r.a1 stays None)
+        # normalised activation a1 = relu(y1*scale + shift) is never written (r.a1 stays None).  bf16 storage, small
+        # tensors (round 4): a1 IS written -- the same fma and the same rounding the load transform applies, so the
+        # operands are bit-identical -- because a plain bf16 view lets conv2 and its weight gradient take the LDS-DMA /
+        # quad kernels, and below a few tens of MB the extra pass costs less than the register-staged kernels lose
         r.y2 = new()
-        r.bn2 = _conv_bn_fwd([V(r.y1, scale=r.bn1[2], shift=r.bn1[3], relu=True)], conv2, bn2, r.y2, b, h, w, training)
+        if adt == torch.bfloat16 and r.y1.numel() * 2 <= _A1_MATERIALIZE_BYTES:
+            r.a1 = new()
+            ops.affine_relu_pool(r.y1, r.bn1[2], r.bn1[3], True, r.a1, None, None)
+            r.bn2 = _conv_bn_fwd([V(r.a1)], conv2, bn2, r.y2, b, h, w, training)
+        else:
+            r.bn2 = _conv_bn_fwd([V(r.y1, scale=r.bn1[2], shift=r.bn1[3], relu=True)], conv2, bn2, r.y2, b, h, w, training)
         r.out = new()
         ops.affine_relu_pool(r.y2, r.bn2[2], r.bn2[3], True, r.out, r.pooled, r.pool_idx)
     else:
@@ -379,7 +391,10 @@ def _pair_bwd(blk, r: _PairRec, d_out, in_targets: Optional[List[V]], b, grads, 
         grads[bn2.weight], grads[bn2.bias] = dg, dbt
         dy2 = V(d_out)
         mean, invstd, scale, shift = r.bn1
-        _conv_wgrad(conv2, [V(r.y1, scale=scale, shift=shift, relu=True)], [dy2], b, h, w, grads)  # a1 on the fly
+        if r.a1 is not None:   # bf16 storage, small tensors: a1 was materialised in the forward pass
+            _conv_wgrad(conv2, [V(r.a1)], [dy2], b, h, w, grads)
+        else:
+            _conv_wgrad(conv2, [V(r.y1, scale=scale, shift=shift, relu=True)], [dy2], b, h, w, grads)  # a1 on the fly
         if flush is not None:
             flush()
         d_a1 = torch.empty_like(r.y1)
