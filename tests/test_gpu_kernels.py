@@ -527,6 +527,25 @@ def test_pool_argmax_and_routing_exact(dev, b, h, w, c, affine, relu):
     assert torch.equal(acc.permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize("b,h,w,c", [(2, 8, 16, 32), (1, 6, 10, 8), (1, 7, 9, 12), (2, 4, 8, 20)])
+def test_affine_relu_pool_without_winner_buffer(dev, b, h, w, c):
+    """unetpp_affine_relu_pool takes pool_idx = NULL (forward-only callers need no winners): the pooled
+    values and the activation are those of the call that records the winners -- row-structured, generic and odd-size
+    (floor) paths."""
+    from unet_nested4tiny_objects_keypoints_amd import ops
+    g = torch.Generator().manual_seed(19)
+    y = torch.randn(b, h, w, c, generator=g).to(dev)
+    scale, shift = (1 + 0.2 * torch.randn(c, generator=g)).to(dev), (0.3 * torch.randn(c, generator=g)).to(dev)
+    act0, act1 = torch.empty_like(y), torch.empty_like(y)
+    p0, p1 = (torch.empty(b, h // 2, w // 2, c, device=dev) for _ in range(2))
+    idx = torch.empty(b, h // 2, w // 2, c, dtype=torch.uint8, device=dev)
+    ops.affine_relu_pool(y, scale, shift, True, act0, p0, idx)
+    ops.affine_relu_pool(y, scale, shift, True, act1, p1, None)
+    assert torch.equal(act0, act1) and torch.equal(p0, p1)
+    ref = F.max_pool2d(act0.permute(0, 3, 1, 2), 2)
+    assert torch.equal(p1.permute(0, 3, 1, 2), ref)
+
+
 @pytest.mark.parametrize("b,h,w,c", [(2, 8, 16, 32), (1, 4, 64, 128), (3, 6, 10, 8), (2, 4, 8, 20)])
 def test_batchnorm_backward_with_pool_routing(dev, b, h, w, c):
     """bn_backward(pool=...) == maxpool_bwd into d_act followed by the plain bn_backward: the fused kernels where the
