@@ -19,6 +19,10 @@
 #include "common.h"
 #include "gemm_units.h"
 
+#ifndef UNETPP_FAST_PW_WGS   // workgroups per CU of the two-tile pointwise instantiation (A/B knob: tools/ab_lib.sh)
+#define UNETPP_FAST_PW_WGS 3
+#endif
+
 namespace unetpp {
 namespace {
 
@@ -27,7 +31,7 @@ constexpr int KC = 16;
 // NT = column tiles per unit.  3x3 convolutions use NT = 1 (3 workgroups per CU); the pointwise GEMMs of the 2x2
 // deconvolution (K = Cin only, N = 4*Cout) use NT = 2 so that one staged input patch feeds 64 columns.
 template <int TAPS, int LOG2TW, int NT>
-__global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : 3) : 3)) void gemm_fast_kernel(const FastArgs a) {
+__global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : UNETPP_FAST_PW_WGS) : 3)) void gemm_fast_kernel(const FastArgs a) {
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
   constexpr int TW = 1 << LOG2TW, TH = kBlockPixels >> LOG2TW;   // compile-time patch shape: every
   constexpr int HWp = TW + 2 * HALO, HHp = TH + 2 * HALO;        // division below is by a constant
@@ -396,7 +400,7 @@ int launch_gemm_fast(const unetpp_gemm_desc* d, hipStream_t st) {
   // persistent grid: at most 3 workgroups per CU (the kernel's LDS/VGPR budget), a multiple of 8
   const int cus = device_cu_count();
   if (cus <= 0) return UNETPP_ELAUNCH;
-  const long per_cu = (d->taps == 1 && a.nt_unit == 1) ? 4 : 3;  // = the kernel's launch bounds
+  const long per_cu = (d->taps == 1 && a.nt_unit == 1) ? 4 : (d->taps == 1 ? UNETPP_FAST_PW_WGS : 3);  // = the kernel's launch bounds
   long workers = (per_cu * cus) & ~7L;
   if (workers < 8) workers = 8;
   const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(kThreads);

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_bf16_kernel(const bf16_
 // DPP / ds_swizzle moves (xor_lane: the ds_bpermute shuffles of __shfl_xor made this kernel, like its fp32 twin,
 // instruction bound at a third of the HBM rate).  DROP: 0 = none, 1 = counter hash, 2 = mask tensor -- separate
 // instantiations keep the loop body straight-line.
-template <int LOG2CG, int DROP, int PCLS>  // PCLS = classes padded to 4 or 8: the class loops carry no n_cls branches
+template <int LOG2CG, int DROP, int PCLS>  // PCLS = classes padded to 4, 6 or 8 (5 key-point maps: configs[4]): the class loops carry no n_cls branches
 __global__ __launch_bounds__(kThreads) void head_fwd_bf16_kernel(const bf16_t* __restrict__ x, const float* __restrict__ weight,
                                                                  const float* __restrict__ bias, long pixels, int HW,
                                                                  int n_cls, float keep_scale, uint32_t thr16,
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kThreads) void head_fwd_bf16_kernel(const bf16_t* _
 // (the first version read 32 weights from LDS per octet); the (class, channel) pairs of the weight-gradient pass are
 // decoded once; DROP (0 none, 1 counter hash, 2 mask tensor) keeps the piece loop free of per-element branches.
 constexpr int kHeadTilePixels = 256;
-template <int LOG2CG, int DROP, int PCLS>  // PCLS = classes padded to 4 or 8: the class loops carry no n_cls branches
+template <int LOG2CG, int DROP, int PCLS>  // PCLS = classes padded to 4, 6 or 8 (5 key-point maps: configs[4]): the class loops carry no n_cls branches
 __global__ __launch_bounds__(kThreads) void head_bwd_bf16_kernel(const float* __restrict__ d_out, const float* __restrict__ outp,
                                                                  const bf16_t* __restrict__ x, const float* __restrict__ weight,
                                                                  unsigned pixels, unsigned HW, int n_cls, float keep_scale,
@@ -637,6 +637,7 @@ extern "C" int unetpp_head_fwd_bf16(const void* x, const float* weight, const fl
 #define UNETPP_HEAD_BF_D(L, D)            \
   do {                                    \
     if (n_cls <= 4) UNETPP_HEAD_BF(L, D, 4); \
+    else if (n_cls <= 6) UNETPP_HEAD_BF(L, D, 6); \
     else UNETPP_HEAD_BF(L, D, 8);         \
   } while (0)
 #define UNETPP_HEAD_BF_L(L)              \
@@ -675,6 +676,7 @@ extern "C" int unetpp_head_bwd_bf16(const float* d_out_nchw, const float* out_nc
 #define UNETPP_HEAD_BWD_BF(L, D)                                    \
   do {                                                              \
     if (n_cls <= 4) UNETPP_HEAD_BWD_BF_P(L, D, 4);                  \
+    else if (n_cls <= 6) UNETPP_HEAD_BWD_BF_P(L, D, 6);             \
     else UNETPP_HEAD_BWD_BF_P(L, D, 8);                             \
   } while (0)
 #define UNETPP_HEAD_BWD_BF_P(L, D, PC)                                                                                 \
