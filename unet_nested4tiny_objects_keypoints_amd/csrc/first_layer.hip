@@ -52,9 +52,12 @@ __device__ __forceinline__ void stage_patch(const SmallArgs& a, float* xs, int n
 // in registers when there is one input channel; the BatchNorm partial sums are reduced with lane shuffles inside a
 // wave and in fixed order across the four waves.
 template <int CIN, bool BF = false>
-__global__ __launch_bounds__(kThreads) void small_cin_fwd_kernel(const SmallArgs a) {
+__global__ __launch_bounds__(kThreads, CIN >= 3 ? 3 : 4) void small_cin_fwd_kernel(const SmallArgs a) {
   constexpr int ITEMS = (kMaxHaloPixels * CIN + kThreads - 1) / kThreads;
-  constexpr bool WREG = CIN == 1;
+  // weights of this thread's four output channels in registers: 9 * CIN float4.  (Round 4: also for 2 and 3 input channels
+  // -- from LDS the 27 16-byte weight reads per pixel and thread of the 3-channel layer kept the LDS array busier than the
+  // VALU: 110 us for the 82 MB of configs[4]'s first layer.)
+  constexpr bool WREG = CIN <= 3;
   __shared__ float xs2[2][kMaxHaloPixels * CIN];
   __shared__ __attribute__((aligned(16))) float ws[WREG ? 4 : 9 * CIN * kMaxCout];
   __shared__ float red[4][kMaxCout * 2];  // [wave][quad][s1 x 4, s2 x 4]
@@ -92,10 +95,10 @@ __global__ __launch_bounds__(kThreads) void small_cin_fwd_kernel(const SmallArgs
     }
   };
 
-  f32x4 wr[WREG ? 9 : 1];
+  f32x4 wr[WREG ? 9 * CIN : 1];
   if (WREG) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) wr[tap] = *reinterpret_cast<const f32x4*>(a.w + tap * a.COUT + 4 * quad);
+    for (int t = 0; t < 9 * CIN; ++t) wr[WREG ? t : 0] = *reinterpret_cast<const f32x4*>(a.w + t * a.COUT + 4 * quad);
   } else {
     for (int i = tid; i < 9 * CIN * a.COUT; i += kThreads) ws[i] = a.w[i];
   }
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(kThreads) void small_cin_fwd_kernel(const SmallArgs
 #pragma unroll
           for (int ci = 0; ci < CIN; ++ci) {
             const f32x2_t xv = {xp[ci], xp[ci]};
-            const f32x4 w4 = WREG ? wr[WREG ? tap : 0]
+            const f32x4 w4 = WREG ? wr[WREG ? tap * CIN + ci : 0]
                                   : *reinterpret_cast<const f32x4*>(&ws[WREG ? 0 : (tap * CIN + ci) * a.COUT + 4 * quad]);
             acc_a = __builtin_elementwise_fma(xv, f32x2_t{w4[0], w4[1]}, acc_a);
             acc_b = __builtin_elementwise_fma(xv, f32x2_t{w4[2], w4[3]}, acc_b);
@@ -376,7 +379,7 @@ int launch_small_cin_fwd(const unetpp_gemm_desc* d, hipStream_t st) {
   if (cus <= 0) return UNETPP_ELAUNCH;
   // persistent grid: as many workgroups as are resident at once (<= 128 registers up to three input channels, 156
   // with four: four / three one-wave-per-SIMD workgroups per CU)
-  long workers = static_cast<long>(cus) * (X.C == 4 ? 3 : 4);
+  long workers = static_cast<long>(cus) * (X.C >= 3 ? 3 : 4);   // = the kernel's launch bounds
   if (workers > kBnFusedRows) workers = kBnFusedRows;
   const dim3 grid(static_cast<unsigned>(a.n_patches < workers ? a.n_patches : workers)), block(kThreads);
   a.bn_in_kernel = bn_rows_per_workgroup(d, a.COUT) ? 1 : 0;
