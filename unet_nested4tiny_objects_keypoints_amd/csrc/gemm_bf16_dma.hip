@@ -667,8 +667,10 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
   // UNETPP_BF16_DMA_ALL=1 lifts the restrictions: the tests run every shape class through both kernels):
   //   8 waves, 512-pixel patches   plain 3x3 launches on images at least 32 wide with more than one chunk or column tile
   //   4 waves, 256-pixel patches   3x3 launches of ONE chunk into ONE tile (32 -> 32: its image is resident either way
-  //                                and two independent workgroups per CU overlap better), statistics launches never
-  //   neither (gemm_bf16.hip)      BatchNorm-statistics launches, load transforms, the pointwise GEMMs
+  //                                and two independent workgroups per CU overlap better); since round 4 also: plain 3x3
+  //                                launches too small for the 8-wave form, BatchNorm-statistics launches with plain inputs,
+  //                                the pointwise GEMMs (see the switches below)
+  //   neither (gemm_bf16.hip)      load transforms (BatchNorm fold / ReLU / gate on load), unaligned channel slices
   const bool all = getenv("UNETPP_BF16_DMA_ALL") != nullptr;
   const bool stats = d->stats_partial != nullptr;
   int form = 4;
@@ -677,6 +679,7 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
   // (the 8-wave form only when its 512-pixel units still cover the chip: the deepest layers of a small image do not)
   const long units8 = static_cast<long>(d->N) * ((d->H + 15) / 16) * a.tiles_x * ((a.n_tiles % 2 == 0) ? a.n_tiles / 2 : a.n_tiles);
   static const long min8 = [] { const char* e = getenv("UNETPP_BF16_DMA_MIN8"); return e != nullptr ? atol(e) : 2L; }();  // (A/B knob)
+  // (one-chunk one-tile launches in the 8-wave form as well: 0 .. +2 % on the configs[3] step depending on the box, not taken)
   if (d->taps == 9 && !stats && a.log2tw == 5 && (a.n_chunks > 1 || a.n_tiles > 1) && units8 >= min8 * cus) form = 8;
   if (const char* e = getenv("UNETPP_BF16_DMA_FORM"); e != nullptr) {
     const int want = atoi(e);
