@@ -91,3 +91,41 @@ def test_bench_spawns_its_ranks_and_propagates_failure():
     assert r.returncode != 0
     assert "rank exit codes" in r.stderr and "bench.py needs a GPU" in r.stderr
     assert r.stderr.count("bench.py needs a GPU") == 2   # both ranks were started
+
+
+def test_graphed_train_step_refuses_cpu_tensors_and_eval_models():
+    """graph.GraphedTrainStep has no CPU form (this path has no CPU fallback): CPU tensors and eval-mode models are
+    refused up front, before anything touches the library."""
+    import torch
+
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, GraphedTrainStep, UNet_Nested
+    m = UNet_Nested(in_channels=1, n_classes=4, feature_scale=8).train()
+    opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+    x, t = torch.randn(1, 1, 32, 32), torch.rand(1, 4, 32, 32)
+    with pytest.raises(RuntimeError, match="GPU"):
+        GraphedTrainStep(m, opt, crit, x, t)
+
+
+def test_bench_other_configs_name_the_baseline_configurations():
+    """bench.py's default run attaches BASELINE.json's configs[3] and configs[4] (as single-GPU geometries) to the headline
+    line; the table that says which is host logic."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    names = [n for n, _ in bench.OTHER_CONFIGS]
+    assert names[0].startswith("configs[3]") and names[1].startswith("configs[4]")
+    c3, c4 = bench.OTHER_CONFIGS[0][1], bench.OTHER_CONFIGS[1][1]
+    assert (c3["dtype"], c3["size"], c3["depth"], c3["in_channels"], c3["n_classes"]) == ("bf16", 512, 4, 1, 4)
+    assert (c4["dtype"], c4["size"], c4["depth"], c4["in_channels"], c4["n_classes"], c4["feature_scale"]) == ("bf16", 384, 5, 3, 5, 0.5)
+    base = json.load(open(os.path.join(root, "BASELINE.json")))["configs"]
+    assert "512" in base[3] and "bf16" in base[3] and "384" in base[4] and "depth=5" in base[4]
+    import argparse
+    ns = argparse.Namespace(dtype="f32", size=256, batch=32, feature_scale=1, depth=4, in_channels=1, n_classes=4)
+    assert bench.is_headline(ns)
+    ns.batch = 8
+    assert not bench.is_headline(ns)     # other shapes asked for on the command line stay single-configuration runs
