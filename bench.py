@@ -23,9 +23,13 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 `frac` = achieved / dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md) -- a fraction of a
                 hardware limit, <= 1.  For the Winograd kernels the executed work is 16/36 of the algorithmic
                 2*9*Cin*Cout per pixel; the algorithmic rate is reported beside it (`achieved_algorithmic`).
-                `traffic` (HBM bytes per launch from PMC counters) cannot be collected from inside the process: it is
-                read from profiles/pmc_hbm_traffic_latest.json when that file was made from THIS build (build hash),
-                next to `traffic_algorithmic` (every operand read/written once) and their ratio.
+                `traffic` (HBM bytes per launch from PMC counters) cannot be collected from inside the process: the
+                default single-GPU run of the headline workload therefore starts, BEFORE it touches the GPU itself,
+                three short children of this script per configuration under `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE,
+                SQ/GRBM: separate passes, 3 train steps each; ~3 s per pass) and summarises them with tools/pmc_traffic.py (`traffic_source`: "live");
+                without rocprofv3, for other workloads or with --no-live-pmc the numbers are read from
+                profiles/pmc_hbm_traffic_latest.json when that file was made from THIS build (build hash).  Beside
+                it `traffic_algorithmic` (every operand read/written once) and their ratio.
   roofline_x00  the X_0,0 conv block forward (1.2457 GFLOP and 42.2 MB algorithmic per image):
                 frac = max(compute floor, HBM floor) / measured block time.
   other_configs the default run (the headline workload) then times BASELINE configs[3] (512x512, bf16 storage, batch 8) and
@@ -70,6 +74,9 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the bf16 configurations (BASELINE configs[3], configs[4]) the default run times after the "
                          "headline and attaches under `other_configs`")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not run the rocprofv3 --pmc passes the default single-GPU headline run starts before its own "
+                         "measurement (roofline.traffic / mfma_busy_pmc then come from profiles/pmc_hbm_traffic_latest.json)")
     ap.add_argument("--other-steps", type=int, default=30, help="timed steps of each `other_configs` entry (>= 20)")
     ap.add_argument("--graphed", action="store_true",
                     help="replay the step from a HIP graph (GraphedTrainStep; single GPU).  The default run uses it for "
@@ -114,30 +121,85 @@ def config_key(args):
     return "%s_d%d_fs%s_s%d_b%d_i%d_c%d" % (args.dtype, args.depth, fs, args.size, args.batch, args.in_channels, args.n_classes)
 
 
-def pmc_counters(kernel_label, build_hash, cfg_key):
-    """(HBM bytes per launch, matrix-pipe occupancy) of the dominant kernel from the committed PMC summary of THIS
-    configuration (counters cannot be read from inside the process: tools/pmc_traffic.py makes the file from separate
-    rocprofv3 --pmc passes of this command).  A summary stamped with another build's hash is refused (None, None): it
-    describes other kernels."""
-    path = os.path.join(ROOT, "profiles", "pmc_hbm_traffic_latest.json")
+_LIVE_PMC = {}   # config key -> summary made by live_pmc() in this run
+
+
+def live_pmc(args):
+    """PMC passes of THIS run (single GPU, before this process touches the GPU: the children are separate programs
+    started under the profiler, `python3 bench.py ...` directly behind `--`).  Three passes as MI355X_MICROARCH.md
+    prescribes for the TCC counters (FETCH_SIZE and WRITE_SIZE apart) plus one SQ/GRBM pass for the matrix-pipe
+    occupancy, each over 3 train steps of the configuration; tools/pmc_traffic.py applies the guide's unit and gfx950
+    corrections.  Any failure (no rocprofv3, a pass that times out or leaves no counter file) returns None and the
+    committed summary is used instead -- the measurement itself never depends on the profiler."""
+    import contextlib
+    import io
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="unetpp_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--prewarm", "0",
+             "--no-cpu-baseline", "--no-launch-timing", "--no-other-configs", "--no-live-pmc",
+             "--dtype", args.dtype, "--size", str(args.size), "--batch", str(args.batch), "--depth", str(args.depth),
+             "--feature-scale", str(args.feature_scale), "--in-channels", str(args.in_channels),
+             "--n-classes", str(args.n_classes)]
+    passes = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES"]))
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.time()
     try:
-        with open(path) as f:
-            doc = json.load(f)["configs"][cfg_key]
-        rows = doc["kernels"]
-    except (OSError, ValueError, KeyError):
-        return None, None
+        for name, counters in passes:
+            out = os.path.join(tmp, name)
+            cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "-o", "p", "--"] + child
+            with open(os.path.join(tmp, name + ".log"), "w") as log:
+                rc = subprocess.run(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT,
+                                    timeout=float(os.environ.get("UNETPP_BENCH_PMC_TIMEOUT", "240"))).returncode
+            if rc != 0 or not os.path.exists(os.path.join(out, "p_counter_collection.csv")):
+                return None
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_traffic
+        summary = os.path.join(tmp, "summary.json")
+        with contextlib.redirect_stdout(io.StringIO()):
+            pmc_traffic.main(os.path.join(tmp, "fetch"), os.path.join(tmp, "write"), summary, config_key(args),
+                             os.path.join(tmp, "sq"))
+        with open(summary) as f:
+            doc = json.load(f)["configs"][config_key(args)]
+        doc["seconds"] = round(time.time() - t0, 1)
+        return doc
+    except Exception as exc:   # the profiler is an extra: never the reason for a missing bench line
+        print("live PMC passes failed (%s: %s): using the committed summary" % (type(exc).__name__, exc), file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_counters(kernel_label, build_hash, cfg_key):
+    """(HBM bytes per launch, matrix-pipe occupancy, source) of the dominant kernel: from the rocprofv3 --pmc passes this
+    run made itself (live_pmc), else from the committed PMC summary of THIS configuration (tools/pmc_traffic.py made it
+    from the same three passes of this command).  A summary stamped with another build's hash is refused: it describes
+    other kernels."""
+    doc, source = _LIVE_PMC.get(cfg_key), "live: rocprofv3 --pmc passes started by this run (3 train steps each)"
+    if doc is None:
+        path, source = os.path.join(ROOT, "profiles", "pmc_hbm_traffic_latest.json"), "profiles/pmc_hbm_traffic_latest.json (same build hash)"
+        try:
+            with open(path) as f:
+                doc = json.load(f)["configs"][cfg_key]
+        except (OSError, ValueError, KeyError):
+            return None, None, None
+    rows = doc.get("kernels", [])
     if doc.get("build_hash") != build_hash:
-        return None, None
+        return None, None, None
     stem = kernel_label.rstrip(">")  # "gemm_fast_kernel<9" matches "gemm_fast_kernel<9, 5, 1>"
     hits = [r for r in rows if r["kernel"].startswith(stem)]
     n = sum(r["launches"] for r in hits)
     if n == 0:
-        return None, None
+        return None, None, None
     traffic = round(sum((r["fetch_bytes_x2_per_launch"] + r["write_bytes_per_launch"]) * r["launches"] for r in hits) / n)
     busy = [(r["sq"]["mfma_busy"] * r["sq"]["avg_us"] * r["sq"]["dispatches"], r["sq"]["avg_us"] * r["sq"]["dispatches"])
             for r in hits if "sq" in r and "mfma_busy" in r["sq"]]
     mfma_busy = round(sum(b for b, _ in busy) / sum(t for _, t in busy), 4) if busy else None   # time-weighted
-    return traffic, mfma_busy
+    return traffic, mfma_busy, source
 
 
 def cpu_baseline(args, n_cls):
@@ -315,7 +377,7 @@ def other_entry(name, o, r, world):
     roof = r["roofline"]
     if roof is not None:
         roof = {k: roof[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_algorithmic",
-                                      "traffic_over_algorithmic", "mfma_busy_pmc", "avg_launch_ms", "launches_per_step",
+                                      "traffic_over_algorithmic", "mfma_busy_pmc", "traffic_source", "avg_launch_ms", "launches_per_step",
                                       "floor_hbm_ms", "floor_mfma_ms", "instrumented_steps_after_timed_region") if k in roof}
     kern = r["kernels"]
     if kern is not None:  # the five kernels with the most device time
@@ -468,7 +530,7 @@ def measure(args, ctx):
         wino = dom[0].startswith("gemm_wino") or dom[0].startswith("wgrad_wino")
         executed = alg / 2.25 if wino else alg
         from unet_nested4tiny_objects_keypoints_amd import _lib as _l
-        traffic, mfma_busy = pmc_counters(dom[0], _l.source_hash(), config_key(args))
+        traffic, mfma_busy, pmc_source = pmc_counters(dom[0], _l.source_hash(), config_key(args))
         traffic_alg = dom[1]["bytes"] / dom[1]["launches"]
         roofline = {"kernel": dom[0], "bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4),
@@ -480,9 +542,11 @@ def measure(args, ctx):
                     "traffic_algorithmic": round(traffic_alg),
                     "traffic_over_algorithmic": None if traffic is None else round(traffic / traffic_alg, 3),
                     "mfma_busy_pmc": mfma_busy,
+                    "traffic_source": pmc_source,
                     "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes "
-                                    "of this command; profiles/pmc_hbm_traffic_latest.json, null when that file is "
-                                    "from another build); traffic_algorithmic = 4 B (bf16 storage: 2 B) x (Cin + Cout) x pixels, plus the "
+                                    "of this command: started by this run itself (traffic_source live), else read from "
+                                    "profiles/pmc_hbm_traffic_latest.json -- null when that file is from another build); "
+                                    "traffic_algorithmic = 4 B (bf16 storage: 2 B) x (Cin + Cout) x pixels, plus the "
                                     "accumulated outputs and ReLU gates an input-gradient launch has to read; mfma_busy_pmc = "
                                     "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) from a third pass",
                     "launches_per_step": dom[1]["launches"] / sampled_steps,
@@ -528,6 +592,17 @@ def main():
         return spawn_ranks(args)
     if args.rehearse_cpu:
         return rehearse_cpu(args)
+    under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(
+        k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)   # this process is itself being profiled: no nesting
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and is_headline(args) and not args.no_live_pmc
+            and not args.no_launch_timing and not under_profiler and os.environ.get("UNETPP_BENCH_LIVE_PMC", "1") != "0"):
+        # children under rocprofv3, finished before this process initialises the GPU; the two other configurations too
+        todo = [args] + ([] if args.no_other_configs else [argparse.Namespace(**dict(vars(args), **over)) for _, over in OTHER_CONFIGS])
+        for cfg in todo:
+            doc = live_pmc(cfg)
+            if doc is None:
+                break   # no profiler here (or it failed once): the committed summary serves all of them
+            _LIVE_PMC[config_key(cfg)] = doc
     import torch
     import torch.distributed as dist
 
@@ -555,9 +630,12 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    import contextlib
+
     import __graft_entry__ as entry
     if rank == 0:
-        entry.build()
+        with contextlib.redirect_stdout(sys.stderr):   # stdout carries the ONE JSON line and nothing else
+            entry.build()
     if distributed:
         dist.barrier()
 
