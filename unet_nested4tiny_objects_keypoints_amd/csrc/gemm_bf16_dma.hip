@@ -38,6 +38,9 @@
 //   * the ten DMA pieces of a chunk issued one behind each MFMA step instead of as a block in front of them: -1 % on the
 //     forward GEMMs of configs[4], 0 / +2 % elsewhere, 256 registers + scratch.  Not kept;
 //   * a second chunk of DMA in flight (experiment build): no change; non-temporal output stores: 5-30 % slower.
+//   * deferred output stores for the forward launches (no gate / accumulate operands: their 64 registers hold the packed
+//     tile, whose eight store instructions are issued one behind every second MFMA step of the NEXT chunk): 1.4-1.9 %
+//     SLOWER on both bf16 steps -- once more: what a CU's memory path moves per unit is the bound, not when it moves it.
 // tools/dma_stamps.py (stamped build): per 32-channel chunk of [64 x 5] -> 64 at 384 x 384 x 4 wave 0 spends 600 cycles in
 // the cursor, 1 860 issuing its ten DMA pieces, 2 650 in LDS reads + MFMAs, 435 in the epilogue (per-chunk average) and
 // 2 450 in the barrier, most of which is the second wave of its SIMD running ITS MFMAs; without the epilogue the barrier
