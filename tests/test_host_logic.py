@@ -129,3 +129,37 @@ def test_bench_other_configs_name_the_baseline_configurations():
     assert bench.is_headline(ns)
     ns.batch = 8
     assert not bench.is_headline(ns)     # other shapes asked for on the command line stay single-configuration runs
+
+
+def test_bench_live_pmc_falls_back_without_a_gpu(tmp_path):
+    """bench.live_pmc() starts children of bench.py under `rocprofv3 --pmc` before the benchmark touches the GPU.  Whatever goes
+    wrong there (here: no GPU, so the first child exits non-zero; elsewhere: no rocprofv3, a timeout) must cost only the
+    live counters -- the function returns None, leaves no scratch directory behind, and pmc_counters() then serves the
+    committed summary if and only if it was made from this build."""
+    import argparse
+    import glob
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module_pmc", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ns = argparse.Namespace(dtype="f32", size=256, batch=32, feature_scale=1, depth=4, in_channels=1, n_classes=4)
+    before = set(glob.glob("/tmp/unetpp_pmc_*"))
+    os.environ["UNETPP_BENCH_PMC_TIMEOUT"] = "120"
+    try:
+        assert bench.live_pmc(ns) is None
+    finally:
+        os.environ.pop("UNETPP_BENCH_PMC_TIMEOUT", None)
+    assert set(glob.glob("/tmp/unetpp_pmc_*")) == before
+    key = bench.config_key(ns)
+    assert key == "f32_d4_fs1_s256_b32_i1_c4"
+    assert bench.pmc_counters("gemm_wino_kernel", "not-a-build-hash", key) == (None, None, None)
+    bench._LIVE_PMC[key] = {"build_hash": "h", "kernels": [
+        {"kernel": "gemm_wino_kernel<5, 2, 1, false>", "launches": 3, "fetch_bytes_x2_per_launch": 100, "write_bytes_per_launch": 20,
+         "sq": {"mfma_busy": 0.5, "avg_us": 10.0, "dispatches": 3}},
+        {"kernel": "gemm_wino_kernel<5, 2, 2, true>", "launches": 1, "fetch_bytes_x2_per_launch": 60, "write_bytes_per_launch": 20,
+         "sq": {"mfma_busy": 0.25, "avg_us": 10.0, "dispatches": 1}}]}
+    traffic, busy, source = bench.pmc_counters("gemm_wino_kernel", "h", key)
+    assert traffic == round((120 * 3 + 80) / 4) and abs(busy - (0.5 * 30 + 0.25 * 10) / 40) < 1e-4 and source.startswith("live")
+    assert bench.pmc_counters("gemm_wino_kernel", "other", key) == (None, None, None)   # a live summary of another build: refused too
