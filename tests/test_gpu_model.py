@@ -216,15 +216,18 @@ def test_train_step_vs_oracle(dev, case):
             assert rel_err(bh.cpu(), br) < TOL, k
 
 
-def test_benchmarked_batch32_forward_vs_float64_oracle(dev):
+def test_benchmarked_batch32_train_step_vs_float64_oracle(dev):
     """The BENCHMARKED configuration end to end, once: BASELINE configs[1] (base 32, 256 x 256) at batch 32 -- 2.1e6
     values per BatchNorm channel at level 0, 8192 patches per launch, the persistent kernels' per-workgroup statistics
-    rows over the full batch.  Train-mode forward (dropout off), loss and the BatchNorm running statistics of all eight
-    encoder layers against the pinned oracle evaluated in float64 (forward only: its backward at this size takes
-    minutes; gradients are covered at batch 4 above and, for the X_0,0 block, at batch 32 in test_gpu_x00_block.py).
-    models/unet.py:255-300."""
+    rows over the full batch, 8.5e8 ReLU gates.  Train-mode forward (dropout off), loss, the BatchNorm running
+    statistics of all sixteen encoder layers AND every parameter gradient against the pinned oracle evaluated in float64,
+    its backward taken with the HIP forward's ReLU gates / pool winners as in test_train_step_vs_oracle (~200 of the
+    8.5e8 gates sit within rounding of zero and differ from the oracle's own).  The oracle needs ~80 s of the box's host
+    cores for this; tests/batch32_backward_experiment.py is the same run as a script with a progress line.
+    models/unet.py:255-300, trainer/trainer.py:114-136."""
     from oracle.step_oracle import focal_bce_2d_oracle
     from oracle.unet_nested_oracle import UNetNestedOracle
+    from tests.helpers import check_flips, install_hip_gates
     ctor, b, h, w = dict(in_channels=1, n_classes=4, feature_scale=1), 32, 256, 256
     torch.manual_seed(13)
     ref = UNetNestedOracle(**ctor).train()
@@ -232,19 +235,26 @@ def test_benchmarked_batch32_forward_vs_float64_oracle(dev):
     state = {k: v.clone() for k, v in ref.state_dict().items()}
     m = _hip_model(ctor, state, dev).train()
     m.drop_out.eval()
+    m._debug_keep_saved = True
     x, target = torch.randn(b, 1, h, w), torch.rand(b, 4, h, w)
-    with torch.no_grad():
-        outs = m(x.to(dev))
-        loss = float(_loss(outs, target.to(dev)))
-        torch.cuda.synchronize()
-        ref = ref.double()
-        ro = ref(x.double())
-        rl = float(sum(focal_bce_2d_oracle(o, target.double()) for o in ro) / len(ro))
+    outs = m(x.to(dev))
+    loss = _loss(outs, target.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    ref = ref.double()
+    gated = install_hip_gates(ref, m._debug_saved)
+    ro = ref(x.double())
+    rl = sum(focal_bce_2d_oracle(o, target.double()) for o in ro) / len(ro)
+    rl.backward()
+    flips = check_flips(gated, "configs[1] at batch 32")
+    assert flips < 1e-5 * 8.5e8   # a handful per million at most: anything more is a wrong value, not a rounding
     assert len(outs) == len(ro) == 3
     for o, r in zip(outs, ro):
         assert tuple(o.shape) == (b, 4, h, w)
-        assert rel_err(o.cpu(), r) < TOL
-    assert abs(loss - rl) <= 1e-5 * abs(rl), (loss, rl)
+        assert rel_err(o.detach().cpu(), r.detach()) < TOL
+    assert abs(float(loss.detach()) - float(rl)) <= 1e-5 * abs(float(rl)), (float(loss.detach()), float(rl))
+    assert_grads_close({k: p.grad.cpu() for k, p in m.named_parameters()}, {k: p.grad for k, p in ref.named_parameters()},
+                       ctor, TOL)
     n_stats = 0
     for (k, bh), (_, br) in zip(m.named_buffers(), ref.named_buffers()):
         if bh.dtype.is_floating_point:
