@@ -4,7 +4,10 @@ backward pass of the HIP model against the pinned CPU oracle in float64 whose ba
 and pool winners (tests/helpers.install_hip_gates), exactly what tests/test_gpu_model.py::test_train_step_vs_oracle does
 at batch 4.  Every parameter gradient must meet the suite's tolerance (tests/helpers.assert_grads_close, TOL = 1e-4).
 
-    python tests/batch32_backward_experiment.py [batch]     -> gpurun_out/batch32_backward_vs_float64.json
+    python tests/batch32_backward_experiment.py [batch] [c2|c3|c5]   -> gpurun_out/batch32_backward_vs_float64[_c3|_c5].json
+
+c3 / c5: the same in fp32 at the geometry AND batch of BASELINE configs[3] (512 x 512, batch 8) / configs[4] (depth 5, base
+64, 3 -> 5 channels, 384 x 384, batch 4) -- the suite runs those geometries at batch 1.
 
 models/unet.py:255-300, trainer/trainer.py:114-136."""
 import json
@@ -29,8 +32,11 @@ def main():
     from oracle.unet_nested_oracle import UNetNestedOracle
     from tests.helpers import check_flips, install_hip_gates, is_pre_bn_bias, rel_err
     from tests.test_gpu_model import TOL, _hip_model, _loss
-    b = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-    ctor, h, w = dict(in_channels=1, n_classes=4, feature_scale=1), 256, 256
+    cfg = sys.argv[2] if len(sys.argv) > 2 else "c2"
+    ctor, h, w, b0 = {"c2": (dict(in_channels=1, n_classes=4, feature_scale=1), 256, 256, 32),
+                      "c3": (dict(in_channels=1, n_classes=4, feature_scale=1), 512, 512, 8),
+                      "c5": (dict(in_channels=3, n_classes=5, feature_scale=0.5, depth=5), 384, 384, 4)}[cfg]
+    b = int(sys.argv[1]) if len(sys.argv) > 1 and int(sys.argv[1]) > 0 else b0
     dev = torch.device("cuda", 0)
     t0 = time.time()
     stop = threading.Event()
@@ -42,7 +48,7 @@ def main():
     m = _hip_model(ctor, state, dev).train()
     m.drop_out.eval()
     m._debug_keep_saved = True
-    x, target = torch.randn(b, 1, h, w), torch.rand(b, 4, h, w)
+    x, target = torch.randn(b, ctor["in_channels"], h, w), torch.rand(b, ctor["n_classes"], h, w)
     outs = m(x.to(dev))
     loss = _loss(outs, target.to(dev))
     loss.backward()
@@ -68,7 +74,8 @@ def main():
         rows[k] = {"max_rel": e, "l2_rel": l2}
         if e > worst[1]:
             worst = (k, e)
-    res = {"configuration": "configs[1]: base 32, 256x256, batch %d, fp32, train mode (dropout off), FocalLoss_BCE_2d on 3 heads" % b,
+    res = {"configuration": "%s geometry: %s, %dx%d, batch %d, fp32, train mode (dropout off), FocalLoss_BCE_2d on every head" % (
+               {"c2": "configs[1]", "c3": "configs[3]", "c5": "configs[4]"}[cfg], sorted(ctor.items()), h, w, b),
            "oracle": "UNetNestedOracle in float64, backward with the HIP forward's ReLU gates / pool winners",
            "relu_gate_or_pool_flips_vs_the_oracles_own": int(flips), "outputs_max_rel": out_err,
            "loss_hip": float(loss), "loss_oracle": float(rl), "loss_rel": abs(float(loss) - float(rl)) / abs(float(rl)),
@@ -76,7 +83,7 @@ def main():
            "worst_gradient_l2": max(v["l2_rel"] for v in rows.values()), "tolerance": TOL,
            "within_tolerance": bool(worst[1] < TOL and out_err < TOL), "seconds": round(time.time() - t0, 1)}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "batch32_backward_vs_float64.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "batch32_backward_vs_float64%s.json" % ("" if cfg == "c2" else "_" + cfg)), "w") as f:
         json.dump({"summary": res, "per_parameter": rows}, f, indent=1)
     print(json.dumps(res))
     if not res["within_tolerance"]:
