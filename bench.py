@@ -153,8 +153,19 @@ def live_pmc(args):
             out = os.path.join(tmp, name)
             cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "-o", "p", "--"] + child
             with open(os.path.join(tmp, name + ".log"), "w") as log:
-                rc = subprocess.run(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT,
-                                    timeout=float(os.environ.get("UNETPP_BENCH_PMC_TIMEOUT", "240"))).returncode
+                # own session: a pass that runs into the timeout is ended as a GROUP (profiler AND the benchmark child
+                # under it), so nothing of it is left on the GPU when the measurement proper starts
+                proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, start_new_session=True)
+                try:
+                    rc = proc.wait(timeout=float(os.environ.get("UNETPP_BENCH_PMC_TIMEOUT", "240")))
+                except subprocess.TimeoutExpired:
+                    import signal
+                    try:
+                        os.killpg(proc.pid, signal.SIGKILL)
+                    except OSError:
+                        pass
+                    proc.wait()
+                    return None
             if rc != 0 or not os.path.exists(os.path.join(out, "p_counter_collection.csv")):
                 return None
         sys.path.insert(0, os.path.join(ROOT, "tools"))
