@@ -79,9 +79,9 @@ def parse():
                          "measurement (roofline.traffic / mfma_busy_pmc then come from profiles/pmc_hbm_traffic_latest.json)")
     ap.add_argument("--other-steps", type=int, default=30, help="timed steps of each `other_configs` entry (>= 20)")
     ap.add_argument("--graphed", action="store_true",
-                    help="replay the step from a HIP graph (GraphedTrainStep; single GPU).  The default run uses it for "
-                         "`other_configs` only; with this flag also for the configuration named on the command line "
-                         "(launch events then move behind the timed region)")
+                    help="EXPERIMENTAL: replay the step from a HIP graph (GraphedTrainStep; single GPU) -- for the configuration "
+                         "named on the command line and for `other_configs` (launch events then move behind the timed "
+                         "region).  No default line uses it")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="multi-process plumbing only, on the CPU over gloo, with synthetic gradients and NO kernels: "
                          "self-spawn, rendezvous, broadcast, bucketed all-reduce, optimizer, max-over-ranks timing, "
@@ -428,10 +428,9 @@ def measure(args, ctx):
     x = torch.randn(args.batch, args.in_channels, args.size, args.size, device=dev)
     target = torch.rand(args.batch, n_cls, args.size, args.size, device=dev)
     crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
-    # `other_configs` on one GPU: the same step replayed from a HIP graph (graph.GraphedTrainStep: the launches, their
-    # order and their arguments are train_step's; the dropout seed varies through a device word).  These bf16 steps take
-    # 7-11 ms on the device and 4.5-7 ms of host time to enqueue; eager, the device idles 0.5-0.7 ms per step where the
-    # host falls behind (profiles/r4/step_gaps_rocprofv3.txt).  The headline stays eager.  UNETPP_BENCH_NO_GRAPH=1: eager.
+    # Opt-in (`--graphed`, single GPU): the same step replayed from a HIP graph (graph.GraphedTrainStep, experimental: the
+    # launches, their order and their arguments are train_step's; the dropout seed varies through a device word).  Every
+    # default line -- headline and `other_configs` -- comes from the eager train_step.
     graphed = (getattr(args, "graphed", False) and not distributed and averager is None
                and os.environ.get("UNETPP_BENCH_NO_GRAPH") != "1")
     try:  # same Adam, one fused device kernel: 0.13 ms of host time per step instead of 2.6 ms (foreach, 90 tensors)
@@ -660,7 +659,9 @@ def main():
         others = []
         for name, over in OTHER_CONFIGS:
             o = argparse.Namespace(**dict(vars(args), **over))
-            o.steps, o.warmup, o.prewarm, o.events_after, o.graphed = max(20, args.other_steps), 10, 15, True, True
+            # eager train_step, like the headline (round 5: the graph replay buys no device time -- DESIGN.md section 8 --
+            # and is experimental; `--graphed` opts in)
+            o.steps, o.warmup, o.prewarm, o.events_after, o.graphed = max(20, args.other_steps), 10, 15, True, bool(args.graphed)
             try:
                 r = measure(o, ctx)
                 entry_ = None if r is None else other_entry(name, o, r, world)

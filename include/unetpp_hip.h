@@ -6,9 +6,17 @@
  * torch.nn layers.  Each entry point below therefore cites the torch.nn call site in
  * /root/reference/models/unet.py that it replaces.  All functions
  *   - take plain device pointers, explicit sizes and a hipStream_t (passed as void*),
- *   - never allocate, never synchronise, never own memory, keep no global state,
+ *   - never allocate, never synchronise, never own memory,
  *   - return 0 on success or a negative UNETPP_E* code (nothing is thrown across the ABI),
  *   - are asynchronous on `stream` and re-entrant per (device, stream).
+ * State.  No entry point passes data to another through the library: whatever a launch needs travels in its arguments
+ * (the number of BatchNorm rows a convolution wrote reaches its finalize inside unetpp_gemm_fwd by value).  What the
+ * library does keep, all of it configuration or diagnostics and none of it per call:
+ *   - the CU count of each device (queried once) and, per kernel and device, the "large LDS" opt-in of the runtime;
+ *   - unetpp_set_reserved_cus(): one process-wide integer;
+ *   - unetpp_debug_set(): a process-wide table of dispatcher switches for A/B runs and tests, initialised ONCE from
+ *     UNETPP_* environment variables at the first lookup -- no launch path reads the environment;
+ *   - unetpp_last_kernel_name(): a thread-local pointer to a static string (profiling label).
  *
  * Tensor layout on the device is NHWC fp32 ("pixel-major": the channels of one pixel are
  * contiguous).  A `unetpp_view` names a channel slice of such a tensor, optionally sampled
@@ -25,7 +33,7 @@
 extern "C" {
 #endif
 
-#define UNETPP_ABI_VERSION 8
+#define UNETPP_ABI_VERSION 9
 #define UNETPP_MAX_VIEWS 8
 
 #define UNETPP_OK 0
@@ -130,8 +138,17 @@ const char* unetpp_build_arch(void); /* "gfx950" */
 
 /* Name of the device kernel the calling thread's most recent unetpp_gemm_fwd / unetpp_wgrad call launched
  * (profiling labels; equals the rocprofv3 kernel name up to template arguments).  Static string, "" before the
- * first call.  Diagnostic only: it is the one piece of (thread-local) state the library keeps. */
+ * first call.  Diagnostic only (thread-local). */
 const char* unetpp_last_kernel_name(void);
+
+/* Dispatcher switches for A/B measurements and for tests that hold two kernels against each other inside one process
+ * (v9; replaces per-launch getenv).  `name` is the switch without its UNETPP_ prefix: BF16_NO_DMA, BF16_DMA_ALL,
+ * BF16_DMA_MIN8, BF16_DMA_FORM, BF16_DMA_SMALL, BF16_DMA_STATS, BF16_DMA_POINTWISE, BF16_DMA_SPLIT, BF16_WGRAD_QUAD,
+ * WINO_NO_LEAN, WINO_ONE_PER_CU, MEMSET_NODES, PW_NO_DMA.  set != 0: the switch takes `value`; set == 0: back to the
+ * dispatcher's built-in default.  The environment variable UNETPP_<name>, if present when the library first looks a
+ * switch up, is the initial setting.  Process-wide; results never depend on a switch beyond the summation order of the
+ * kernel it selects.  UNETPP_EINVAL for an unknown name. */
+int unetpp_debug_set(const char* name, int64_t value, int32_t set);
 
 /* Data-parallel co-scheduling knob (v8).  Every hot kernel is a persistent launch sized to fill all CUs at 2-3 workgroups
  * per CU, so a collective kernel (RCCL all-reduce of a gradient bucket on a side stream, trainer/trainer.py:338's
@@ -142,6 +159,9 @@ const char* unetpp_last_kernel_name(void);
  * at the next launch; results do not depend on it.  Returns the value now in force (n clamped to [0, CUs - 8]);
  * unetpp_set_reserved_cus(-1) only reads it. */
 int32_t unetpp_set_reserved_cus(int32_t n);
+/* CUs of the current device a persistent grid may fill (physical - reserved, at least 8); *physical (may be NULL) gets
+ * the device's CU count.  A caller that sizes unetpp_wgrad's n_split scales its target by usable / physical (v9). */
+int32_t unetpp_usable_cus(int32_t* physical);
 
 /* ---- multi-view pixel GEMM on MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32) ------ */
 int64_t unetpp_gemm_pixel_blocks(int32_t N, int32_t H, int32_t W);

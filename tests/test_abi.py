@@ -41,7 +41,7 @@ def test_exported_symbols_are_plain_c(built_lib):
     out = subprocess.run(["nm", "-D", "--defined-only", built_lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
     assert set(_declared_functions()) <= exported
-    assert built_lib.lib().unetpp_abi_version() == built_lib.ABI_VERSION == 8
+    assert built_lib.lib().unetpp_abi_version() == built_lib.ABI_VERSION == 9
     assert built_lib.lib().unetpp_build_arch() == b"gfx950"
 
 
@@ -121,6 +121,29 @@ def test_product_never_imports_the_oracle():
         if fn.endswith(".py"):
             text = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), fn
+
+
+def test_no_launch_path_reads_the_environment(built_lib):
+    """VERDICT r4 item 7 / ADVICE r3: dispatcher switches are a process-wide table (unetpp_debug_set) that is filled from
+    UNETPP_* variables once; no source file but the table's owner may call getenv, and there only inside the
+    once-initialiser.  The launch-to-finalize hand-over of the BatchNorm row count travels by value (no thread_local)."""
+    csrc = os.path.join(ROOT, "unet_nested4tiny_objects_keypoints_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        text = open(os.path.join(csrc, fn)).read()
+        code = re.sub(r"//[^\n]*", "", text)     # comments may talk about it
+        if fn == "gemm_pix.hip":
+            body = code[code.index("void opts_from_environment()"):]
+            body = body[:body.index("bool opt_is_set(")]
+            assert code.count("getenv(") == body.count("getenv(") == 2, "getenv outside the once-initialiser"
+            assert "std::call_once" in body
+        else:
+            assert "getenv(" not in code, fn
+        assert "g_bn_rows" not in code and "note_bn_rows" not in code, fn
+    lib = built_lib.lib()
+    assert lib.unetpp_debug_set(b"BF16_DMA_FORM", 8, 1) == 0
+    assert lib.unetpp_debug_set(b"BF16_DMA_FORM", 0, 0) == 0
+    assert lib.unetpp_debug_set(b"NO_SUCH_SWITCH", 1, 1) < 0
+    assert lib.unetpp_debug_set(None, 1, 1) < 0
 
 
 def test_clean_build_from_sources(tmp_path):

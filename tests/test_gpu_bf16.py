@@ -89,20 +89,14 @@ def test_conv3x3_bf16_forward(dev, b, h, w, cins, cout, affine):
 def _both_kernels(fn, forms=(4, 0)):
     """run fn() with the LDS-DMA kernel in the given forms (8 = 8 waves / 512-pixel patches, 4 = 4 waves / 256-pixel
     patches; forced also where they are not the default) and with the register-staged one (0); -> [(results, name)]"""
-    import os
-
     from unet_nested4tiny_objects_keypoints_amd import ops
+    from unet_nested4tiny_objects_keypoints_amd._lib import debug_switch
     out = []
     for form in forms:
-        os.environ["UNETPP_BF16_DMA_FORM"] = str(form)
-        os.environ["UNETPP_BF16_DMA_ALL"] = "1"
-        try:
+        with debug_switch("BF16_DMA_FORM", form), debug_switch("BF16_DMA_ALL", 1):
             res = fn()
             torch.cuda.synchronize()
             out.append((res, ops._lib.lib().unetpp_last_kernel_name()))
-        finally:
-            os.environ.pop("UNETPP_BF16_DMA_FORM", None)
-            os.environ.pop("UNETPP_BF16_DMA_ALL", None)
     return out
 
 
@@ -155,12 +149,9 @@ def test_bf16_dma_and_register_kernels_agree(dev, b, h, w, cins, cout, mode):
                 part = torch.zeros(ops.gemm_pixel_blocks(b, h, w) * cout * 2, device=dev)
             ops.gemm_fwd(b, h, w, 9, [V(x) for x in xs], [V(y, relu=(mode == "relu"))], engine.pack_conv_fwd(wt), bias, part)
             return [y] + ([part] if part is not None else [])
-    import os
-    os.environ["UNETPP_BF16_DMA_SPLIT"] = "1"    # (an experiment that is off by default; it only acts on the two large shapes)
-    try:
+    from unet_nested4tiny_objects_keypoints_amd._lib import debug_switch
+    with debug_switch("BF16_DMA_SPLIT", 1):    # (an experiment that is off by default; it only acts on the two large shapes)
         (dma8, name8), (dma, dma_name), (reg, reg_name) = _both_kernels(run, forms=(8, 4, 0))
-    finally:
-        os.environ.pop("UNETPP_BF16_DMA_SPLIT", None)
     assert name8 == dma_name == b"gemm_bf16_dma_kernel<9>" and reg_name == b"gemm_bf16_kernel<9>"
     bits = lambda t: t.view(torch.int16) if t.dtype == BF else t   # noqa: E731
     for a8, a_, b_ in zip(dma8, dma, reg):
@@ -195,6 +186,38 @@ def test_bf16_dma_and_register_kernels_agree_on_transposed_convolutions(dev, b, 
         (dma, dma_name), (reg, reg_name) = _both_kernels(fn)
         assert dma_name == b"gemm_bf16_dma_kernel<1>" and reg_name == b"gemm_bf16_kernel<1>"
         assert torch.equal(dma[0].view(torch.int16), reg[0].view(torch.int16))
+
+
+@pytest.mark.parametrize("b,h,w,ci,co", [(4, 128, 128, 128, 32), (2, 64, 96, 64, 32), (2, 32, 32, 64, 96)])
+def test_bf16_pointwise_into_an_odd_number_of_column_tiles_is_reproducible(dev, b, h, w, ci, co):
+    """Round 5 (the cause of GPUTEST_r04): a pointwise launch into ONE column tile -- the 1x1 convolution of the bilinear up
+    path at 32 output channels (models/unet.py:189-191), the transposed convolution's input gradient into 32 channels --
+    has a two-block weight slot; waves 2 and 3 of gemm_bf16_dma_kernel<1, ., 1> used to send their DMA to blocks 2 and 3,
+    i.e. zeros into the OTHER weight slot while the MFMAs of the running chunk read it.  Timing decided whether the
+    zeros landed before those reads (~1e-3 per unit), so one launch proves little: many units, twenty launches, each
+    bit-identical to the register-staged kernel."""
+    from unet_nested4tiny_objects_keypoints_amd import engine, ops
+    from unet_nested4tiny_objects_keypoints_amd._lib import debug_switch
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(b, h, w, ci, generator=g).to(BF).to(dev)
+    wt = (torch.randn(co, ci, 1, 1, generator=g) * 0.1).to(dev)
+    bias = (torch.randn(co, generator=g) * 0.1).to(dev)
+
+    def run():
+        y = torch.full((b, h, w, co), float("nan"), dtype=BF, device=dev)
+        ops.gemm_fwd(b, h, w, 1, [ops.V(x)], [ops.V(y)], engine.pack_conv_fwd(wt), bias)
+        return y
+    with debug_switch("BF16_NO_DMA", 1):
+        ref = run()
+        assert ops._lib.lib().unetpp_last_kernel_name() == b"gemm_bf16_kernel<1>"
+    want = F.conv2d(rb(x.permute(0, 3, 1, 2).cpu()), rb(wt.cpu()), bias.double().cpu())
+    close_bf16(ref.permute(0, 3, 1, 2), want, "register kernel vs the float64 statement on the same bf16 operands")
+    for i in range(20):
+        if i % 2:
+            torch.cuda.synchronize()      # every other launch starts on an idle device
+        got = run()
+        assert ops._lib.lib().unetpp_last_kernel_name() == b"gemm_bf16_dma_kernel<1>"
+        assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), "launch %d" % i
 
 
 def test_conv3x3_bf16_input_gradient_targets(dev):
@@ -292,12 +315,9 @@ def test_conv3x3_bf16_weight_gradient(dev, b, h, w, cis, co, affine, target_bloc
     close_f32(db, dyr.sum((0, 2, 3)), 1e-4, "db")
     if quad:   # the pair kernel on the same operands: same products, another summation order
         dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
-        os.environ["UNETPP_BF16_WGRAD_QUAD"] = "0"
-        try:
+        with ops._lib.debug_switch("BF16_WGRAD_QUAD", 0):
             ops.wgrad(b, h, w, 9, views, [V(dyd)], dw2, (1, 9, ci * 9, 0), db2, target_blocks=target_blocks)
             assert ops._lib.lib().unetpp_last_kernel_name() == b"wgrad_bf16_kernel<9>"
-        finally:
-            del os.environ["UNETPP_BF16_WGRAD_QUAD"]
         close_f32(dw2, dw.double().cpu(), 1e-5, "dW pair vs quad")
         close_f32(db2, db.double().cpu(), 1e-5, "db pair vs quad")
 

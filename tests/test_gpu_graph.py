@@ -1,13 +1,17 @@
-"""The whole training step replayed from a HIP graph (graph.GraphedTrainStep) against the eager step (step.train_step,
-the reference's loop body trainer/trainer.py:114-136): same kernels, same order, same arguments -- bit-identical
-parameters, losses and BatchNorm buffers step after step; dropout varies from replay to replay through the device-side
-seed word (unetpp_head_fwd / unetpp_head_bwd ``seed_dev``, ABI v8)."""
+"""The whole training step replayed from a HIP graph (graph.GraphedTrainStep, EXPERIMENTAL) against the eager step
+(step.train_step, the reference's loop body trainer/trainer.py:114-136): same kernels, same order, same arguments --
+bit-identical parameters, losses and BatchNorm buffers step after step; dropout varies from replay to replay through the
+device-side seed word (unetpp_head_fwd / unetpp_head_bwd ``seed_dev``, ABI v8).
+
+Self-comparison (no oracle): tests/conftest.py runs this file LAST, behind every parity test."""
 import copy
 
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              # a gradient accumulator bound to another stream than its producer puts event hops into a capture
+              pytest.mark.filterwarnings("error:.*AccumulateGrad node's stream does not match.*")]
 
 BF = torch.bfloat16
 
@@ -69,6 +73,62 @@ def test_graphed_step_is_bit_identical_to_eager(dev, ctor, bf16, opt_kind, captu
             assert p.grad is not None and torch.equal(p.grad, q.grad), k
         for (k, p), (_, q) in zip(a.named_buffers(), b.named_buffers()):
             assert torch.equal(p, q), k
+
+
+class _IntStepAdamW(torch.optim.Optimizer):
+    """An optimizer in the style of the reference's tools/optimizers/adamw.py: ``state['step']`` is a Python int, the
+    moments are created on the first step, the update goes through ``p.data`` (test-local; not the reference's code)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self):
+        for grp in self.param_groups:
+            b1, b2 = grp["betas"]
+            for p in grp["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"], st["m"], st["v"] = 0, torch.zeros_like(p), torch.zeros_like(p)
+                st["step"] += 1
+                st["m"].mul_(b1).add_(p.grad, alpha=1 - b1)
+                st["v"].mul_(b2).addcmul_(p.grad, p.grad, value=1 - b2)
+                size = grp["lr"] * (1 - b2 ** st["step"]) ** 0.5 / (1 - b1 ** st["step"])
+                p.data.mul_(1 - grp["lr"] * grp["weight_decay"])
+                p.data.addcdiv_(st["m"], st["v"].sqrt().add_(grp["eps"]), value=-size)
+
+
+def test_warmup_leaves_no_trace_in_an_int_step_optimizer(dev):
+    """the warm-up steps must not advance an optimizer that counts its steps in a Python int (the reference's
+    tools/optimizers/adamw.py:62,76, adabound.py:78,92): state created by the warm-up is removed, existing state is put
+    back by value -- the first replay is step 1 (or step k+1 of a resumed run) exactly as train_step would run it."""
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, GraphedTrainStep, train_step
+    ctor = dict(in_channels=1, n_classes=4, feature_scale=4)
+    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.randn(2, 1, 64, 64, generator=g).to(dev) for _ in range(4)]
+    ts = [torch.rand(2, 4, 64, 64, generator=g).to(dev) for _ in range(4)]
+    for pre_steps in (0, 2):      # fresh optimizer / optimizer that already holds state
+        a = _make(dev, ctor, False, 0.0)
+        b = copy.deepcopy(a)
+        oa, ob = _IntStepAdamW(a.parameters()), _IntStepAdamW(b.parameters())
+        for i in range(pre_steps):
+            train_step(a, oa, crit, xs[i], ts[i])
+            train_step(b, ob, crit, xs[i], ts[i])
+        step = GraphedTrainStep(a, oa, crit, xs[0], ts[0], capture_optimizer=False)
+        assert len(oa.state) == len(ob.state)
+        for p in a.parameters():
+            if p in oa.state:
+                assert oa.state[p]["step"] == pre_steps
+        for x, t in zip(xs[pre_steps:], ts[pre_steps:]):
+            _, loss_g = step(x, t)
+            _, loss_e = train_step(b, ob, crit, x, t)
+            assert float(loss_g) == float(loss_e)
+            for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+                assert torch.equal(p, q), k
+                assert oa.state[p]["step"] == ob.state[q]["step"]
 
 
 def test_graphed_step_dropout_varies_and_trains(dev):

@@ -726,17 +726,13 @@ def test_wino_lean_and_general_kernels_agree(dev, shape, fold, monkeypatch):
 
     res = []
     for general in (False, True):
-        if general:
-            monkeypatch.setenv("UNETPP_WINO_NO_LEAN", "1")
-        else:
-            monkeypatch.delenv("UNETPP_WINO_NO_LEAN", raising=False)
-        out = torch.empty(b, h, w, co, device=dev)
-        part = torch.empty(ops.gemm_pixel_blocks(b, h, w) * co * 2, device=dev)
-        ops.gemm_fwd(b, h, w, 9, views(), [V(out, relu=True)], wp, bias, part)
-        acc = prev.clone()
-        ops.gemm_fwd(b, h, w, 9, views(), [V(acc, gate=gate, accumulate=True)], wp)
+        with ops._lib.debug_switch("WINO_NO_LEAN", 1 if general else 0):
+            out = torch.empty(b, h, w, co, device=dev)
+            part = torch.empty(ops.gemm_pixel_blocks(b, h, w) * co * 2, device=dev)
+            ops.gemm_fwd(b, h, w, 9, views(), [V(out, relu=True)], wp, bias, part)
+            acc = prev.clone()
+            ops.gemm_fwd(b, h, w, 9, views(), [V(acc, gate=gate, accumulate=True)], wp)
         res.append((out, part, acc))
-    monkeypatch.delenv("UNETPP_WINO_NO_LEAN", raising=False)
     for a, c in zip(res[0], res[1]):
         assert torch.equal(a, c)
 

@@ -18,7 +18,7 @@ INCLUDE = os.path.join(_REPO, "include")
 SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_wino.hip", "gemm_bf16.hip", "gemm_bf16_dma.hip", "wgrad_bf16.hip", "pointwise_bf16.hip", "keypoints.hip", "weight_image.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "wgrad_wino.hip", "first_layer.hip", "pointwise.hip", "caller.hip")
 HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h", "lds_asm.h", "bf16_common.h", "dropout.h", "bn_fused.h")
 MAX_VIEWS = 8
-ABI_VERSION = 8
+ABI_VERSION = 9
 # packed-f32 VALU (SLP-vectorised add pairs) costs issue slots beside MFMAs: keep the Winograd transforms scalar
 EXTRA_FLAGS = {"gemm_wino.hip": ("-fno-slp-vectorize",), "wgrad_wino.hip": ("-fno-slp-vectorize",)}
 GEMM_DIRECT = 1  # unetpp_gemm_desc.flags: direct summation only (no Winograd)
@@ -97,6 +97,8 @@ SIGNATURES = {
     "unetpp_build_arch": (C.c_char_p, []),
     "unetpp_last_kernel_name": (C.c_char_p, []),
     "unetpp_set_reserved_cus": (_I32, [_I32]),
+    "unetpp_debug_set": (C.c_int, [C.c_char_p, _I64, _I32]),
+    "unetpp_usable_cus": (_I32, [C.POINTER(C.c_int32)]),
     "unetpp_gemm_pixel_blocks": (_I64, [_I32, _I32, _I32]),
     "unetpp_gemm_stats_rows": (_I64, [_I32, _I32, _I32]),
     "unetpp_gemm_fwd": (C.c_int, [C.POINTER(GemmDesc), _P]),
@@ -224,3 +226,22 @@ def check(status: int, what: str) -> None:
     if status != 0:
         raise RuntimeError("%s failed with status %d (%s)" % (
             what, status, {-1: "invalid argument", -2: "kernel launch error"}.get(status, "unknown")))
+
+
+class debug_switch:
+    """with debug_switch("BF16_DMA_FORM", 8): ...  -- a dispatcher switch of the library (unetpp_debug_set) for the
+    duration of a block; tests use it to hold two kernels against each other inside one process, tools for A/B runs.
+    Leaves the switch UNSET on exit (the dispatcher's default; an environment setting made before the library's first
+    lookup is not restored)."""
+
+    def __init__(self, name: str, value: int):
+        self.name, self.value = name.encode(), int(value)
+
+    def __enter__(self):
+        check(lib().unetpp_debug_set(self.name, self.value, 1), "unetpp_debug_set")
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().unetpp_debug_set(self.name, 0, 0), "unetpp_debug_set")
+        return False
+

@@ -128,15 +128,34 @@ inline int device_cu_count() {  // what a persistent grid may fill
 
 // remembers the kernel a dispatch chose (unetpp_last_kernel_name); defined in gemm_pix.hip
 void note_kernel(const char* name);
-// a launcher tells unetpp_gemm_fwd how many rows of BatchNorm partial sums its kernel wrote (bn_fused.h: one per
-// workgroup); without the note the dispatcher assumes one row per 256-pixel block.  Thread-local, like the kernel name.
-void note_bn_rows(long rows);
+
+// A/B and test switches of the dispatchers (unetpp_debug_set, gemm_pix.hip).  A switch is an int that is either unset
+// (the dispatcher's built-in default applies) or set -- by unetpp_debug_set(), else by the environment variable
+// UNETPP_<name>, which is read ONCE per process when the first switch is looked up (never per launch).
+enum Opt {
+  OPT_BF16_NO_DMA,         // 1: the bf16 GEMMs never take the LDS-DMA kernel (tests compare the two kernels)
+  OPT_BF16_DMA_ALL,        // 1: every launch the LDS-DMA kernel can express takes it
+  OPT_BF16_DMA_MIN8,       // 8-wave form when at least this many 512-pixel units per CU exist (default 2)
+  OPT_BF16_DMA_FORM,       // 0: no DMA kernel, 4 / 8: force that form where it applies
+  OPT_BF16_DMA_SMALL,      // 0: small 3x3 launches back on the register kernel (round-3 dispatch)
+  OPT_BF16_DMA_STATS,      // 0: BatchNorm-statistics launches back on the register kernel
+  OPT_BF16_DMA_POINTWISE,  // 0: transposed-convolution GEMMs back on the register kernel
+  OPT_BF16_DMA_SPLIT,      // 1: split-tail second launch (experiment, off)
+  OPT_BF16_WGRAD_QUAD,     // 0: wide bf16 weight gradients on the pair kernel
+  OPT_WINO_NO_LEAN,        // 1: the general Winograd instantiation for every launch
+  OPT_WINO_ONE_PER_CU,     // 1: (stamped / experiment builds) one Winograd workgroup per CU
+  OPT_MEMSET_NODES,        // 1: unused workspace rows cleared by hipMemsetAsync instead of zero_rows_kernel (graph probe only)
+  OPT_PW_NO_DMA,           // 1: fp32 pointwise GEMMs (transposed convolutions, 1x1) never take the LDS-DMA kernel
+  OPT_COUNT
+};
+bool opt_is_set(Opt o);
+long opt_value(Opt o, long dflt);   // dflt when unset
 
 // gemm_fast.hip: register-prefetched kernel for plain aligned views (needs d->weight_image)
 int launch_gemm_fast(const unetpp_gemm_desc* d, hipStream_t st);
 // gemm_wino.hip: Winograd F(2x2,3x3) kernel for taps == 9 without UNETPP_GEMM_DIRECT (needs its own weight image)
 bool wino_applies(const unetpp_gemm_desc* d);
-int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st);
+int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st, long* bn_rows);  // *bn_rows = rows of BatchNorm sums written, when per workgroup
 // gemm_bf16.hip: bf16-storage direct implicit GEMM (UNETPP_GEMM_BF16); needs its own weight image
 bool bf16_gemm_args(const unetpp_gemm_desc* d, struct FastArgs& a);
 int launch_gemm_bf16(const unetpp_gemm_desc* d, hipStream_t st);
@@ -157,7 +176,7 @@ int launch_wgrad_wino(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_til
 int launch_wgrad_finish_wino(const float* slabs, int n_split, int K, int Ncols, float* dw, long d_t, long d_k, long d_n,
                              float* db, hipStream_t st);
 // first_layer.hip: VALU kernels for the 1..4-channel first convolution; return 1 when they do not apply
-int launch_small_cin_fwd(const unetpp_gemm_desc* d, hipStream_t st);
+int launch_small_cin_fwd(const unetpp_gemm_desc* d, hipStream_t st, long* bn_rows);
 int launch_small_cin_wgrad(const unetpp_wgrad_desc* d, hipStream_t st);
 
 }  // namespace unetpp

@@ -355,7 +355,7 @@ void fill_geom(SmallArgs& a, int N, int H, int W) {
 }  // namespace
 
 // 3x3 forward for <= 4 input channels.  Returns 1 when the descriptor does not fit this path.
-int launch_small_cin_fwd(const unetpp_gemm_desc* d, hipStream_t st) {
+int launch_small_cin_fwd(const unetpp_gemm_desc* d, hipStream_t st, long* bn_rows) {
   if (d->taps != 9 || d->n_in != 1 || d->n_out != 1) return 1;
   const unetpp_view& X = d->in[0];
   const unetpp_view& Y = d->out[0];
@@ -397,7 +397,7 @@ int launch_small_cin_fwd(const unetpp_gemm_desc* d, hipStream_t st) {
   }
 #undef UNETPP_SMALL_FWD
   note_kernel("small_cin_fwd_kernel");
-  if (a.bn_in_kernel) note_bn_rows(grid.x);
+  if (a.bn_in_kernel && bn_rows != nullptr) *bn_rows = grid.x;
   return launch_status();
 }
 

@@ -110,6 +110,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
   constexpr int NQ = (NBLK + WAVES - 1) / WAVES;       // input blocks per wave
   constexpr int WBLK = W_BYTES / 1024, NWQ = (WBLK + WAVES - 1) / WAVES;
   static_assert(!STATS || IN_BYTES >= 4 * 4096 + 1024, "epilogue scratch + statistics rows do not fit in an input buffer");
+  static_assert(NBLK >= WAVES, "input staging: a wave past the patch repeats block `wave`, which must exist");
   static_assert(2 * IN_BYTES + W_SLOTS * W_BYTES <= (WAVES == 4 ? 80 : 160) * 1024, "LDS: two workgroups (one) per CU");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * IN_BYTES + W_SLOTS * W_BYTES];
 
@@ -235,7 +236,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
     const int wchunk = group_off + chunk * IMG;
 #pragma unroll
     for (int q = 0; q < NWQ; ++q) {
-      const int blk = (wave + WAVES * q < WBLK) ? wave + WAVES * q : wave;  // 1 KB block of the NT images (uniform)
+      // 1 KB block of the NT images (uniform).  A wave whose block index runs past the slot repeats a block INSIDE it.
+      // Round 5: this read `: wave`, which is only inside the slot when WBLK >= WAVES.  A pointwise launch into ONE column
+      // tile has WBLK = 2: waves 2 and 3 then sent blocks 2 and 3 -- source past the image (the resource returns zeros),
+      // destination the OTHER weight slot, i.e. the one the MFMAs of the running chunk read from -- whenever the target was
+      // slot 0.  The zeros normally land after those reads (a DMA takes longer than the two fragment reads of a pointwise
+      // chunk), so the launch was right ~99.9 % of the time and dropped a chunk's weights in the rest: the eager step that
+      // disagreed with the graph replay in the driver's round-4 run (tools/probes/determinism_probe.py found the launch).
+      const int blk = (wave + WAVES * q < WBLK) ? wave + WAVES * q : wave % WBLK;
+      static_assert(WBLK >= 1, "a slot holds at least one block");
       const int t = blk / (IMG / 1024), r = blk - t * (IMG / 1024);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (dma_lptr_t)(w_dst + blk * 1024), 16, lane16,
                                                wchunk + t * a.n_chunks * IMG + r * 1024, 0, 0);
@@ -643,7 +652,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
 #endif
 }
 
-bool dma_env_off() { return getenv("UNETPP_BF16_NO_DMA") != nullptr; }  // read per launch: tests compare the two kernels
+bool dma_env_off() { return opt_value(OPT_BF16_NO_DMA, 0) != 0; }  // unetpp_debug_set: tests compare the two kernels
 
 }  // namespace
 
@@ -674,18 +683,18 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
   //                                launches too small for the 8-wave form, BatchNorm-statistics launches with plain inputs,
   //                                the pointwise GEMMs (see the switches below)
   //   neither (gemm_bf16.hip)      load transforms (BatchNorm fold / ReLU / gate on load), unaligned channel slices
-  const bool all = getenv("UNETPP_BF16_DMA_ALL") != nullptr;
+  const bool all = opt_value(OPT_BF16_DMA_ALL, 0) != 0;
   const bool stats = d->stats_partial != nullptr;
   int form = 4;
   const int cus = device_cu_count();
   if (cus <= 0) return UNETPP_ELAUNCH;
   // (the 8-wave form only when its 512-pixel units still cover the chip: the deepest layers of a small image do not)
   const long units8 = static_cast<long>(d->N) * ((d->H + 15) / 16) * a.tiles_x * ((a.n_tiles % 2 == 0) ? a.n_tiles / 2 : a.n_tiles);
-  static const long min8 = [] { const char* e = getenv("UNETPP_BF16_DMA_MIN8"); return e != nullptr ? atol(e) : 2L; }();  // (A/B knob)
+  const long min8 = opt_value(OPT_BF16_DMA_MIN8, 2);  // (A/B knob)
   // (one-chunk one-tile launches in the 8-wave form as well: 0 .. +2 % on the configs[3] step depending on the box, not taken)
   if (d->taps == 9 && !stats && a.log2tw == 5 && (a.n_chunks > 1 || a.n_tiles > 1) && units8 >= min8 * cus) form = 8;
-  if (const char* e = getenv("UNETPP_BF16_DMA_FORM"); e != nullptr) {
-    const int want = atoi(e);
+  if (opt_is_set(OPT_BF16_DMA_FORM)) {
+    const int want = static_cast<int>(opt_value(OPT_BF16_DMA_FORM, 4));
     if (want == 0) return 1;
     if (want == 4 || (want == 8 && d->taps == 9 && !stats && a.log2tw == 5)) form = want;
   }
@@ -693,16 +702,15 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
   // form as well instead of falling back to the register kernel: its 256-pixel x 32-column units are the finest the
   // library has, and at these sizes the number of units per CU is what counts (288 / 144 / 80 units of the 8-wave shape
   // for 256 CUs at levels 2-4 of configs[4]).  UNETPP_BF16_DMA_SMALL=0 restores the round-3 choice (A/B runs).
-  static const bool small_too = [] { const char* e = getenv("UNETPP_BF16_DMA_SMALL"); return e == nullptr || e[0] != '0'; }();
+  const bool small_too = opt_value(OPT_BF16_DMA_SMALL, 1) != 0;
   const bool small3x3 = small_too && d->taps == 9 && !stats && form == 4 && a.n_tiles > 1;
   // BatchNorm-statistics launches with plain inputs (conv1 of the encoder levels >= 1) through the 4-wave statistics
   // instantiation: +0.3 % on the configs[4] step, nothing at configs[3] (same box, alternating); =0 switches it off
-  static const bool stats_too = [] { const char* e = getenv("UNETPP_BF16_DMA_STATS"); return e == nullptr || e[0] != '0'; }();
+  const bool stats_too = opt_value(OPT_BF16_DMA_STATS, 1) != 0;
   const bool stats3x3 = stats_too && d->taps == 9 && stats && form == 4 && d->n_out == 1;
   // the transposed-convolution GEMMs (pointwise, four phase views) through this kernel as well: +1 % on the configs[3]
   // step, nothing at configs[4] (same box, alternating); UNETPP_BF16_DMA_POINTWISE=0 keeps them on the register kernel
-  const char* pw_env = getenv("UNETPP_BF16_DMA_POINTWISE");
-  const bool pointwise = !(pw_env != nullptr && pw_env[0] == '0') && d->taps == 1 && !stats;
+  const bool pointwise = opt_value(OPT_BF16_DMA_POINTWISE, 1) != 0 && d->taps == 1 && !stats;
   if (!all && !small3x3 && !stats3x3 && !pointwise && form == 4 && (d->taps != 9 || a.n_tiles != 1 || stats)) return 1;
   const unetpp_view& V0 = d->in[0];
   for (int i = 0; i < d->n_in; ++i) {
@@ -741,8 +749,7 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
     // 10.53 ms per step on one box, alternating.  Half (level 0) or a quarter (level 1) of the workgroups carry the extra
     // unit, the others idle for ~10 % / ~25 % of the launch -- but the second launch's gap, prologue and weight re-staging
     // cost more than that idle time gives back.
-    const char* split_env = getenv("UNETPP_BF16_DMA_SPLIT");
-    const bool split_tail = split_env != nullptr && split_env[0] == '1';
+    const bool split_tail = opt_value(OPT_BF16_DMA_SPLIT, 0) == 1;
     long units_here = a.total_blocks;
     const long row8 = static_cast<long>(a.tiles_x) * a.n_groups;            // units of one 16-row patch row
     if (split_tail && (d->H % 16) == 0 && a.total_blocks > workers) {

@@ -17,7 +17,10 @@
 // output channels, so one stored register is 32 consecutive floats of one pixel (a full 128-B line).
 #include "bn_fused.h"
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 
 #include "common.h"
 
@@ -190,34 +193,87 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_pix_kernel(const GemmArgs a)
 namespace unetpp {
 namespace {
 thread_local const char* g_last_kernel = "";
+
+// The switches of common.h's Opt: one table for the process, filled from the environment ONCE (std::call_once, at the
+// first lookup) and changed afterwards only through unetpp_debug_set().  No launch path calls getenv.
+const char* const kOptNames[OPT_COUNT] = {
+    "BF16_NO_DMA", "BF16_DMA_ALL", "BF16_DMA_MIN8", "BF16_DMA_FORM", "BF16_DMA_SMALL", "BF16_DMA_STATS",
+    "BF16_DMA_POINTWISE", "BF16_DMA_SPLIT", "BF16_WGRAD_QUAD", "WINO_NO_LEAN", "WINO_ONE_PER_CU", "MEMSET_NODES",
+    "PW_NO_DMA"};
+struct OptSlot {
+  std::atomic<long> value{0};
+  std::atomic<bool> set{false};
+};
+OptSlot g_opts[OPT_COUNT];
+std::atomic<int> g_reserved_cus{0};
+std::once_flag g_opts_once;
+
+void opts_from_environment() {
+  std::call_once(g_opts_once, [] {
+    char name[64];
+    for (int i = 0; i < OPT_COUNT; ++i) {
+      snprintf(name, sizeof(name), "UNETPP_%s", kOptNames[i]);
+      const char* e = getenv(name);
+      if (e != nullptr) {
+        // a variable that is present but empty / not a number counts as 1 (the old `getenv(..) != nullptr` switches)
+        char* end = nullptr;
+        const long v = strtol(e, &end, 10);
+        g_opts[i].value.store(end == e ? 1 : v, std::memory_order_relaxed);
+        g_opts[i].set.store(true, std::memory_order_release);
+      }
+    }
+    if (const char* e = getenv("UNETPP_RESERVED_CUS"); e != nullptr) {
+      const int v = atoi(e);
+      g_reserved_cus.store(v < 0 ? 0 : v, std::memory_order_relaxed);
+    }
+  });
 }
-thread_local long g_bn_rows = 0;
-std::atomic<int> g_reserved_cus{-1};  // -1: not set yet (the environment decides at the first read)
+}  // namespace
+
+bool opt_is_set(Opt o) {
+  opts_from_environment();
+  return g_opts[o].set.load(std::memory_order_acquire);
+}
+long opt_value(Opt o, long dflt) {
+  opts_from_environment();
+  return g_opts[o].set.load(std::memory_order_acquire) ? g_opts[o].value.load(std::memory_order_relaxed) : dflt;
+}
 int reserved_cus() {
-  int v = g_reserved_cus.load(std::memory_order_relaxed);
-  if (v < 0) {
-    const char* e = getenv("UNETPP_RESERVED_CUS");
-    v = (e != nullptr) ? atoi(e) : 0;
-    if (v < 0) v = 0;
-    g_reserved_cus.store(v, std::memory_order_relaxed);
-  }
-  return v;
+  opts_from_environment();
+  return g_reserved_cus.load(std::memory_order_relaxed);
 }
 void note_kernel(const char* name) { g_last_kernel = name; }
-void note_bn_rows(long rows) { g_bn_rows = rows; }
 }  // namespace unetpp
 
 using namespace unetpp;
 
 extern "C" const char* unetpp_last_kernel_name(void) { return g_last_kernel; }
 
+extern "C" int unetpp_debug_set(const char* name, int64_t value, int32_t set) {
+  if (name == nullptr) return UNETPP_EINVAL;
+  opts_from_environment();   // (so that a later first lookup does not overwrite this call with the environment)
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (strcmp(name, kOptNames[i]) == 0) {
+      g_opts[i].value.store(static_cast<long>(value), std::memory_order_relaxed);
+      g_opts[i].set.store(set != 0, std::memory_order_release);
+      return UNETPP_OK;
+    }
+  return UNETPP_EINVAL;
+}
+
 extern "C" int32_t unetpp_set_reserved_cus(int32_t n) {
+  opts_from_environment();
   if (n >= 0) {
     const int cus = physical_cu_count();
     const int cap = cus > 8 ? cus - 8 : 0;
     g_reserved_cus.store(n > cap ? cap : n, std::memory_order_relaxed);
   }
   return reserved_cus();
+}
+
+extern "C" int32_t unetpp_usable_cus(int32_t* physical) {
+  if (physical != nullptr) *physical = physical_cu_count();
+  return device_cu_count();
 }
 
 extern "C" int64_t unetpp_gemm_pixel_blocks(int32_t N, int32_t H, int32_t W) {
@@ -233,28 +289,30 @@ extern "C" int64_t unetpp_gemm_stats_rows(int32_t N, int32_t H, int32_t W) {
 }
 
 namespace {
-int gemm_fwd_dispatch(const unetpp_gemm_desc* d, void* stream);
+// *bn_rows: rows of BatchNorm partial sums the launched kernel writes when that is NOT one per 256-pixel block (the
+// persistent kernels of bn_fused.h write one per workgroup); left untouched otherwise
+int gemm_fwd_dispatch(const unetpp_gemm_desc* d, void* stream, long* bn_rows);
 }
 
 extern "C" int unetpp_gemm_fwd(const unetpp_gemm_desc* d, void* stream) {
   if (d == nullptr || d->N <= 0 || d->H <= 0 || d->W <= 0) return UNETPP_EINVAL;
   const unetpp_bn_fused& bn = d->bn;
-  if (bn.scale == nullptr) return gemm_fwd_dispatch(d, stream);
+  long bn_rows = 0;
+  if (bn.scale == nullptr) return gemm_fwd_dispatch(d, stream, &bn_rows);
   // BatchNorm finalize attached to this call: over the kernel's per-workgroup rows where it writes those (bn_fused.h),
   // else over per-block rows
   if (!d->stats_partial || !bn.gamma || !bn.beta || !bn.mean || !bn.invstd || !bn.shift || bn.count < 1 ||
       (bn.running_mean == nullptr) != (bn.running_var == nullptr) || d->n_out != 1)
     return UNETPP_EINVAL;
-  g_bn_rows = 0;
-  const int rc = gemm_fwd_dispatch(d, stream);
+  const int rc = gemm_fwd_dispatch(d, stream, &bn_rows);
   if (rc != UNETPP_OK) return rc;
-  const int64_t rows = g_bn_rows > 0 ? g_bn_rows : unetpp_gemm_pixel_blocks(d->N, d->H, d->W);
+  const int64_t rows = bn_rows > 0 ? bn_rows : unetpp_gemm_pixel_blocks(d->N, d->H, d->W);
   return unetpp_bn_finalize(d->stats_partial, rows, d->out[0].c_len, bn.count, bn.gamma, bn.beta, bn.eps, bn.momentum,
                             bn.running_mean, bn.running_var, bn.mean, bn.invstd, bn.scale, bn.shift, stream);
 }
 
 namespace {
-int gemm_fwd_dispatch(const unetpp_gemm_desc* d, void* stream) {
+int gemm_fwd_dispatch(const unetpp_gemm_desc* d, void* stream, long* bn_rows) {
   if (d == nullptr || d->N <= 0 || d->H <= 0 || d->W <= 0) return UNETPP_EINVAL;
   if (d->taps != 9 && d->taps != 1) return UNETPP_EINVAL;
   if (d->n_in < 1 || d->n_in > UNETPP_MAX_VIEWS || d->n_out < 1 || d->n_out > UNETPP_MAX_VIEWS) return UNETPP_EINVAL;
@@ -265,11 +323,11 @@ int gemm_fwd_dispatch(const unetpp_gemm_desc* d, void* stream) {
       const int dma = launch_gemm_bf16_dma(d, static_cast<hipStream_t>(stream));
       return dma != 1 ? dma : launch_gemm_bf16(d, static_cast<hipStream_t>(stream));
     }
-    const int small = launch_small_cin_fwd(d, static_cast<hipStream_t>(stream));
+    const int small = launch_small_cin_fwd(d, static_cast<hipStream_t>(stream), bn_rows);
     return small == 1 ? UNETPP_EINVAL : small;  // no generic bf16 kernel: unaligned views are refused
   }
   if (d->weight_image != nullptr)  // the image was packed for the algorithm the same descriptor selects
-    return wino_applies(d) ? launch_gemm_wino(d, static_cast<hipStream_t>(stream))
+    return wino_applies(d) ? launch_gemm_wino(d, static_cast<hipStream_t>(stream), bn_rows)
                            : launch_gemm_fast(d, static_cast<hipStream_t>(stream));
   GemmArgs a;
   a.d = *d;
@@ -292,7 +350,7 @@ int gemm_fwd_dispatch(const unetpp_gemm_desc* d, void* stream) {
   const int64_t pix_blocks = static_cast<int64_t>(d->N) * g.tiles_y * g.tiles_x;
   if (pix_blocks > 0x7fffffffLL || n_tiles > 65535) return UNETPP_EINVAL;
   {
-    const int small = launch_small_cin_fwd(d, static_cast<hipStream_t>(stream));  // 1..4-channel first layer
+    const int small = launch_small_cin_fwd(d, static_cast<hipStream_t>(stream), bn_rows);  // 1..4-channel first layer
     if (small != 1) return small;
   }
   const dim3 grid(static_cast<unsigned>(pix_blocks), static_cast<unsigned>(n_tiles));

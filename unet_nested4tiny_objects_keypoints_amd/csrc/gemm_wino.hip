@@ -805,7 +805,7 @@ bool wino_applies(const unetpp_gemm_desc* d) {
   return d != nullptr && d->taps == 9 && (d->flags & (UNETPP_GEMM_DIRECT | UNETPP_GEMM_BF16)) == 0;
 }
 
-int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
+int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st, long* bn_rows) {
   FastArgs a;
   if (!wino_applies(d) || !fast_args(d, a, WKC, WNC) || d->weight_image == nullptr) return UNETPP_EINVAL;
   if (d->stats_partial != nullptr && d->n_out != 1) return UNETPP_EINVAL;
@@ -813,7 +813,7 @@ int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
   if (cus <= 0) return UNETPP_ELAUNCH;
   long workers = (2L * cus) & ~7L;  // persistent grid: two workgroups per CU (= the kernel's launch bounds)
 #if defined(UNETPP_WINO_STAMPS) || defined(UNETPP_WINO_EXP)
-  if (const char* e = getenv("UNETPP_WINO_ONE_PER_CU"); e != nullptr && e[0] == '1') workers = cus & ~7L;  // waves alone on their SIMD
+  if (opt_value(OPT_WINO_ONE_PER_CU, 0) == 1) workers = cus & ~7L;  // waves alone on their SIMD
 #endif
   if (workers < 8) workers = 8;
   if (workers > kBnFusedRows) workers = kBnFusedRows;
@@ -821,7 +821,7 @@ int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
   bool narrow = true;  // no output view wider than 16 channels: the second column half is never used
   for (int i = 0; i < d->n_out; ++i) narrow = narrow && d->out[i].c_len <= 16;
   // lean staging: launch-sized fp32 tensors, whole 8-channel chunks, 2 GB at most; mode 1 = no transform on load
-  bool lean = getenv("UNETPP_WINO_NO_LEAN") == nullptr, fold = false;
+  bool lean = opt_value(OPT_WINO_NO_LEAN, 0) == 0, fold = false;
   for (int i = 0; i < d->n_in; ++i) {
     const unetpp_view& v = d->in[i];
     lean = lean && (v.c_len & 7) == 0 && v.Hs == d->H && v.Ws == d->W && v.sy == 1 && v.sx == 1 && v.oy == 0 &&
@@ -849,7 +849,7 @@ int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st) {
 #undef UNETPP_LAUNCH_WINO
 #undef UNETPP_LAUNCH_WINO_M
   note_kernel("gemm_wino_kernel");
-  if (a.bn_in_kernel) note_bn_rows(grid.x);
+  if (a.bn_in_kernel && bn_rows != nullptr) *bn_rows = grid.x;
   return launch_status();
 }
 

@@ -1287,6 +1287,10 @@ __global__ __launch_bounds__(kThreads) void zero_rows_kernel(float* __restrict__
     p[i] = 0.f;
 }
 inline void zero_rows(float* p, long n, hipStream_t st) {
+  if (opt_value(OPT_MEMSET_NODES, 0) == 1) {   // tools/probes/graph_topology.py only: what a memset NODE does to a captured step
+    (void)hipMemsetAsync(p, 0, static_cast<size_t>(n) * sizeof(float), st);
+    return;
+  }
   const long want = (n + kThreads - 1) / kThreads;
   hipLaunchKernelGGL(zero_rows_kernel, dim3(static_cast<unsigned>(want < 1024 ? want : 1024)), dim3(kThreads), 0, st, p, n);
 }

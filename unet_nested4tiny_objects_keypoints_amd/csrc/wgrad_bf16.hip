@@ -831,8 +831,8 @@ int launch_quad(const WBfArgs& a, dim3 grid, hipStream_t st) {
 // the quad kernel takes a layer when every view is a multiple of 64 channels wide (UNETPP_BF16_WGRAD_QUAD=0 keeps the
 // pair kernel, for A/B runs and the tests that compare the two)
 bool wgrad_bf16_quads(const unetpp_wgrad_desc* d) {
-  const char* e = getenv("UNETPP_BF16_WGRAD_QUAD");  // read per call: the tests switch it inside one process
-  if ((e != nullptr && e[0] == '0') || !(d->flags & UNETPP_GEMM_BF16)) return false;
+  // (unetpp_debug_set("BF16_WGRAD_QUAD", 0): the tests compare the quad and the pair kernel inside one process)
+  if (opt_value(OPT_BF16_WGRAD_QUAD, 1) == 0 || !(d->flags & UNETPP_GEMM_BF16)) return false;
   if (d->taps == 9 && d->n_x == 1 && d->x[0].c_len <= 4) return false;  // first layer: its own kernel
   auto fits = [&](const unetpp_view& v) { return v.c_len > 0 && (v.c_len & 63) == 0; };
   for (int i = 0; i < d->n_x; ++i)

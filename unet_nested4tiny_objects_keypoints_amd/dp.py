@@ -240,12 +240,11 @@ def make_data_parallel(model, process_group=None, bucket_bytes: Optional[int] = 
                        always_reduce: bool = False, reserved_cus: Optional[int] = None) -> GradientAverager:
     """Broadcast rank 0's parameters/buffers, then hook the gradient averager into the model's backward.
 
-    reserved_cus (or the UNETPP_DP_RESERVED_CUS environment variable): CUs the persistent compute grids leave free for
-    the RCCL kernels of the side stream (include/unetpp_hip.h, unetpp_set_reserved_cus).  Default: none -- the knob
-    exists because the overlap of a bucket's all-reduce with the remaining backward is per kernel boundary otherwise
-    (DESIGN.md section 6); it has not been measured on a multi-GPU node, so it is not switched on blindly."""
-    if reserved_cus is None and os.environ.get("UNETPP_DP_RESERVED_CUS"):
-        reserved_cus = int(os.environ["UNETPP_DP_RESERVED_CUS"])
+    reserved_cus: CUs the persistent compute grids leave free for the RCCL kernels of the side stream
+    (include/unetpp_hip.h, unetpp_set_reserved_cus; without the argument the library's own UNETPP_RESERVED_CUS
+    environment variable -- the one variable for this knob -- decides).  Default: none -- the knob exists because the
+    overlap of a bucket's all-reduce with the remaining backward is per kernel boundary otherwise (DESIGN.md section 6);
+    UNMEASURED: no multi-GPU node has run it yet, so it is not switched on blindly."""
     if reserved_cus is not None and next(model.parameters()).is_cuda:
         from . import _lib
         _lib.lib().unetpp_set_reserved_cus(int(reserved_cus))

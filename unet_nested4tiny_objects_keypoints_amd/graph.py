@@ -1,13 +1,12 @@
-"""One whole training step replayed from a HIP graph.
+"""One whole training step replayed from a HIP graph.  EXPERIMENTAL: nothing on a default path uses it.
 
 The reference's loop body (trainer/trainer.py:114-136: zero_grad -> forward -> criterion on every head -> mean ->
 backward -> optimizer.step()) is ~200-280 kernel launches per step on this path.  Eager PyTorch needs 4.5-7 ms of host
 time to enqueue them; the bf16 steps of BASELINE configs[3] / configs[4] take 7.2 / 10.9 ms on the device, so the host is
-never far ahead, and wherever it falls behind -- the hand-over from the autograd thread to ``optimizer.step()`` is the
-largest spot -- the device idles (0.5-0.7 ms per step in a rocprofv3 trace, profiles/r4/step_gaps_rocprofv3.txt).
-``GraphedTrainStep`` captures the step once for fixed tensor shapes (torch.cuda.CUDAGraph = hipGraph) and replays it
-with one call: the launches, their order and their arguments are those of ``train_step`` -- the same kernels do the
-same work -- only the enqueueing is gone.
+never far ahead.  ``GraphedTrainStep`` captures the step once for fixed tensor shapes (torch.cuda.CUDAGraph = hipGraph)
+and replays it with one call: the launches, their order and their arguments are those of ``train_step`` -- the same
+kernels do the same work -- only the enqueueing is gone (host 7 ms -> 0.15 ms per step; the DEVICE time of these steps
+does not change, they are device-bound: DESIGN.md section 8).
 
 What a captured launch cannot take by value any more is handled explicitly:
   * inputs / targets are copied into the graph's static tensors before each replay;
@@ -20,32 +19,92 @@ What a captured launch cannot take by value any more is handled explicitly:
     eager ``optimizer.step()`` (``capture_optimizer=False``: any optimizer, including the reference's own
     tools/optimizers/*) finds them even if something set ``p.grad`` to None in between.
 
-The warm-up passes that size the allocator pools and record the weight-image jobs are real training steps on the
-example batch; by default their effect is undone (parameters, buffers and optimizer state are restored in place,
-optimizer state created during warm-up is zeroed) so that the first replay is the first step of the run.
+Capture discipline (round 5, after the driver's run of round 4 saw a replay and the eager step disagree):
+  * warm-up and capture run on ONE private stream (``torch.cuda.graph(g, stream=side)``): the gradient accumulators
+    PyTorch creates for the parameters are bound to the stream they are first used on, and an accumulator bound to
+    another stream than the producer of its gradient makes the autograd engine put event hops into the capture -- a
+    fork / join DAG instead of a chain.  PyTorch's warning about that ("AccumulateGrad node's stream does not match")
+    is an ERROR inside ``__init__``;
+  * the capture starts with no autograd state from the warm-up (``p.grad = None``, no output or loss of a warm-up
+    step alive) and the step hands out DETACHED static outputs and loss, so no autograd graph -- and no accumulator
+    bound to the capture stream -- outlives the capture; eager passes of the same model afterwards create their own;
+  * backward is captured with single-threaded autograd (every captured launch is enqueued by this thread);
+  * ``check_topology=True`` keeps the hipGraph_t (``CUDAGraph(keep_graph=True)``) and reads its nodes and edges back
+    through hipGraphGetNodes / hipGraphGetEdges / hipGraphNodeGetType (``self.topology``; ``debug_dot`` also has
+    hipGraphDebugDotPrint write them out): tests/test_gpu_graph.py asserts that what was captured is the chain this
+    file assumes -- one root, one leaf, no node with two successors or two predecessors.
 
-Two properties of hipGraph on ROCm 7.2 shaped this file and csrc/ (both found with tools/probes/dbg_graph*.py, both silent):
-launches captured from a second thread (PyTorch's autograd worker) leave the graph with a tail the launch stream does
-not wait for -- backward is therefore captured with single-threaded autograd; and memset NODES are not reliably ordered
-against neighbouring kernel nodes -- the library zeroes workspace rows with a kernel (pointwise.hip, zero_rows).
+The warm-up passes that size the allocator pools and record the weight-image jobs are real training steps on the
+example batch; by default their effect is undone: parameters and buffers are restored in place, and the optimizer's
+state is put back from a deep copy taken before the warm-up -- tensors in place, Python numbers by value (the
+reference's tools/optimizers/adamw.py:62,76 and adabound.py:78,92 keep ``state['step']`` as an int), entries the
+warm-up created are removed (``capture_optimizer=False``) or zeroed in place (captured optimizer: the graph holds their
+addresses).
 
 Not supported: a model with a data-parallel averager attached (the gradient all-reduce runs on a side stream with its
 own events: use ``train_step`` there), CPU tensors (this path has no CPU fallback).
 """
 from __future__ import annotations
 
+import collections
+import copy
+import ctypes
+import warnings
+from typing import Optional
+
 import torch
+
+_HIP_NODE_TYPES = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event",
+                   7: "event_record", 8: "ext_sem_signal", 9: "ext_sem_wait", 10: "mem_alloc", 11: "mem_free",
+                   12: "memcpy_from_symbol", 13: "memcpy_to_symbol"}
+
+
+def graph_topology(raw_graph: int, dot_path: Optional[str] = None) -> dict:
+    """Nodes and edges of a hipGraph_t (the integer torch.cuda.CUDAGraph.raw_cuda_graph() returns), read back through the
+    HIP runtime this process already has loaded.  ``chain`` is True when the graph is one path: a single root, a single
+    leaf, edges = nodes - 1, no fork, no join."""
+    hip = ctypes.CDLL("libamdhip64.so")
+    g = ctypes.c_void_p(raw_graph)
+    n = ctypes.c_size_t(0)
+    if hip.hipGraphGetNodes(g, None, ctypes.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    nodes = (ctypes.c_void_p * max(1, n.value))()
+    hip.hipGraphGetNodes(g, nodes, ctypes.byref(n))
+    e = ctypes.c_size_t(0)
+    if hip.hipGraphGetEdges(g, None, None, ctypes.byref(e)) != 0:
+        raise RuntimeError("hipGraphGetEdges failed")
+    src, dst = (ctypes.c_void_p * max(1, e.value))(), (ctypes.c_void_p * max(1, e.value))()
+    hip.hipGraphGetEdges(g, src, dst, ctypes.byref(e))
+    kinds = collections.Counter()
+    kind_of = {}
+    for i in range(n.value):
+        t = ctypes.c_int(-1)
+        hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t))
+        kind_of[nodes[i]] = _HIP_NODE_TYPES.get(t.value, "type%d" % t.value)
+        kinds[kind_of[nodes[i]]] += 1
+    succ, pred = collections.Counter(src[i] for i in range(e.value)), collections.Counter(dst[i] for i in range(e.value))
+    ids = [nodes[i] for i in range(n.value)]
+    forks = [kind_of[v] for v in ids if succ[v] > 1]
+    joins = [kind_of[v] for v in ids if pred[v] > 1]
+    roots = [kind_of[v] for v in ids if pred[v] == 0]
+    leaves = [kind_of[v] for v in ids if succ[v] == 0]
+    if dot_path is not None:
+        hip.hipGraphDebugDotPrint(g, dot_path.encode(), ctypes.c_uint(0))
+    return {"nodes": n.value, "edges": e.value, "kinds": dict(kinds), "roots": roots, "leaves": leaves, "forks": forks,
+            "joins": joins,
+            "chain": bool(n.value >= 1 and e.value == n.value - 1 and len(roots) == 1 and len(leaves) == 1 and not forks and not joins)}
 
 
 class GraphedTrainStep:
     """step = GraphedTrainStep(model, optimizer, criterion, x, target); outputs, loss = step(x, target)
 
-    ``outputs`` / ``loss`` are the graph's static tensors: the next call overwrites them (clone what must live longer).
-    capture_optimizer=True puts ``optimizer.step()`` into the graph; it needs an optimizer whose step makes no host
-    decision that depends on device data (torch.optim.Adam / AdamW with ``capturable=True``, SGD)."""
+    ``outputs`` / ``loss`` are the graph's static tensors (detached): the next call overwrites them (clone what must
+    live longer).  capture_optimizer=True puts ``optimizer.step()`` into the graph; it needs an optimizer whose step
+    makes no host decision that depends on device data (torch.optim.Adam / AdamW with ``capturable=True``, SGD)."""
 
     def __init__(self, model, optimizer, criterion, inputs: torch.Tensor, target: torch.Tensor, warmup: int = 3,
-                 capture_optimizer: bool = False, restore_state: bool = True):
+                 capture_optimizer: bool = False, restore_state: bool = True, check_topology: bool = False,
+                 debug_dot: Optional[str] = None, _threaded_backward: bool = False):
         if not inputs.is_cuda or not target.is_cuda:
             raise RuntimeError("GraphedTrainStep needs GPU tensors: this path has no CPU fallback")
         if not model.training:
@@ -63,28 +122,35 @@ class GraphedTrainStep:
         saved = None
         if restore_state:
             saved = ([p.detach().clone() for p in params], [b.detach().clone() for b in model.buffers()],
-                     {id(t): t.detach().clone() for t in self._optimizer_tensors()})
+                     copy.deepcopy(optimizer.state_dict()), {id(p) for p in optimizer.state})
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        # Backward must be captured from THIS thread.  PyTorch runs the backward of device tensors on a per-device worker
-        # thread; launches that another thread puts into a capturing stream do end up in the graph, but on ROCm 7.2 a
-        # graph whose last nodes were captured from the second thread completes -- as far as the launch stream can tell
-        # -- before those nodes have run: `stream.synchronize()` returned while the last weight-gradient kernels were
-        # still writing (19 of 20 replays, tools/probes/dbg_graph3.py), and whatever the stream did next raced with them.
-        # Single-threaded autograd keeps every captured launch on one thread and the graph a plain chain.
-        with torch.cuda.stream(side), torch.autograd.set_multithreading_enabled(False):
-            for _ in range(max(1, warmup)):   # records the weight-image jobs, sizes the pools, creates optimizer state
-                self._new_seed()
-                self._body(True)
+        check_topology = check_topology or debug_dot is not None
+        self._graph = torch.cuda.CUDAGraph(keep_graph=True) if check_topology else torch.cuda.CUDAGraph()
+        self.topology = None
+        with warnings.catch_warnings():
+            warnings.filterwarnings("error", message=".*AccumulateGrad node's stream does not match.*")
+            # Backward is captured from THIS thread (PyTorch would run it on a per-device worker thread).
+            # (_threaded_backward: tools/probes/graph_topology.py only -- what PyTorch's worker thread does to the capture)
+            with torch.autograd.set_multithreading_enabled(bool(_threaded_backward)):
+                with torch.cuda.stream(side):
+                    for _ in range(max(1, warmup)):   # records the weight-image jobs, sizes the pools, creates optimizer state
+                        self._new_seed()
+                        self._body(True)
+                    optimizer.zero_grad(set_to_none=True)    # the capture starts without autograd state of the warm-up
+                side.synchronize()
+                # the captured launches carry raw pointers into the model's weight-image plan: keep it alive and un-evicted
+                self._plan = model.__dict__.get("_pack_plan")
+                if self._plan is not None:
+                    self._plan.pin()
+                with torch.cuda.graph(self._graph, stream=side):
+                    outs, loss = self._body(self.capture_optimizer)
+                    outs = tuple(o.detach() for o in outs) if isinstance(outs, tuple) else outs.detach()
+                    loss = loss.detach()
         torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        # the captured launches carry raw pointers into the model's weight-image plan: keep it alive and un-evicted
-        self._plan = model.__dict__.get("_pack_plan")
-        if self._plan is not None:
-            self._plan.pin()
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(self._graph):
-            outs, loss = self._body(self.capture_optimizer)
+        if check_topology:
+            self.topology = graph_topology(self._graph.raw_cuda_graph(), debug_dot)
+            self._graph.instantiate()
         # eager passes of the model (evaluation, instrumented steps) must draw their own seeds again: the captured head
         # launches hold the address of the device word themselves
         model._dropout_seed_dev = None
@@ -93,26 +159,40 @@ class GraphedTrainStep:
         self._grads = [(p, p.grad) for p in params if p.grad is not None]
         self._param_ptrs = [p.data_ptr() for p in params]
         if saved is not None:
-            with torch.no_grad():
-                for p, v in zip(params, saved[0]):
-                    p.copy_(v)
-                for b, v in zip(model.buffers(), saved[1]):
-                    b.copy_(v)
-                for t in self._optimizer_tensors():
-                    if id(t) in saved[2]:
-                        t.copy_(saved[2][id(t)])
-                    else:
-                        t.zero_()   # state the warm-up created (moments, step counters): as before the first step
-            if self._plan is not None:
-                self._plan.invalidate()
+            self._restore(params, saved)
+        torch.cuda.synchronize(dev)
 
-    def _optimizer_tensors(self):
-        out = []
-        for st in self.optimizer.state.values():
-            for v in st.values():
-                if torch.is_tensor(v):
-                    out.append(v)
-        return out
+    def _restore(self, params, saved):
+        """Undo the warm-up: parameters, buffers, optimizer state as they were before ``__init__``."""
+        with torch.no_grad():
+            for p, v in zip(params, saved[0]):
+                p.copy_(v)
+            for b, v in zip(self.model.buffers(), saved[1]):
+                b.copy_(v)
+            before, had = saved[2], saved[3]
+            ids = [p for grp in self.optimizer.param_groups for p in grp["params"]]
+            old_state = before["state"]                       # keyed by the parameter's index in param_groups order
+            for idx, p in enumerate(ids):
+                st = self.optimizer.state.get(p)
+                if st is None:
+                    continue
+                if id(p) not in had and not self.capture_optimizer:
+                    del self.optimizer.state[p]               # created by the warm-up: the first real step creates it again
+                    continue
+                old = old_state.get(idx, {})
+                for k in list(st.keys()):
+                    v = st[k]
+                    if torch.is_tensor(v):
+                        if k in old and torch.is_tensor(old[k]):
+                            v.copy_(old[k])
+                        else:
+                            v.zero_()                         # captured optimizer: its state tensors are graph addresses
+                    elif k in old:
+                        st[k] = copy.deepcopy(old[k])
+                    elif isinstance(v, (int, float)):
+                        st[k] = type(v)(0)
+        if self._plan is not None:
+            self._plan.invalidate()
 
     def _new_seed(self):
         # CPU generator, as the eager path draws its seed (engine._dropout_config); fill_ takes it as a launch argument

@@ -452,9 +452,10 @@ def wgrad(n: int, h: int, w: int, taps: int, xs: Sequence[V], dys: Sequence[V], 
         target_blocks = 2048  # the 1..4-channel first layer runs an HBM-bound VALU kernel: many small workgroups
     d.flags = (_lib.GEMM_DIRECT if (direct or not USE_WINOGRAD) else 0) | _storage_flag(dys, xs)
     wg_pairs = int(lib.unetpp_wgrad_pairs_per_workgroup(C.byref(d)))
-    reserved = int(lib.unetpp_set_reserved_cus(-1))   # data parallel: CUs left to the collective (0 unless asked for)
-    if reserved > 0:
-        target_blocks = max(8, target_blocks * (256 - min(reserved, 248)) // 256)
+    phys = C.c_int32(0)
+    usable = int(lib.unetpp_usable_cus(C.byref(phys)))   # data parallel: CUs not left to the collective (all unless asked)
+    if 0 < usable < phys.value:
+        target_blocks = max(8, target_blocks * usable // phys.value)
     if dys[0].t.dtype == torch.bfloat16 and target_blocks == 256 and wg_pairs == 1:
         target_blocks = 512  # the bf16 pair kernel runs two 4-wave workgroups per CU (the quad kernel one of 8 waves)
     split = max(1, min(int(lib.unetpp_wgrad_max_split(n, h, w)), target_blocks // max(1, pairs // max(1, wg_pairs))))
