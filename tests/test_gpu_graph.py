@@ -58,7 +58,11 @@ def test_graphed_step_is_bit_identical_to_eager(dev, ctor, bf16, opt_kind, captu
     g = torch.Generator().manual_seed(5)
     xs = [torch.randn(2, ctor["in_channels"], 64, 64, generator=g).to(dev) for _ in range(4)]
     ts = [torch.rand(2, ctor["n_classes"], 64, 64, generator=g).to(dev) for _ in range(4)]
-    step = GraphedTrainStep(a, oa, crit, xs[0], ts[0], capture_optimizer=capture_opt)
+    step = GraphedTrainStep(a, oa, crit, xs[0], ts[0], capture_optimizer=capture_opt, check_topology=True)
+    # what was captured is the plain chain graph.py assumes (hipGraphGetNodes / hipGraphGetEdges): kernels only, one root,
+    # one leaf, nobody with two successors or two predecessors
+    topo = step.topology
+    assert topo["chain"] and set(topo["kinds"]) == {"kernel"} and topo["nodes"] > 100, topo
     # the warm-up steps left no trace: parameters and buffers are the initial ones
     for k, v in a.state_dict().items():
         assert torch.equal(v, before[k]), k

@@ -175,3 +175,70 @@ def test_eval_forward_reads_no_unwritten_memory(dev):
                 got = got if isinstance(got, tuple) else (got,)
                 for p, q in zip(ref, got):
                     assert torch.equal(p, q)
+
+
+@pytest.mark.parametrize("name,ctor,bf16", [
+    ("bf16-bilinear-fs2", dict(in_channels=1, n_classes=4, feature_scale=2, is_deconv=False), True),   # GPUTEST_r04's network
+    ("bf16-deconv-fs2", dict(in_channels=1, n_classes=4, feature_scale=2), True),                       # dgrad into 32 channels: one column tile
+    ("f32-fs2", dict(in_channels=1, n_classes=4, feature_scale=2), False),
+], ids=lambda v: v if isinstance(v, str) else None)
+def test_the_step_is_reproducible_run_to_run(dev, name, ctor, bf16):
+    """Every tensor of a training step -- all activations kept for backward, BatchNorm coefficients, outputs, loss,
+    every gradient -- is bit-identical from run to run, back to back and from an idle device (no floating-point
+    atomics on the path; every cross-workgroup sum has a fixed order).  This is the comparison that found the cause of
+    GPUTEST_r04: one 256-pixel x 32-column unit of the bilinear path's 1x1 convolution differed in ~1 of 100 steps
+    (profiles/r5/gputest_r04_root_cause.txt).  Twelve runs per regime: a guard, not a stress loop."""
+    import time
+
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, UNet_Nested
+    torch.manual_seed(81)
+    m = UNet_Nested(**ctor).to(dev).train()
+    if bf16:
+        m.set_activation_dtype(BF)
+    m.drop_out.p = 0.0
+    m._debug_keep_saved = True
+    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 1, 64, 64, generator=g).to(dev)
+    t = torch.rand(2, 4, 64, 64, generator=g).to(dev)
+    running = [b.clone() for b in m.buffers()]
+
+    def one_step():
+        for p in m.parameters():
+            p.grad = None
+        outs = m(x)
+        loss = sum(crit(o, t) for o in outs) / len(outs)
+        s = m._debug_saved
+        got = {}
+        for key, r in s.pairs.items():
+            for nm in ("y1", "a1", "y2", "out", "pooled", "pool_idx"):
+                v = getattr(r, nm)
+                if v is not None:
+                    got["X%d%d.%s" % (key + (nm,))] = v.clone()
+        for key, u in s.ups.items():
+            for nm in ("interp", "up"):
+                v = getattr(u, nm)
+                if v is not None:
+                    got["up%d%d.%s" % (key + (nm,))] = v.clone()
+        for i, o in enumerate(outs):
+            got["out%d" % i] = o.detach().clone()
+        got["loss"] = loss.detach().clone()
+        loss.backward()
+        for k, p in m.named_parameters():
+            got["grad/" + k] = p.grad.clone()
+        with torch.no_grad():
+            for b, v in zip(m.buffers(), running):
+                b.copy_(v)
+        torch.cuda.synchronize()
+        return got
+
+    def bits(v):
+        return v.view(torch.int16) if v.dtype == BF else v
+
+    ref = one_step()
+    for i in range(24):
+        if i >= 12:
+            time.sleep(0.01)    # idle start
+        got = one_step()
+        bad = [k for k in ref if not torch.equal(bits(ref[k]), bits(got[k]))]
+        assert not bad, "run %d: %d tensors differ, first %s" % (i, len(bad), bad[:4])

@@ -28,12 +28,12 @@ class GraphedForward:
             raise RuntimeError("GraphedForward captures the eval forward: call model.eval() first")
         self.model = model
         self._x = example.clone()
-        side = torch.cuda.Stream(device=example.device)
+        side = torch.cuda.Stream(device=example.device)   # warm-up AND capture run on this one stream (as graph.py)
         side.wait_stream(torch.cuda.current_stream(example.device))
         with torch.no_grad(), torch.cuda.stream(side):
             for _ in range(max(1, warmup)):  # first passes record the weight-image jobs and size the allocator pools
                 model(self._x)
-        torch.cuda.current_stream(example.device).wait_stream(side)
+        side.synchronize()
         # The captured launches carry raw pointers into the model's weight-image plan (the images and the device job
         # table of the in-graph pack launch): pin the plan so that neither is evicted / freed while this graph lives,
         # and remember what was captured -- a replay after the plan changed shape (set_activation_dtype, a differently
@@ -42,8 +42,9 @@ class GraphedForward:
         if self._plan is not None:
             self._plan.pin()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self._graph):
+        with torch.no_grad(), torch.cuda.graph(self._graph, stream=side):
             outs = model(self._x)
+        torch.cuda.current_stream(example.device).wait_stream(side)
         self._held = None
         if self._plan is not None:
             self._held = (self._plan._tables.get("fwd"), [e.image for e in self._plan.entries.values()])
