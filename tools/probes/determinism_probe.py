@@ -75,6 +75,14 @@ def main():
         ("bf16-deconv-fs2-64", dict(in_channels=1, n_classes=4, feature_scale=2), True, 2, 64),
         ("f32-fs4-64", dict(in_channels=1, n_classes=4, feature_scale=4), False, 2, 64),
         ("bf16-d5-fs4-64", dict(in_channels=3, n_classes=5, feature_scale=4, depth=5), True, 2, 64),
+        # wider sweep (round 5, after the fix): the other structures and larger geometries, both storages
+        ("wide-f32-base32-128", dict(in_channels=1, n_classes=4, feature_scale=1), False, 4, 128),
+        ("wide-bf16-base32-128", dict(in_channels=1, n_classes=4, feature_scale=1), True, 4, 128),
+        ("wide-bf16-d5-base64-96", dict(in_channels=3, n_classes=5, feature_scale=0.5, depth=5), True, 2, 96),
+        ("wide-f32-bilinear-nobn-fs2", dict(in_channels=3, n_classes=5, feature_scale=2, is_deconv=False, is_batchnorm=False), False, 2, 64),
+        ("wide-bf16-nobn-fs2", dict(in_channels=1, n_classes=4, feature_scale=2, is_batchnorm=False), True, 2, 96),
+        ("wide-f32-fs2-160", dict(in_channels=3, n_classes=4, feature_scale=2), False, 2, 160),
+        ("wide-bf16-bilinear-base32-96", dict(in_channels=1, n_classes=4, feature_scale=1, is_deconv=False), True, 2, 96),
     ]
     crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
     for name, ctor, bf16, b, size in cases:

@@ -1278,10 +1278,12 @@ inline long bn_bwd_blocks_for(long pixels, int C, bool vec) {
 }  // namespace
 
 namespace {
-// Unused rows of a partial-sum workspace are zeroed by a KERNEL, not by hipMemsetAsync: inside a captured training step
-// (graph.GraphedTrainStep) a memset node of ROCm 7.2's hipGraph was not reliably ordered against the kernel nodes around
-// it -- the BatchNorm-backward finalize summed rows the memset had not cleared yet, whenever a replay started on an idle
-// device (tools/probes/dbg_graph4.py: encoder gradients of 1e19 .. inf from the second replay on).
+// Unused rows of a partial-sum workspace are zeroed by a KERNEL, not by hipMemsetAsync.  History: round 4 saw non-finite
+// BatchNorm gradients from the second replay of a captured training step and blamed the ordering of memset NODES; round 5
+// read the captured graph back (tools/probes/graph_topology.py): memset nodes sit in the chain like any kernel node and
+// the symptom did not reproduce once warm-up and capture shared one stream.  The kernel stays -- it
+// costs the same and keeps the captured step a chain of kernel nodes only; unetpp_debug_set("MEMSET_NODES", 1) switches
+// to the memset for that probe.
 __global__ __launch_bounds__(kThreads) void zero_rows_kernel(float* __restrict__ p, long n) {
   for (long i = blockIdx.x * static_cast<long>(kThreads) + threadIdx.x; i < n; i += static_cast<long>(gridDim.x) * kThreads)
     p[i] = 0.f;
