@@ -36,9 +36,9 @@ def report(path, defines=()):
             continue
         if cur is None:
             continue
-        for key, pat in (("vgpr", r" VGPRs: (\d+)"), ("agpr", r"AGPRs: (\d+)"), ("sgpr", r" SGPRs: (\d+)"),
-                         ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("vspill", r"VGPR Spill: (\d+)"),
-                         ("sspill", r"SGPR Spill: (\d+)"), ("occ", r"Occupancy \[waves/SIMD\]: (\d+)"),
+        for key, pat in (("vgpr", r" VGPRs: (\d+)"), ("agpr", r"AGPRs: (\d+)"), ("sgpr", r"TotalSGPRs: (\d+)"),
+                         ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("vspill", r"VGPRs Spill: (\d+)"),
+                         ("sspill", r"SGPRs Spill: (\d+)"), ("occ", r"Occupancy \[waves/SIMD\]: (\d+)"),
                          ("lds", r"LDS Size \[bytes/block\]: (\d+)")):
             m = re.search(pat, ln)
             if m:
@@ -49,6 +49,15 @@ def report(path, defines=()):
     return rows
 
 
+def all_reports(files=None, defines=(), workers=6):
+    """[(file, rows)] for the given sources (default: every .hip of the library), compiled in parallel"""
+    from concurrent.futures import ThreadPoolExecutor
+    files = files or sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+    paths = [f if os.path.exists(f) else os.path.join(CSRC, f) for f in files]
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        return list(zip(files, ex.map(lambda p: report(p, defines), paths)))
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("-")]
     spills_only = "--spills-only" in sys.argv
@@ -56,8 +65,8 @@ def main():
     args = [a for a in args if a not in defines]
     files = args or sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
     bad = 0
-    for f in files:
-        for r in report(f if os.path.exists(f) else os.path.join(CSRC, f), defines):
+    for f, rows in all_reports(files, defines):
+        for r in rows:
             spilled = r.get("vspill", 0) or r.get("sspill", 0) or r.get("scratch", 0)
             bad += int(bool(r.get("vspill", 0) or r.get("scratch", 0)))
             if spills_only and not spilled:

@@ -39,11 +39,16 @@ __device__ unsigned long long g_gbf_stamps[16];
   } while (0)
 #endif
 
+// Workgroups per CU = the register budget.  Round 5: TWO everywhere (256 registers, no spills, no scratch).  Until round 4
+// the one-tile and the statistics instantiations ran three per CU at 168 registers with 3-23 registers spilled; since the
+// LDS-DMA kernel took the plain launches (gemm_bf16_dma.hip) this kernel only runs the launches with a load transform --
+// one per step in the benchmark configurations (conv2 of X_0,0 with the BatchNorm fold) -- and the A/B of round 4 had the
+// spill-free two-per-CU build equal to the spilling three-per-CU one on it (profiles/r4, section 5 of DESIGN.md).
 #ifndef UNETPP_BF16_WGS
-#define UNETPP_BF16_WGS(TAPS, NT) (((NT) == 2 && (TAPS) == 9) ? 2 : 3)
+#define UNETPP_BF16_WGS(TAPS, NT) 2
 #endif
-#ifndef UNETPP_BF16_STATS_WGS   // workgroups per CU of the BatchNorm-statistics instantiations (3: 168 registers, 8-23 spilled)
-#define UNETPP_BF16_STATS_WGS 3
+#ifndef UNETPP_BF16_STATS_WGS
+#define UNETPP_BF16_STATS_WGS 2
 #endif
 constexpr int BKC = 32;        // channels per K chunk
 constexpr int BPIX = 80;       // LDS bytes per staged pixel (64 + 16 pad)
@@ -625,7 +630,7 @@ int launch_gemm_bf16(const unetpp_gemm_desc* d, hipStream_t st) {
   const int cus = device_cu_count();
   if (cus <= 0) return UNETPP_ELAUNCH;
   // = the kernels' launch bounds (four workgroups per CU for the pointwise GEMMs: 128 VGPRs, spills, 2x slower)
-  long workers = ((d->taps == 9 && a.nt_unit == 2 ? 2L : 3L) * cus) & ~7L;
+  long workers = (static_cast<long>(UNETPP_BF16_WGS(d->taps, a.nt_unit)) * cus) & ~7L;
   if (d->stats_partial != nullptr) workers = (static_cast<long>(UNETPP_BF16_STATS_WGS) * cus) & ~7L;
   if (workers < 8) workers = 8;
   const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(kThreads);

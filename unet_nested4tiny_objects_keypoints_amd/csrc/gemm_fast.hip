@@ -81,6 +81,13 @@ __global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : UNETPP_FAST_P
   int p_n = 0, p_ty0 = 0, p_tx0 = 0;
   const float* p_wimg = nullptr;
 
+  // (per-unit code: everything per-thread below derives from a thread index that is "produced" in place, so that hipcc
+  // cannot hoist the items' halo coordinates out of the unit loop into registers the MFMA loop needs -- kept live across
+  // the loop they were the 3-11 registers this kernel spilled under its 168 / 128-register bounds until round 4)
+  auto in_place = [](int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+  };
   auto prefetch_unit = [&](long k) {  // geometry of unit k for the loads
     const UnitGeom g = decode_unit<LOG2TW>(a, first_unit + k * unit_step);
     p_n = g.n;
@@ -88,9 +95,10 @@ __global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : UNETPP_FAST_P
     p_tx0 = g.tx0;
     p_wimg = d.weight_image + static_cast<long>(g.group) * NT * a.n_chunks * IMG;
     in_mask = 0;
+    const int tidp = in_place(tid);
 #pragma unroll
     for (int q = 0; q < IN_ITEMS; ++q) {
-      const int it = tid + q * kThreads;
+      const int it = tidp + q * kThreads;
       const int hp = it >> 2;
       const int hy = hp / HWp, hx = hp - hy * HWp;
       const int y = p_ty0 + hy - HALO, x = p_tx0 + hx - HALO;
@@ -101,9 +109,10 @@ __global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : UNETPP_FAST_P
   // items are clamped into the image, channels past the view to channel 0) and the zeroing happens at the LDS
   // write.  Conditional loads would sit under divergent branches, where hipcc drains vmcnt at every join.
   auto view_offsets = [&](const unetpp_view& V) {
+    const int tidp = in_place(tid);
 #pragma unroll
     for (int q = 0; q < IN_ITEMS; ++q) {
-      const int hp = min((tid + q * kThreads) >> 2, NPIX - 1);
+      const int hp = min((tidp + q * kThreads) >> 2, NPIX - 1);
       const int hy = hp / HWp, hx = hp - hy * HWp;
       const int yy = min(max(p_ty0 + hy - HALO, 0), d.H - 1), xx = min(max(p_tx0 + hx - HALO, 0), d.W - 1);
       voff[q] = static_cast<unsigned>(view_pixel_offset(V, p_n, yy, xx));
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(kThreads, (TAPS == 1 ? (NT == 1 ? 4 : UNETPP_FAST_P
           }
         } else {
 #pragma unroll
-          for (int half = 0; half < 2; ++half) {  // two pieces per batch: four would spill under the 168-register bound
+          for (int half = 0; half < 2; ++half) {  // two pieces per batch: four spill under the 168-register bound (re-checked in round 5)
             f32x4 gt[2], old[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {  // dead pieces read the tile's first (always valid) address

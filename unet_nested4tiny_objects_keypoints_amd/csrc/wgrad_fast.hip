@@ -106,7 +106,12 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_fast_kernel(const WFastArg
   };
   // Loads are branch-free (coordinates clamped into the image, channels past the tile clamped to 0) so that
   // hipcc keeps them in flight across the MFMA quarter; the zeroing happens at the LDS write.
+  auto in_place = [](int v) {  // a thread index "produced" where it is used: item coordinates are not hoisted out of the tile loop
+    asm volatile("" : "+v"(v));
+    return v;
+  };
   auto load_item = [&](int q) -> f32x4 {
+    const int tid = in_place(static_cast<int>(threadIdx.x));
     if (q < X_ITEMS) {
       const int it = tid + q * kWThreads;
       const int hp = min(it >> 3, NPIX - 1), cc = (it & 7) << 2;
