@@ -12,11 +12,12 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 # Order of the GPU suite (the driver runs `pytest -x`): parity against the oracle / the reference's golden fixtures comes
 # first -- per kernel, then whole network, then the benchmarked block, the caller, the bf16 twins, the classic UNet, key
 # points, the >2 GB operands -- then the data-parallel path, and LAST the tests that only compare the library with
-# itself (HIP-graph replay against the eager step, workspace poisoning): a failure there must never hide a parity row
+# itself (repeatability of every kernel, workspace poisoning, HIP-graph replay against the eager step): a failure there must never hide a parity row
 # of SURVEY.md section 8 (reference path models/unet.py:121-300).
 _GPU_ORDER = [
     "test_gpu_kernels", "test_gpu_model", "test_gpu_x00_block", "test_gpu_caller", "test_gpu_bf16",
-    "test_gpu_unet_plain", "test_keypoints", "test_gpu_large", "test_gpu_dp", "test_gpu_workspaces", "test_gpu_graph",
+    "test_gpu_unet_plain", "test_keypoints", "test_gpu_large", "test_gpu_dp", "test_gpu_repeat", "test_gpu_workspaces",
+    "test_gpu_graph",
 ]
 _LAST_KEYWORDS = ("graphed", "GraphedForward", "graph_replay")   # self-comparison cases inside parity files
 

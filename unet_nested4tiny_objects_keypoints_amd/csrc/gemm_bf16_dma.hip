@@ -93,11 +93,17 @@ struct DmaArgs {
 // that holds the launch's WHOLE weight image when it has at most four (tile, chunk) images (K = 128 -> 32, 64 -> 64):
 // everything that passes through a CU's vector memory path costs the same whether it comes from HBM or hits the L2, so
 // the bytes per pixel -- halo, patch re-staging per column group, weight re-streaming per chunk -- are what to cut.
-template <int TAPS, int LOG2TW, int NT, bool STATS, int WAVES = 4>
-__global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaArgs da) {
+// RMW = false (round 5, pointwise launches only): no output view has a ReLU gate or an accumulate flag -- the forward of a
+// transposed convolution / 1x1 convolution.  The epilogue then carries no gate / previous-value operands (64 registers for
+// two column tiles), the kernel fits 168 registers and THREE workgroups share a CU: a pointwise unit is 16 MFMAs per wave
+// behind 40 KB of DMA, so what it needs is more bytes in flight per CU, and a third workgroup is the cheapest way to get
+// them (its LDS is 40 KB).
+template <int TAPS, int LOG2TW, int NT, bool STATS, int WAVES = 4, bool RMW = true>
+__global__ __launch_bounds__(64 * WAVES, RMW ? 2 : 3) void gemm_bf16_dma_kernel(const DmaArgs da) {
   const FastArgs& a = da.f;
   constexpr int THREADS = 64 * WAVES, PIX = 64 * WAVES;
   static_assert(WAVES == 4 || (WAVES == 8 && TAPS == 9 && !STATS), "the 8-wave form: plain 3x3 launches");
+  static_assert(RMW || (TAPS == 1 && WAVES == 4 && !STATS), "the three-per-CU form: plain pointwise launches");
   constexpr int HALO = (TAPS == 9) ? 1 : 0;
   constexpr int TW = 1 << LOG2TW, TH = PIX >> LOG2TW;
   constexpr int HWp = TW + 2 * HALO, HHp = TH + 2 * HALO;
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
   // register of the load is rewritten there), which makes every unit wait for the previous unit's output stores.
   struct EpiOps {
     f32x4 b4[NT][4];
-    u32x4 gate_raw[NT][2][2], old_raw[NT][2][2];
+    u32x4 gate_raw[RMW ? NT : 1][2][2], old_raw[RMW ? NT : 1][2][2];   // (!RMW: never touched, no registers)
   };
   EpiOps eo;
   auto asm_load16 = [](auto& dst, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p)); };
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
           asm_load16(eo.b4[t][q], d.bias + tc.n0 + c);
         }
       }
-      if (gptr != nullptr || O.accumulate) {  // uniform
+      if (RMW && (gptr != nullptr || O.accumulate)) {  // uniform
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           const bool pix_ok = (g.ty0 + epi_py[mt] < d.H) && (g.tx0 + epi_px[mt] < d.W);
@@ -456,8 +462,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
           for (int half = 0; half < 2; ++half) {
             const int c0 = 16 * half + 8 * (1 - h);
             const unsigned off = (pix_ok && c0 < tc.n_cnt) ? pbase + c0 : tile_base;  // dead pieces: any valid address
-            if (gptr != nullptr) asm_load16(eo.gate_raw[t][mt][half], gptr + off);
-            if (O.accumulate) asm_load16(eo.old_raw[t][mt][half], optr + off);
+            if (gptr != nullptr) asm_load16(eo.gate_raw[RMW ? t : 0][mt][half], gptr + off);
+            if (O.accumulate) asm_load16(eo.old_raw[RMW ? t : 0][mt][half], optr + off);
           }
         }
       }
@@ -470,7 +476,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
       const TileCols tc = decode_tile(a, g.group * NT + t);
       const unetpp_view& O = d.out[tc.ov];
       bf16_t* optr = reinterpret_cast<bf16_t*>(O.ptr);
-      const bool has_gate = O.gate != nullptr, acc_out = O.accumulate != 0;  // uniform
+      const bool has_gate = RMW && O.gate != nullptr, acc_out = RMW && O.accumulate != 0;  // uniform
       const unsigned row_stride = static_cast<unsigned>(O.sy) * O.Ws * O.C, col_stride = static_cast<unsigned>(O.sx) * O.C;
       const unsigned tile_base = view_pixel_offset32(O, g.n, g.ty0, g.tx0) + tc.nt * 32;
 #pragma unroll
@@ -506,14 +512,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
             float v[8];
             unpack8(out, v);
             float gt[8];
-            if (has_gate) unpack8(eo.gate_raw[t][mt][half], gt);
+            if (has_gate) unpack8(eo.gate_raw[RMW ? t : 0][mt][half], gt);
             if (has_gate && !O.gate_sum) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = (gt[e] > 0.f) ? v[e] : 0.f;
             }
             if (acc_out) {
               float old[8];
-              unpack8(eo.old_raw[t][mt][half], old);
+              unpack8(eo.old_raw[RMW ? t : 0][mt][half], old);
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] += old[e];
             }
@@ -606,8 +612,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void gemm_bf16_dma_kernel(const DmaA
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(eo.b4[t][0]), "+v"(eo.b4[t][1]), "+v"(eo.b4[t][2]), "+v"(eo.b4[t][3])::"memory");
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(eo.gate_raw[t][0][0]), "+v"(eo.gate_raw[t][0][1]), "+v"(eo.gate_raw[t][1][0]), "+v"(eo.gate_raw[t][1][1])::"memory");
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(eo.old_raw[t][0][0]), "+v"(eo.old_raw[t][0][1]), "+v"(eo.old_raw[t][1][0]), "+v"(eo.old_raw[t][1][1])::"memory");
+        if constexpr (RMW) {
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(eo.gate_raw[t][0][0]), "+v"(eo.gate_raw[t][0][1]), "+v"(eo.gate_raw[t][1][0]), "+v"(eo.gate_raw[t][1][1])::"memory");
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(eo.old_raw[t][0][0]), "+v"(eo.old_raw[t][0][1]), "+v"(eo.old_raw[t][1][0]), "+v"(eo.old_raw[t][1][1])::"memory");
+        }
       }
     }
     DMA_STAMP(3);  // 3: wait for the DMA (and whatever is older: the previous unit's stores)
@@ -795,20 +803,29 @@ int launch_gemm_bf16_dma(const unetpp_gemm_desc* d, hipStream_t st) {
     a.n_groups = a.n_tiles;
     a.total_blocks *= 2;
   }
-  long workers = (2L * cus) & ~7L;
+  // pointwise launches whose output views carry no gate / accumulate flag (the forward of a transposed or 1x1 convolution):
+  // the three-per-CU instantiation (UNETPP_BF16_PW_PLAIN=0 / unetpp_debug_set keeps them on the two-per-CU one: A/B runs)
+  bool plain_out = d->taps == 1 && !stats && opt_value(OPT_BF16_PW_PLAIN, 1) != 0;
+  for (int i = 0; i < d->n_out; ++i) plain_out = plain_out && d->out[i].gate == nullptr && d->out[i].accumulate == 0;
+  long workers = ((plain_out ? 3L : 2L) * cus) & ~7L;
   if (workers < 8) workers = 8;
   const dim3 grid(static_cast<unsigned>(a.total_blocks <= workers ? a.total_blocks : workers)), block(kThreads);
-#define UNETPP_LAUNCH_BF16_DMA(T, NTU, ST)                                                                     \
-  do {                                                                                                         \
-    if (a.log2tw == 5) hipLaunchKernelGGL((gemm_bf16_dma_kernel<T, 5, NTU, ST>), grid, block, 0, st, da);      \
-    else if (a.log2tw == 4) hipLaunchKernelGGL((gemm_bf16_dma_kernel<T, 4, NTU, ST>), grid, block, 0, st, da); \
-    else hipLaunchKernelGGL((gemm_bf16_dma_kernel<T, 3, NTU, ST>), grid, block, 0, st, da);                    \
+#define UNETPP_LAUNCH_BF16_DMA(T, NTU, ST, RW)                                                                         \
+  do {                                                                                                                 \
+    if (a.log2tw == 5) hipLaunchKernelGGL((gemm_bf16_dma_kernel<T, 5, NTU, ST, 4, RW>), grid, block, 0, st, da);      \
+    else if (a.log2tw == 4) hipLaunchKernelGGL((gemm_bf16_dma_kernel<T, 4, NTU, ST, 4, RW>), grid, block, 0, st, da); \
+    else hipLaunchKernelGGL((gemm_bf16_dma_kernel<T, 3, NTU, ST, 4, RW>), grid, block, 0, st, da);                    \
   } while (0)
   if (d->taps == 9) {
-    if (stats) UNETPP_LAUNCH_BF16_DMA(9, 1, true);
-    else UNETPP_LAUNCH_BF16_DMA(9, 1, false);
-  } else if (a.nt_unit == 2) UNETPP_LAUNCH_BF16_DMA(1, 2, false);
-  else UNETPP_LAUNCH_BF16_DMA(1, 1, false);
+    if (stats) UNETPP_LAUNCH_BF16_DMA(9, 1, true, true);
+    else UNETPP_LAUNCH_BF16_DMA(9, 1, false, true);
+  } else if (a.nt_unit == 2) {
+    if (plain_out) UNETPP_LAUNCH_BF16_DMA(1, 2, false, false);
+    else UNETPP_LAUNCH_BF16_DMA(1, 2, false, true);
+  } else {
+    if (plain_out) UNETPP_LAUNCH_BF16_DMA(1, 1, false, false);
+    else UNETPP_LAUNCH_BF16_DMA(1, 1, false, true);
+  }
 #undef UNETPP_LAUNCH_BF16_DMA
   note_kernel(d->taps == 9 ? "gemm_bf16_dma_kernel<9>" : "gemm_bf16_dma_kernel<1>");
   return launch_status();
