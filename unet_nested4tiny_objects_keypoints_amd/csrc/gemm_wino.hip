@@ -618,6 +618,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 
   int c_chunk = 0, c_unit = 0;  // compute side: chunk of unit c_ug currently in LDS
   int cur = 0;                  // buffer being computed from
+#ifdef UNETPP_WINO_STAGGER
+  // experiment (tools/ab_lib.sh): the two workgroups of a CU run the same program on equal units from the same start, so
+  // their staging / barrier / epilogue phases can coincide; the second half of the grid starts N x 1024 cycles late
+  if (blockIdx.x >= (gridDim.x >> 1)) {
+    for (int i = 0; i < UNETPP_WINO_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
   while (true) {
     // ---- this chunk's first LDS operands are requested before the staging work below, which covers their latency
     const unsigned in_b = lds_offset(in_tile) + a_base * 4, w_b = lds_offset(w_tile) + b_base * 4;
