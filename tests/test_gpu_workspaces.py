@@ -242,3 +242,51 @@ def test_the_step_is_reproducible_run_to_run(dev, name, ctor, bf16):
         got = one_step()
         bad = [k for k in ref if not torch.equal(bits(ref[k]), bits(got[k]))]
         assert not bad, "run %d: %d tensors differ, first %s" % (i, len(bad), bad[:4])
+
+
+def test_classic_unet_step_reads_no_unwritten_memory_and_is_reproducible(dev):
+    """The same two properties for the classic UNet (models/unet.py:8-117; engine_unet.py schedules the same kernels,
+    plus floor pooling / zero padding of odd sizes): poisoned + guard-banded allocations change nothing, and eight runs
+    of the step give bit-identical outputs, loss and gradients."""
+    from unet_nested4tiny_objects_keypoints_amd import FocalLoss_BCE_2d, UNet
+    torch.manual_seed(29)
+    base = UNet(n_classes=5, n_channels=3, widths=(16, 32, 64, 128, 128)).to(dev).train()
+    crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 3, 40, 56, generator=g).to(dev)       # not a multiple of 16: the reference's padding path
+    t = torch.rand(2, 5, 40, 56, generator=g).to(dev)
+
+    def run(poison=None, guard=False):
+        m = copy.deepcopy(base)
+        xx, tt = x, t
+        if guard:
+            with torch.no_grad():
+                for p in list(m.parameters()) + list(m.buffers()):
+                    p.data = guarded(p.data, poison)
+            xx, tt = guarded(x, poison), guarded(t, poison)
+        ctx = contextlib.nullcontext() if poison is None else poisoned_empty(poison, guard)
+        with ctx:
+            for _ in range(2):
+                for p in m.parameters():
+                    p.grad = None
+                out = m(xx)
+                loss = crit(out, tt)
+                loss.backward()
+        torch.cuda.synchronize()
+        d = {"out": out.detach().clone(), "loss": loss.detach().clone()}
+        d.update({"grad/" + k: p.grad.clone() for k, p in m.named_parameters()})
+        return d
+
+    ref = run()
+    for k, v in ref.items():
+        assert torch.isfinite(v).all(), k
+    for poison, guard in ((float("nan"), False), (3.0e30, True), (float("nan"), True)):
+        got = run(poison, guard)
+        bad = [k for k in ref if not torch.equal(ref[k], got[k])]
+        assert not bad, "poison %r (guard bands: %s): %s" % (poison, guard, bad[:6])
+    for i in range(8):
+        if i % 2:
+            torch.cuda.synchronize()
+        got = run()
+        bad = [k for k in ref if not torch.equal(ref[k], got[k])]
+        assert not bad, "run %d: %s" % (i, bad[:6])
