@@ -241,18 +241,36 @@ __global__ __launch_bounds__(kThreads) void small_cin_wgrad_kernel(const SmallAr
     __syncthreads();
     stage_patch<CIN>(a, xs, n, ty0, tx0, TW, TH);
     __syncthreads();
-    for (int p = psub; p < kBlockPixels; p += pstep) {
-      const int py = p >> a.log2tw, px = p & (TW - 1);
-      const int y = ty0 + py, x = tx0 + px;
-      if (y < a.H && x < a.W) {
-        const long o = ((static_cast<long>(n) * a.H + y) * a.W + x) * a.yC + 4 * quad;
+    // Round 5: the dy quads of this thread's pixels are requested in batches of eight BEFORE the arithmetic of the batch.
+    // The one-pixel-at-a-time loop exposed a memory round trip per pixel (a dependent load at the head of 36..108 FMAs,
+    // 8..32 pixels per thread and patch): the kernel ran at 0.8-1.0 TB/s of its 16 us HBM floor's 5 (configs[4]: 99 us).
+    // Same pixels in the same order per thread; a pixel outside the image contributes g = 0 (x * 0 added: no change).
+    constexpr int G = (CIN == 4) ? 4 : 8;   // (36 accumulator quads at CIN = 4: a batch of eight does not fit the register file)
+    for (int p0 = psub; p0 < kBlockPixels; p0 += G * pstep) {
+      f32x4 gq[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int p = p0 + u * pstep;
+        const int py = p >> a.log2tw, px = p & (TW - 1);
+        const int y = ty0 + py, x = tx0 + px;
+        const bool ok = (p < kBlockPixels) & (y < a.H) & (x < a.W);
+        // dead items read the patch's first pixel (always inside the image): straight-line loads, no branch
+        const long o = ((static_cast<long>(n) * a.H + (ok ? y : ty0)) * a.W + (ok ? x : tx0)) * a.yC + 4 * quad;
         f32x4 g;
         if (BF) {
-          const u32x2 u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(a.dy) + o);
-          g = f32x4{bf_lo(u[0]), bf_hi(u[0]), bf_lo(u[1]), bf_hi(u[1])};
+          const u32x2 v = *reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(a.dy) + o);
+          g = f32x4{bf_lo(v[0]), bf_hi(v[0]), bf_lo(v[1]), bf_hi(v[1])};
         } else {
           g = *reinterpret_cast<const f32x4*>(a.dy + o);
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gq[u][e] = ok ? g[e] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int p = min(p0 + u * pstep, kBlockPixels - 1);   // (dead items: any staged pixel, times zero)
+        const int py = p >> a.log2tw, px = p & (TW - 1);
+        const f32x4 g = gq[u];
 #pragma unroll
         for (int e = 0; e < 4; ++e) db[e] += g[e];
 #pragma unroll

@@ -169,6 +169,10 @@ class V:
 
 
 USE_FAST_GEMM = True  # tests flip this to exercise the generic kernel on the same shapes
+# workgroups of the first layer's weight gradient (A/B knob).  Round 5: 1024 (four per CU) instead of 2048 -- every
+# workgroup ends in a 28-row cross-thread sum that costs more than a patch of its arithmetic: 84 -> 69 us (fp32 headline),
+# 106 -> 80 us (configs[4], 3 channels); 768 / 512 / 256 are slower again (75-145 us)
+_SMALL_WGRAD_BLOCKS = int(os.environ.get("UNETPP_SMALL_WGRAD_BLOCKS", "1024"))
 USE_WINOGRAD = os.environ.get("UNETPP_NO_WINOGRAD") is None  # 3x3 fast path: Winograd F(2x2,3x3) unless disabled
 
 
@@ -449,7 +453,7 @@ def wgrad(n: int, h: int, w: int, taps: int, xs: Sequence[V], dys: Sequence[V], 
     nc = sum(v.fill(d.dy[i]) for i, v in enumerate(dys))
     pairs = sum((v.c_len + 31) // 32 for v in d.x[:len(xs)]) * sum((v.c_len + 31) // 32 for v in d.dy[:len(dys)])
     if len(xs) == 1 and xs[0].t.shape[3] <= 4:
-        target_blocks = 2048  # the 1..4-channel first layer runs an HBM-bound VALU kernel: many small workgroups
+        target_blocks = _SMALL_WGRAD_BLOCKS  # the 1..4-channel first layer: a VALU kernel with an expensive per-workgroup sum
     d.flags = (_lib.GEMM_DIRECT if (direct or not USE_WINOGRAD) else 0) | _storage_flag(dys, xs)
     wg_pairs = int(lib.unetpp_wgrad_pairs_per_workgroup(C.byref(d)))
     phys = C.c_int32(0)
