@@ -747,8 +747,20 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     __builtin_amdgcn_s_setprio(0);
     WINO_STAMP(4);  // 4: second half of the MFMA phase
 #ifndef UNETPP_WINO_EXP_NO_BARRIER
+#ifndef UNETPP_WINO_FENCED_BARRIER   // (-DUNETPP_WINO_FENCED_BARRIER: the __syncthreads() form of rounds 1-4, for A/B runs)
+    // Raw barrier (round 5: 19.765 -> 19.715 ms per step, same box, alternating; profiles/r5/ab_wino_raw_barrier.txt).  __syncthreads() carries a workgroup fence for which hipcc emits `s_waitcnt vmcnt(0) lgkmcnt(0)` in
+    // front of the s_barrier of THIS loop (the epilogue's global stores of an earlier iteration may be outstanding): that
+    // also drains the three input loads of the chunk after next, which were requested in MFMA group 2 of this very chunk
+    // precisely so that they would have more than a chunk to arrive (and which the explicit vmcnt(IN_ITEMS) leaves in
+    // flight).  What the barrier has to order is complete in every wave without it: its fragment reads of the current
+    // buffers and its staging stores (lgkmcnt(0)), its share of the next weight image (vmcnt(IN_ITEMS)).
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(IN_ITEMS) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_ITEMS) : "memory");  // this wave's share of the next weight image is in
     __syncthreads();  // all waves: done reading the current buffers, next buffers written
+#endif
 #endif
     WINO_STAMP(5);  // 5: barrier
     if (c_chunk + 1 == a.n_chunks) {
