@@ -619,10 +619,22 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   int c_chunk = 0, c_unit = 0;  // compute side: chunk of unit c_ug currently in LDS
   int cur = 0;                  // buffer being computed from
 #ifdef UNETPP_WINO_STAGGER
-  // experiment (tools/ab_lib.sh): the two workgroups of a CU run the same program on equal units from the same start, so
-  // their staging / barrier / epilogue phases can coincide; the second half of the grid starts N x 1024 cycles late
-  if (blockIdx.x >= (gridDim.x >> 1)) {
-    for (int i = 0; i < UNETPP_WINO_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
+  // experiment (tools/ab_multi.sh): the two workgroups of a CU run the same program on equal units from the same start, so
+  // their staging / barrier / epilogue phases can coincide; one of the two starts N x 1024 cycles late.  Which two share
+  // a CU is not defined by HIP: UNETPP_WINO_STAGGER_BY = 0 second half of the grid, 1 every other block of an XCD
+  // (blocks b and b + 8 share an XCD), 2 the parity of the hardware wave slot (HW_REG_HW_ID[3:0]: the first workgroup of
+  // a SIMD sits in slot 0, the second in slot 1)
+#ifndef UNETPP_WINO_STAGGER_BY
+#define UNETPP_WINO_STAGGER_BY 0
+#endif
+  {
+    bool late;
+    if (UNETPP_WINO_STAGGER_BY == 0) late = blockIdx.x >= (gridDim.x >> 1);
+    else if (UNETPP_WINO_STAGGER_BY == 1) late = ((blockIdx.x >> 3) & 1) != 0;
+    else late = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) != 0;
+    if (late) {
+      for (int i = 0; i < UNETPP_WINO_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
+    }
   }
 #endif
   while (true) {
