@@ -83,6 +83,10 @@ def main():
         ("wide-bf16-nobn-fs2", dict(in_channels=1, n_classes=4, feature_scale=2, is_batchnorm=False), True, 2, 96),
         ("wide-f32-fs2-160", dict(in_channels=3, n_classes=4, feature_scale=2), False, 2, 160),
         ("wide-bf16-bilinear-base32-96", dict(in_channels=1, n_classes=4, feature_scale=1, is_deconv=False), True, 2, 96),
+        # the BENCHMARKED geometries themselves (BASELINE configs[1], [3], [4]): a few runs each is all they take
+        ("bench-f32-configs1-256-b32", dict(in_channels=1, n_classes=4, feature_scale=1), False, 32, 256),
+        ("bench-bf16-configs3-512-b8", dict(in_channels=1, n_classes=4, feature_scale=1), True, 8, 512),
+        ("bench-bf16-configs4-d5-384-b4", dict(in_channels=3, n_classes=5, feature_scale=0.5, depth=5), True, 4, 384),
     ]
     crit = FocalLoss_BCE_2d(gamma=3, size_average=False)
     for name, ctor, bf16, b, size in cases:
