@@ -707,7 +707,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     if constexpr (LEAN) {
       lds_wait8x2(dp);
       lds_wait(us[0][0], us[0][1]);
+#ifdef UNETPP_WINO_EXP_NO_XFORM   // inner-loop ablation: the window values go to the MFMAs untransformed (wrong results)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) V[k] = dp[k >> 1][k & 1];
+#else
       wino_input_transform_pk(dp, V);
+#endif
     } else {
       lds_wait16(dd);
       lds_wait(us[0][0], us[0][1]);
@@ -716,15 +721,25 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     static_for<8>([&](auto gc) {  // group g = steps 4g .. 4g+3 of the chunk's 32 ([s][xi]); 8 MFMAs each
       constexpr int g = decltype(gc)::v, cs = g & 1, ns = cs ^ 1;
       if constexpr (g + 1 < 8) {
+#ifdef UNETPP_WINO_EXP_NO_WREAD   // inner-loop ablation: the first group's weight fragments for every group (wrong results)
+        us[ns][0] = us[cs][0];
+        us[ns][1] = us[cs][1];
+#else
         lds_read2st64_b64<4 * (g + 1), 4 * (g + 1) + 1>(us[ns][0], w_b);
         lds_read2st64_b64<4 * (g + 1) + 2, 4 * (g + 1) + 3>(us[ns][1], w_b);
+#endif
       }
       if constexpr (g == 0) {  // the second channel's window, needed from group 4 on
         if constexpr (LEAN) {
+#ifdef UNETPP_WINO_EXP_NO_INREAD   // inner-loop ablation: the first channel's window again (wrong results)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dpn[e] = dp[e];
+#else
           static_for<8>([&](auto ic) {
             constexpr int e = decltype(ic)::v, j = 2 * (e & 1);
             lds_read2_b32<j * WP + 1, (j + 1) * WP + 1>(dpn[e], row_b[e >> 1]);
           });
+#endif
         } else {
           static_for<16>([&](auto ic) {
             constexpr int e = decltype(ic)::v;
@@ -752,8 +767,16 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       if constexpr (g + 1 < 8) lds_wait(us[ns][0], us[ns][1]);
       if constexpr (g == 3) {
         WINO_STAMP(2);  // 2: first half of the MFMA phase
+#ifdef UNETPP_WINO_EXP_NO_XFORM
+        if constexpr (LEAN) {
+#pragma unroll
+          for (int k = 0; k < 16; ++k) V[k] = dpn[k >> 1][k & 1];
+        } else
+#else
         if constexpr (LEAN) wino_input_transform_pk(dpn, V);
-        else wino_input_transform(ddn, V);  // (inside group 4's fences it interleaves with the MFMAs, and is 1 % slower)
+        else
+#endif
+          wino_input_transform(ddn, V);  // (inside group 4's fences it interleaves with the MFMAs, and is 1 % slower)
       }
     });
     __builtin_amdgcn_s_setprio(0);
