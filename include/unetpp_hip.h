@@ -365,13 +365,21 @@ int64_t unetpp_heatmap_pattern_workspace_bytes(int32_t N, int32_t n_maps, int32_
 int unetpp_heatmap_pattern(const float* points, int32_t N, int32_t P, const int32_t* map_points,
                            const int32_t* map_begin, int32_t n_maps, int32_t H, int32_t W, float radius,
                            float* out_nchw, void* workspace, void* stream);
-/* unetpp_keypoints_extract: Heatmap.extract_points_ (heatmap.py:148-200) with 8-connected components of the region
- * mask in place of the OpenCV watershed (heatmap.py:100-144).  heat [maps, H, W]; thr [maps] (device).  Three stages on
- * one workspace: 0 = mask (values < thr zeroed, 3x3 median > 0) and label initialisation; 1 = `sweeps` rounds of label
- * merging, *changed (device int32, zeroed by the caller) is set while labels still move: repeat until it stays 0;
- * 2 = per-region maximum and selection: points [maps, num, 2] = (x, y) of the first pixel in raster order attaining the
- * maximum of the num brightest regions (ties: raster order of the regions' first pixels), -1 where there are fewer;
- * counts [maps] = regions found (results are only complete when counts <= max_regions). */
+/* unetpp_keypoints_extract: Heatmap.extract_points_ (heatmap.py:148-200).  heat [maps, H, W]; thr [maps] (device).
+ * Stages on one workspace: 0 = mask (values < thr zeroed, 3x3 median > 0) and label initialisation; 1 = `sweeps` rounds
+ * of label merging (8-connected components), *changed (device int32, zeroed by the caller) is set while labels still
+ * move: repeat until it stays 0; 2 = per-region maximum and selection: points [maps, num, 2] = (x, y) of the first pixel
+ * in raster order attaining the maximum of the num brightest regions (ties: raster order of the regions' first
+ * pixels), -1 where there are fewer; counts [maps] = regions found (every count is ranked exactly; max_regions only
+ * sizes the fast path's buffer).  0, 1.., 2 alone take a region to be a component of the mask.  The reference's own
+ * region step (region_segment_, heatmap.py:100-144: distance-transform cores grown back by a watershed, so that blobs
+ * which touch are split) goes between: 0; 3 = 3x3 chamfer distance initialised; 4 = `sweeps` relaxation sweeps, repeat
+ * until *changed stays 0; 5 = cores (distance > 0.1 * the map's maximum) as labels; 1.. = components of the cores;
+ * 6 = markers (core root / background beyond the two-pixel ring / unknown); 7 = `sweeps` pairs of flood rounds, repeat
+ * until *changed stays 0; 8 = region labels; 2.
+ * Workspace layout (for callers that want the regions themselves, region_segment_'s return value): uint64 best
+ * [maps*H*W], uint64 [maps*max_regions*2], then int32 label [maps*H*W] (after stage 8 / the last stage 1: raster index
+ * of the region's first pixel, -1 outside), int32 distance [maps*H*W] (16-bit fixed point), int32 marker [maps*H*W]. */
 int64_t unetpp_keypoints_workspace_bytes(int32_t maps, int32_t H, int32_t W, int32_t max_regions);
 int unetpp_keypoints_extract(int32_t stage, const float* heat, int32_t maps, int32_t H, int32_t W,
                              const float* thr_per_map, int32_t num, int32_t max_regions, int32_t sweeps,

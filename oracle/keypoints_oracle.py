@@ -8,11 +8,19 @@ file cannot be imported and no vectors can be generated from it.  What is restat
     exp(-0.5 * distance / radius) of its key points are summed into a float32 array (one rounding per addition, in
     pattern order) and the map is divided by its maximum.  For the pattern [[0], [1, 2, 3], [4], [5, 6]] the multi-point
     maps equal channels 1 and 3 of tools/misc/helper.py:87-172, which IS pinned (tests/golden kp/heatmap).
-  * ``extract_points``  heatmap.py:148-200 (extract_points_) with its region step (region_segment_, :100-144) REPLACED:
-    the reference seeds cv2.watershed with the cores of cv2.distanceTransform and so splits blobs that touch; here a
-    region is an 8-connected component of the same mask (values below the threshold zeroed, 3x3 median, > 0).  For
-    separated blobs -- what the network is trained to produce -- both give one region per blob and the same peak.
-    Kept as in the reference: regions ordered by their maximum (descending, stable in label order), the first `num`
+  * ``extract_points``  heatmap.py:148-200 (extract_points_) with its region step (region_segment_, :100-144) restated
+    from the published algorithms of the OpenCV calls it makes (``segmentation="watershed"``, the default since round 5):
+    cv2.distanceTransform(mask, DIST_L2, 3) is the two-pass 3x3 chamfer transform in 16-bit fixed point (weights
+    round(0.955 * 2^16) and round(1.3693 * 2^16), result x 2^-16 as float32); the cores are the pixels above
+    float32(0.1 * max); cv2.connectedComponents labels them 8-connected in raster order; cv2.watershed on the BINARY
+    mask image floods, at priority 0, every unknown pixel from labelled 4-neighbours of its own value (the cores grow
+    through their blob, the background marker through the two-pixel ring that two dilations put around the mask) and
+    marks a pixel whose labelled neighbours disagree as a watershed line -- restated here as synchronous breadth-first
+    rounds (OpenCV pops one pixel at a time from a FIFO queue: the two differ, if at all, in which of two equidistant
+    pixels becomes the line).  Consequences the restatement keeps: blobs that touch through a thin neck are SPLIT, a blob
+    whose distance maximum is below a tenth of the map's has no core and is NOT a region, the outermost pixel layer of a
+    blob belongs to no region.  ``segmentation="components"`` is the round-2 stand-in (a region = an 8-connected component
+    of the mask).  Kept as in the reference: regions ordered by their maximum (descending, stable in label order), the first `num`
     taken, each reported as (x, y) of the first pixel in raster order that attains the maximum; when no region exists
     the extraction is retried once at 0.9 * threshold (heatmap.py:176-198).
   * ``transfer_points``  heatmap.py:241-263 up to the matcher: the reference's match_distmin is unfinished and
@@ -47,10 +55,70 @@ def region_mask(pred: np.ndarray, threshold: float) -> np.ndarray:
     return ndimage.median_filter(heat, size=3, mode="nearest") > 0
 
 
-def _extract_once(pred: np.ndarray, num: int, threshold: float):
+HV_DIST, DIAG_DIST = 62587, 89738   # cv2 distanceTransform, DIST_L2 with a 3x3 mask: CV_FLT_TO_FIX(0.955, 16), (1.3693, 16)
+DIST_INF = 0x3FFFFFFF
+
+
+def chamfer_distance(mask: np.ndarray) -> np.ndarray:
+    """int64 [H, W]: 3x3 chamfer distance (16-bit fixed point) of every mask pixel to the nearest non-mask pixel, by the
+    two sequential passes of Borgefors' algorithm as cv2.distanceTransform runs them; 0 outside the mask"""
+    h, w = mask.shape
+    d = np.full((h + 2, w + 2), DIST_INF, dtype=np.int64)
+    d[1:-1, 1:-1] = np.where(mask, DIST_INF, 0)
+    for y in range(1, h + 1):
+        for x in range(1, w + 1):
+            if d[y, x]:
+                d[y, x] = min(d[y, x], d[y - 1, x - 1] + DIAG_DIST, d[y - 1, x] + HV_DIST, d[y - 1, x + 1] + DIAG_DIST,
+                              d[y, x - 1] + HV_DIST)
+    for y in range(h, 0, -1):
+        for x in range(w, 0, -1):
+            if d[y, x]:
+                d[y, x] = min(d[y, x], d[y + 1, x + 1] + DIAG_DIST, d[y + 1, x] + HV_DIST, d[y + 1, x - 1] + DIAG_DIST,
+                              d[y, x + 1] + HV_DIST)
+    return np.minimum(d[1:-1, 1:-1], DIST_INF)
+
+
+def watershed_regions(mask: np.ndarray):
+    """region_segment_ (heatmap.py:100-144) on the median mask -> (labels int64 [H, W]: core label >= 1 inside a region,
+    0 elsewhere; number of regions).  Labels follow the raster order of each core's first pixel."""
+    h, w = mask.shape
+    dist_f = (chamfer_distance(mask).astype(np.float32) * np.float32(1.0 / 65536.0)).astype(np.float32)
+    thr = np.float32(0.1 * float(dist_f.max())) if mask.any() else np.float32(0)
+    core = mask & (dist_f > thr)
+    core_lab, count = ndimage.label(core, structure=np.ones((3, 3), dtype=int))
+    sure_bg = ndimage.binary_dilation(mask, structure=np.ones((3, 3), dtype=bool), iterations=2)
+    mk = np.where(core, core_lab + 1, np.where(sure_bg, 0, 1)).astype(np.int64)   # 1 = background marker, 0 = unknown
+    pad_m = np.zeros((h + 2, w + 2), dtype=np.int64)
+    pad_v = np.full((h + 2, w + 2), -1, dtype=np.int64)   # value outside the image: matches nothing
+    pad_v[1:-1, 1:-1] = mask
+    while True:
+        pad_m[1:-1, 1:-1] = mk
+        nb_l = [pad_m[0:-2, 1:-1], pad_m[2:, 1:-1], pad_m[1:-1, 0:-2], pad_m[1:-1, 2:]]
+        nb_v = [pad_v[0:-2, 1:-1], pad_v[2:, 1:-1], pad_v[1:-1, 0:-2], pad_v[1:-1, 2:]]
+        active = np.zeros((h, w), dtype=bool)
+        lo = np.full((h, w), np.iinfo(np.int64).max)
+        hi = np.zeros((h, w), dtype=np.int64)
+        for l, v in zip(nb_l, nb_v):
+            lab = l > 0
+            active |= lab & (v == mask)
+            lo = np.where(lab, np.minimum(lo, l), lo)
+            hi = np.where(lab, np.maximum(hi, l), hi)
+        grow = (mk == 0) & active
+        if not grow.any():
+            break
+        mk = np.where(grow, np.where(lo == hi, lo, -1), mk)
+    labels = np.where(mk >= 2, mk - 1, 0)
+    return labels, count
+
+
+def _extract_once(pred: np.ndarray, num: int, threshold: float, segmentation: str = "watershed"):
     heat = pred.astype(np.float32).copy()
     heat[heat < threshold] = 0
-    labels, count = ndimage.label(region_mask(pred.astype(np.float32), threshold), structure=np.ones((3, 3), dtype=int))
+    mask = region_mask(pred.astype(np.float32), threshold)
+    if segmentation == "watershed":
+        labels, count = watershed_regions(mask)
+    else:
+        labels, count = ndimage.label(mask, structure=np.ones((3, 3), dtype=int))
     regions = []
     for lab in range(1, count + 1):  # scipy labels in raster order of each component's first pixel
         inside = np.where(labels == lab, heat, 0)
@@ -63,17 +131,17 @@ def _extract_once(pred: np.ndarray, num: int, threshold: float):
     return points, count
 
 
-def extract_points(pred: np.ndarray, num: int, threshold: float = 0.5):
+def extract_points(pred: np.ndarray, num: int, threshold: float = 0.5, segmentation: str = "watershed"):
     """[H, W] heat map -> up to `num` [x, y] points, brightest region first"""
     assert pred.ndim == 2, "Heatmap assertion failed. It should be [H, W]"
-    points, count = _extract_once(pred, num, threshold)
+    points, count = _extract_once(pred, num, threshold, segmentation)
     if count == 0:
-        points, count = _extract_once(pred, num, threshold * 0.9)
+        points, count = _extract_once(pred, num, threshold * 0.9, segmentation)
     return points
 
 
-def transfer_points(preds: np.ndarray, pattern, threshold: float = 0.5):
+def transfer_points(preds: np.ndarray, pattern, threshold: float = 0.5, segmentation: str = "watershed"):
     """[N, C, H, W] -> list (image) of list (map) of points"""
     assert preds.ndim == 4, "preds shape should be [N, C, H, W]"
-    return [[extract_points(preds[n, c], len(hmap), threshold) for c, hmap in enumerate(pattern)]
+    return [[extract_points(preds[n, c], len(hmap), threshold, segmentation) for c, hmap in enumerate(pattern)]
             for n in range(preds.shape[0])]

@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 import torch
 
-from oracle.keypoints_oracle import create_heatmap_pattern, extract_points, region_mask, transfer_points
+from oracle.keypoints_oracle import (DIAG_DIST, HV_DIST, chamfer_distance, create_heatmap_pattern, extract_points, region_mask,
+                                     transfer_points, watershed_regions)
 from tests.helpers import load_golden
 
 PATTERN = [[0], [1, 2, 3], [4], [5, 6]]
@@ -52,6 +53,89 @@ def test_oracle_edge_cases():
     assert extract_points(two, 2) == [[16, 9], [3, 3]]                 # ... of the REGION (the median drops the corners)
     assert extract_points(two, 1) == [[16, 9]]                         # brightest region first, (x, y)
     assert region_mask(two, 0.5).sum() > 0
+
+
+def _discs(h, w, blobs):
+    """max-composition of exp(-0.5 * distance / radius) blobs [(x, y, radius, height)]"""
+    yy, xx = np.mgrid[0:h, 0:w]
+    heat = np.zeros((h, w), dtype=np.float64)
+    for x, y, r, a in blobs:
+        heat = np.maximum(heat, a * np.exp(-0.5 * np.sqrt((xx - x) ** 2 + (yy - y) ** 2) / r))
+    return heat.astype(np.float32)
+
+
+def _touching_maps():
+    """the cases the reference's distance-transform + watershed step exists for (heatmap.py:100-144)"""
+    bar = np.zeros((48, 72), dtype=np.float32)          # two 24 x 24 squares joined by a two-pixel neck
+    bar[10:34, 6:30] = 0.8
+    bar[10:34, 38:62] = 0.7
+    bar[21:23, 30:38] = 0.6
+    bar[15, 12] = 0.95
+    bar[22, 45] = 0.9
+    corner = np.zeros((56, 56), dtype=np.float32)       # 8-connected through one corner
+    corner[4:28, 4:28] = 0.6
+    corner[28:52, 28:52] = 0.7
+    corner[10, 10] = 0.8
+    corner[30, 38] = 0.9
+    return {
+        "squares touching at a corner": (corner, 0.5),
+        "two discs that overlap": (_discs(64, 64, [(20, 30, 4.0, 1.0), (34, 30, 4.0, 0.9)]), 0.3),
+        "thick blob next to a thin one": (_discs(64, 96, [(30, 30, 8.0, 1.0), (80, 12, 0.9, 0.9)]), 0.4),
+        "squares joined by a neck": (bar, 0.5),
+        "three in a row": (_discs(40, 120, [(20, 20, 3.0, 1.0), (42, 20, 3.0, 0.8), (64, 20, 3.0, 0.9), (100, 8, 2.0, 0.7)]), 0.2),
+        "blob on the border": (_discs(32, 32, [(0, 0, 4.0, 1.0), (31, 16, 3.0, 0.9)]), 0.4),
+        "everything above the threshold": (np.full((24, 24), 0.9, dtype=np.float32), 0.5),
+    }
+
+
+def test_chamfer_distance_is_the_fixed_point_shortest_path():
+    """the two sequential passes (cv2.distanceTransform, DIST_L2, 3x3) equal the 8-neighbour shortest path with weights
+    HV / DIAG to the nearest non-mask pixel, which is what the device kernel relaxes to"""
+    rng = np.random.default_rng(3)
+    for h, w, p in [(17, 23, 0.8), (32, 32, 0.95), (9, 40, 0.6)]:
+        mask = rng.uniform(size=(h, w)) < p
+        mask[h // 2, w // 2] = False
+        d = chamfer_distance(mask)
+        it = np.where(mask, 0x3FFFFFFF, 0).astype(np.int64)
+        while True:
+            pad = np.pad(it, 1, constant_values=0x3FFFFFFF)
+            new = it.copy()
+            for dy in (-1, 0, 1):
+                for dx in (-1, 0, 1):
+                    if dy or dx:
+                        new = np.minimum(new, pad[1 + dy:1 + dy + h, 1 + dx:1 + dx + w] + (DIAG_DIST if dy and dx else HV_DIST))
+            new = np.where(mask, new, 0)
+            if (new == it).all():
+                break
+            it = new
+        np.testing.assert_array_equal(d, it)
+    one = np.ones((5, 7), dtype=bool)
+    one[2, 1] = False
+    d = chamfer_distance(one)
+    assert d[2, 2] == HV_DIST and d[3, 2] == DIAG_DIST and d[4, 3] == 2 * DIAG_DIST and d[2, 6] == 5 * HV_DIST
+    assert d[0, 4] == 2 * DIAG_DIST + HV_DIST
+
+
+def test_oracle_splits_touching_blobs_and_drops_coreless_ones():
+    maps = _touching_maps()
+    heat, thr = maps["two discs that overlap"]
+    assert extract_points(heat, 4, thr, "components") == [[20, 30]]
+    assert extract_points(heat, 4, thr) == [[20, 30]]       # a wide overlap stays one region: the cores are everything
+    heat, thr = maps["squares joined by a neck"]            # deeper than a TENTH of the maximum distance (heatmap.py:121)
+    assert extract_points(heat, 4, thr, "components") == [[12, 15]]               # one component ...
+    assert extract_points(heat, 4, thr) == [[12, 15], [45, 22]]                   # ... two regions
+    heat, thr = maps["squares touching at a corner"]
+    assert extract_points(heat, 4, thr, "components") == [[38, 30]]
+    assert extract_points(heat, 4, thr) == [[38, 30], [10, 10]]
+    heat, thr = maps["thick blob next to a thin one"]
+    assert extract_points(heat, 4, thr, "components") == [[30, 30], [80, 12]]
+    assert extract_points(heat, 4, thr) == [[30, 30]]                             # thinner than a tenth of the thickest: no core
+    heat, thr = maps["three in a row"]
+    assert extract_points(heat, 4, thr) == [[20, 20], [64, 20], [42, 20], [100, 8]]
+    labels, count = watershed_regions(region_mask(heat, thr))
+    assert count == 4 and set(np.unique(labels)) == {0, 1, 2, 3, 4}
+    heat, thr = maps["everything above the threshold"]
+    assert extract_points(heat, 2, thr) == [[0, 0]]                               # one region, plateau: first pixel
 
 
 # ------------------------------------------------------------------------------------------ GPU
@@ -98,17 +182,18 @@ def _random_blob_maps(seed, n, c, h, w):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("segmentation", ["watershed", "components"])
 @pytest.mark.parametrize("seed,h,w", [(2, 64, 64), (3, 48, 80), (4, 128, 128)])
-def test_extraction_hip_equals_oracle(dev, seed, h, w):
+def test_extraction_hip_equals_oracle(dev, seed, h, w, segmentation):
     """random blobs (touching ones, border ones, plateaus from the max-composition, empty maps, retry path included):
     points, their order and the counts must equal the oracle's exactly"""
     from unet_nested4tiny_objects_keypoints_amd import Heatmap
     pattern = [[0], [1, 2, 3], [4, 5]]
     maps = _random_blob_maps(seed, 3, len(pattern), h, w)
     maps[1, 2] = np.where(maps[1, 2] >= 0.5, 0.47, maps[1, 2])                # only the 0.9 * threshold retry finds these
-    hm = Heatmap(pattern, w, h)
+    hm = Heatmap(pattern, w, h, segmentation=segmentation)
     points, found = hm.transfer_points(torch.from_numpy(maps))
-    want = transfer_points(maps, pattern)
+    want = transfer_points(maps, pattern, segmentation=segmentation)
     points, found = points.cpu().numpy(), found.cpu().numpy()
     for n in range(maps.shape[0]):
         for c, hmap in enumerate(pattern):
@@ -117,8 +202,52 @@ def test_extraction_hip_equals_oracle(dev, seed, h, w):
             assert [[int(x), int(y)] for x, y in points[n, c, :len(ref)]] == ref, (n, c)
             assert (points[n, c, len(ref):] == -1).all()
     # the single-map form of the reference's API
-    assert hm.extract_points_(maps[2, 1], 3) == extract_points(maps[2, 1], 3)
+    assert hm.extract_points_(maps[2, 1], 3) == extract_points(maps[2, 1], 3, segmentation=segmentation)
     assert hm.extract_points_(np.zeros((h, w), dtype=np.float32), 2) == []
+
+
+def _same_partition(got, want_labels, want_count):
+    """device labels (root index, -1 outside) describe the oracle's regions (1..count, 0 outside), in the same order"""
+    roots = np.unique(got[got >= 0])
+    assert len(roots) == want_count
+    for k, r in enumerate(roots):      # oracle labels follow the raster order of the cores' first pixels, as the roots do
+        np.testing.assert_array_equal(got == r, want_labels == k + 1)
+    np.testing.assert_array_equal(got < 0, want_labels == 0)
+
+
+@pytest.mark.gpu
+def test_region_step_hip_equals_oracle(dev):
+    """the reference's region step on its own (region_segment_, heatmap.py:100-144): chamfer distance EXACTLY (integers),
+    then the regions pixel by pixel, on the touching / coreless / border cases and on random blobs; then the points"""
+    from unet_nested4tiny_objects_keypoints_amd import ops
+    cases = dict(_touching_maps())
+    rb = _random_blob_maps(11, 2, 2, 96, 80)
+    for i in range(2):
+        for j in range(2):
+            cases["random blobs %d/%d" % (i, j)] = (rb[i, j], 0.5)
+    for name, (heat, thr) in cases.items():
+        t = torch.from_numpy(heat).to(dev).unsqueeze(0)
+        labels, dist = ops.keypoints_regions(t, thr)
+        mask = region_mask(heat, thr)
+        np.testing.assert_array_equal(dist[0].cpu().numpy(), chamfer_distance(mask), err_msg=name)
+        want_labels, want_count = watershed_regions(mask)
+        _same_partition(labels[0].cpu().numpy(), want_labels, want_count)
+        comp, _ = ops.keypoints_regions(t, thr, segmentation="components")
+        from scipy import ndimage
+        cl, cc = ndimage.label(mask, structure=np.ones((3, 3), dtype=int))
+        _same_partition(comp[0].cpu().numpy(), cl, cc)
+        for seg in ("watershed", "components"):
+            points, counts = ops.keypoints_extract(t, 5, thr, segmentation=seg)
+            ref = extract_points(heat, 5, thr, seg)
+            k = min(int(counts[0]), 5)
+            assert [[int(x), int(y)] for x, y in points[0, :k].cpu().tolist()] == ref, (name, seg)
+    # all maps of the batch at once give what they give one by one (grid y = map)
+    same = [c for c in cases.values() if c[0].shape == (96, 80)]
+    batch = torch.from_numpy(np.stack([c[0] for c in same])).to(dev)
+    labels, dist = ops.keypoints_regions(batch, 0.5)
+    for m, (heat, thr) in enumerate(same):
+        one, d1 = ops.keypoints_regions(batch[m:m + 1], 0.5)
+        assert torch.equal(one[0], labels[m]) and torch.equal(d1[0], dist[m])
 
 
 @pytest.mark.gpu
@@ -129,12 +258,17 @@ def test_extraction_has_no_region_limit(dev):
     all roots.  Also: the blob maps with a ranking buffer of only `num` entries (every map takes the uncapped path)."""
     from scipy import ndimage
 
-    from oracle.keypoints_oracle import region_mask
     from unet_nested4tiny_objects_keypoints_amd import ops
     rng = np.random.default_rng(9)
     h, w, num, thr = 512, 512, 7, 0.7
     heat = rng.uniform(0, 1, (2, h, w)).astype(np.float32)
-    points, counts = ops.keypoints_extract(torch.from_numpy(heat).to(dev), num, thr)
+    w_points, w_counts = ops.keypoints_extract(torch.from_numpy(heat).to(dev), num, thr)     # the reference's region step
+    for m in range(2):
+        _, cores = watershed_regions(region_mask(heat[m], thr))
+        assert cores > 4096 and int(w_counts[m]) == cores
+        ref = extract_points(heat[m], num, thr)
+        assert [[int(x), int(y)] for x, y in w_points[m].cpu().tolist()] == ref
+    points, counts = ops.keypoints_extract(torch.from_numpy(heat).to(dev), num, thr, segmentation="components")
     points, counts = points.cpu().numpy(), counts.cpu().numpy()
     for m in range(2):
         labels, count = ndimage.label(region_mask(heat[m], thr), structure=np.ones((3, 3), dtype=int))

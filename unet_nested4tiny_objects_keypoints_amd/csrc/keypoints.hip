@@ -3,12 +3,17 @@
 //                              exp(-0.5 * distance / radius) of its key points summed in float32 (one rounding per
 //                              addition, in pattern order), divided by the map's maximum
 //   unetpp_keypoints_extract   heat map -> up to `num` (x, y) peaks per map (heatmap.py:148-200): values below the
-//                              threshold zeroed, 3x3 median > 0 as the region mask, one region per 8-connected component
-//                              of the mask, regions ordered by their maximum (descending, ties in raster order of the
-//                              region's first pixel), each reported at the first pixel in raster order that attains it.
-// The reference finds its regions with OpenCV (distance transform cores + watershed, heatmap.py:100-144), which also
-// splits blobs that touch; connected components give the same regions and peaks for separated blobs.  OpenCV is
-// absent from the build image, so this row is "parity unpinned": checked against oracle/keypoints_oracle.py only.
+//                              threshold zeroed, 3x3 median > 0 as the region mask, the mask cut into regions, regions
+//                              ordered by their maximum (descending, ties in raster order of the region's first pixel),
+//                              each reported at the first pixel in raster order that attains it.
+// Regions, as the reference finds them with OpenCV (region_segment_, heatmap.py:100-144), restated from the published
+// algorithms of the calls it makes (stages 3-8 below): the 3x3 chamfer distance transform in 16-bit fixed point, cores =
+// distance > float32(0.1 * the map's maximum), 8-connected components of the cores, and the watershed of the BINARY mask
+// image seeded with them: cores grow over 4-neighbours through their blob, the background marker through the two-pixel
+// ring the reference leaves unknown around the mask, a pixel reached by two different labels in the same round becomes a
+// line.  Blobs that touch are split, a blob without a core (thinner than a tenth of the thickest) is no region.  The
+// round-2 stand-in -- a region = an 8-connected component of the mask -- stays available (stages 0, 1, 2 alone).
+// OpenCV is absent from the build image, so this row is "parity unpinned": checked against oracle/keypoints_oracle.py only.
 //
 // All kernels are HBM/latency trivial (a 512x512 map is 1 MB); what matters is that the whole extraction stays on the
 // device: the reference moves every head output to the CPU and runs OpenCV per map (trainer/trainer.py:213-221).
@@ -132,6 +137,147 @@ __global__ __launch_bounds__(kKpThreads) void kp_flatten_kernel(int H, int W, in
   if (l < 0) return;
   while (lab[l] != l) l = lab[l];
   lab[i] = l;
+}
+
+// ---- the reference's region step (heatmap.py:100-144).  Extra work buffers per map: dist int32 [H*W], marker int32 [H*W].
+constexpr int kDistHV = 62587, kDistDiag = 89738;  // cv2.distanceTransform(DIST_L2, 3): 0.955 and 1.3693 in 16-bit fixed point
+constexpr int kDistInf = 0x3FFFFFFF;
+
+__global__ __launch_bounds__(kKpThreads) void kp_dist_init_kernel(int H, int W, const int* __restrict__ label,
+                                                                  int* __restrict__ dist, int* __restrict__ mapmax) {
+  const long hw = static_cast<long>(H) * W;
+  const long i = blockIdx.x * static_cast<long>(kKpThreads) + threadIdx.x;
+  if (i == 0) mapmax[blockIdx.y] = 0;
+  if (i >= hw) return;
+  dist[static_cast<long>(blockIdx.y) * hw + i] = label[static_cast<long>(blockIdx.y) * hw + i] >= 0 ? kDistInf : 0;
+}
+
+// one relaxation sweep of the chamfer distance: a pixel writes only its own entry and entries only ever decrease, so
+// sweeps in any interleaving end at the one fixed point -- the shortest 8-neighbour path (weights HV / DIAG) to a
+// non-mask pixel, which is what cv2's two sequential passes compute on a full rectangle.  Outside the image counts as
+// far away (cv2 pads its work buffer with the maximum distance).
+__global__ __launch_bounds__(kKpThreads) void kp_dist_sweep_kernel(int H, int W, int* __restrict__ dist, int* __restrict__ changed) {
+  const long hw = static_cast<long>(H) * W;
+  const long i = blockIdx.x * static_cast<long>(kKpThreads) + threadIdx.x;
+  if (i >= hw) return;
+  int* d = dist + static_cast<long>(blockIdx.y) * hw;
+  const int mine = d[i];
+  if (mine == 0) return;
+  const int y = static_cast<int>(i / W), x = static_cast<int>(i % W);
+  int m = mine;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int yy = y + dy, xx = x + dx;
+      if ((dy == 0 && dx == 0) || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+      const int v = __atomic_load_n(&d[static_cast<long>(yy) * W + xx], __ATOMIC_RELAXED) + ((dy != 0 && dx != 0) ? kDistDiag : kDistHV);
+      m = v < m ? v : m;
+    }
+  if (m < mine) {
+    __atomic_store_n(&d[i], m, __ATOMIC_RELAXED);
+    *changed = 1;
+  }
+}
+
+__global__ __launch_bounds__(kKpThreads) void kp_dist_max_kernel(int H, int W, const int* __restrict__ dist, int* __restrict__ mapmax) {
+  __shared__ int red[kKpThreads / 64];
+  const long hw = static_cast<long>(H) * W;
+  const long i = blockIdx.x * static_cast<long>(kKpThreads) + threadIdx.x;
+  int m = i < hw ? dist[static_cast<long>(blockIdx.y) * hw + i] : 0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = max(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(red[0], red[1]), max(red[2], red[3]));
+    if (m > 0) atomicMax(&mapmax[blockIdx.y], m);
+  }
+}
+
+// cores (the reference's sure_fg): distance as float32 (fixed point x 2^-16, cv2's output) above float32(0.1 * maximum),
+// the product taken in double as Python takes it (heatmap.py:121).  label = own index on a core, -1 elsewhere: stage 1's
+// component sweeps then run on the cores.
+__global__ __launch_bounds__(kKpThreads) void kp_core_kernel(int H, int W, const int* __restrict__ dist,
+                                                             const int* __restrict__ mapmax, int* __restrict__ label) {
+  const long hw = static_cast<long>(H) * W;
+  const long i = blockIdx.x * static_cast<long>(kKpThreads) + threadIdx.x;
+  if (i >= hw) return;
+  const float scale = 1.0f / 65536.0f;
+  const float top = static_cast<float>(mapmax[blockIdx.y]) * scale;
+  const float thr = static_cast<float>(0.1 * static_cast<double>(top));
+  const int d = dist[static_cast<long>(blockIdx.y) * hw + i];
+  label[static_cast<long>(blockIdx.y) * hw + i] = (d > 0 && static_cast<float>(d) * scale > thr) ? static_cast<int>(i) : -1;
+}
+
+// markers (heatmap.py:131-137): a core pixel carries its component's root + 2; a pixel further than two 3x3 dilations
+// from the mask is background (1); the rest -- the blobs outside their cores and the ring around them -- is unknown (0)
+__global__ __launch_bounds__(kKpThreads) void kp_marker_kernel(int H, int W, const int* __restrict__ dist,
+                                                               const int* __restrict__ label, int* __restrict__ marker) {
+  const long hw = static_cast<long>(H) * W;
+  const long i = blockIdx.x * static_cast<long>(kKpThreads) + threadIdx.x;
+  if (i >= hw) return;
+  const int* d = dist + static_cast<long>(blockIdx.y) * hw;
+  const int l = label[static_cast<long>(blockIdx.y) * hw + i];
+  int mk = l + 2;
+  if (l < 0) {
+    const int y = static_cast<int>(i / W), x = static_cast<int>(i % W);
+    bool near = false;
+    for (int dy = -2; dy <= 2; ++dy)
+      for (int dx = -2; dx <= 2; ++dx) {
+        const int yy = y + dy, xx = x + dx;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) near = near || d[static_cast<long>(yy) * W + xx] > 0;
+      }
+    mk = near ? 0 : 1;
+  }
+  marker[static_cast<long>(blockIdx.y) * hw + i] = mk;
+}
+
+// one round of the watershed of a two-valued image (cv2.watershed floods level by level; every difference between equal
+// pixels is level 0): an unknown pixel with a labelled 4-neighbour of its own mask value takes the label its labelled
+// neighbours agree on, or becomes a line (-1) where they differ.  Lines and the background marker do not count as a
+// region later; lines are not propagated.  Rounds are synchronous (src -> dst): the result does not depend on timing.
+__global__ __launch_bounds__(kKpThreads) void kp_flood_kernel(int H, int W, const int* __restrict__ dist,
+                                                              const int* __restrict__ src, int* __restrict__ dst,
+                                                              int* __restrict__ changed) {
+  const long hw = static_cast<long>(H) * W;
+  const long i = blockIdx.x * static_cast<long>(kKpThreads) + threadIdx.x;
+  if (i >= hw) return;
+  const int* d = dist + static_cast<long>(blockIdx.y) * hw;
+  const int* in = src + static_cast<long>(blockIdx.y) * hw;
+  int mk = in[i];
+  if (mk == 0) {
+    const int y = static_cast<int>(i / W), x = static_cast<int>(i % W);
+    const bool inside = d[i] > 0;
+    int lo = 0x7fffffff, hi = 0;
+    bool active = false;
+    const int ny[4] = {-1, 1, 0, 0}, nx[4] = {0, 0, -1, 1};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = y + ny[k], xx = x + nx[k];
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+      const long q = static_cast<long>(yy) * W + xx;
+      const int l = in[q];
+      if (l <= 0) continue;
+      lo = min(lo, l);
+      hi = max(hi, l);
+      active = active || ((d[q] > 0) == inside);
+    }
+    if (active) {
+      mk = lo == hi ? lo : -1;
+      *changed = 1;
+    }
+  }
+  dst[static_cast<long>(blockIdx.y) * hw + i] = mk;
+}
+
+// region labels for the peak / selection kernels: the root index of the core a pixel was flooded from, -1 elsewhere
+__global__ __launch_bounds__(kKpThreads) void kp_region_kernel(int H, int W, const int* __restrict__ marker, int* __restrict__ label) {
+  const long hw = static_cast<long>(H) * W;
+  const long i = blockIdx.x * static_cast<long>(kKpThreads) + threadIdx.x;
+  if (i >= hw) return;
+  const int mk = marker[static_cast<long>(blockIdx.y) * hw + i];
+  label[static_cast<long>(blockIdx.y) * hw + i] = mk >= 2 ? mk - 2 : -1;
 }
 
 // per region: (maximum of the thresholded map, first raster index attaining it), packed so that a 64-bit max does both
@@ -263,12 +409,15 @@ extern "C" int unetpp_heatmap_pattern(const float* points, int32_t N, int32_t P,
 extern "C" int64_t unetpp_keypoints_workspace_bytes(int32_t maps, int32_t H, int32_t W, int32_t max_regions) {
   if (maps < 1 || H < 1 || W < 1 || max_regions < 1) return 0;
   const int64_t hw = static_cast<int64_t>(H) * W;
-  return static_cast<int64_t>(maps) * (hw * 4 + hw * 8 + static_cast<int64_t>(max_regions) * 16) + 64;
+  return static_cast<int64_t>(maps) * (hw * 4 * 3 + hw * 8 + static_cast<int64_t>(max_regions) * 16 + 4) + 64;
 }
 
 // stage 0: mask + labels initialised; stage 1: `sweeps` merge + flatten sweeps (sets *changed when a sweep moved a
 // label: the caller repeats stage 1 until it stays 0); stage 2: peaks + selection.  heat [maps, H, W]; thr [maps];
 // points [maps, num, 2] as (x, y), -1 where there is no region; counts [maps] = regions found.
+// The reference's region step sits between 0 and 2: 3 = distance initialised from the mask; 4 = `sweeps` relaxation
+// sweeps (repeat until *changed stays 0); 5 = cores -> labels (then stage 1 until stable: components of the cores);
+// 6 = markers; 7 = `sweeps` pairs of flood rounds (repeat until *changed stays 0); 8 = region labels; then stage 2.
 extern "C" int unetpp_keypoints_extract(int32_t stage, const float* heat, int32_t maps, int32_t H, int32_t W,
                                         const float* thr_per_map, int32_t num, int32_t max_regions, int32_t sweeps,
                                         void* workspace, int32_t* changed, float* points, int32_t* counts, void* stream) {
@@ -279,6 +428,9 @@ extern "C" int unetpp_keypoints_extract(int32_t stage, const float* heat, int32_
   unsigned long long* best = static_cast<unsigned long long*>(workspace);  // 8-byte aligned first
   unsigned long long* cand = best + static_cast<long>(maps) * hw;
   int* label = reinterpret_cast<int*>(cand + static_cast<long>(maps) * max_regions * 2);
+  int* dist = label + static_cast<long>(maps) * hw;
+  int* marker = dist + static_cast<long>(maps) * hw;
+  int* mapmax = marker + static_cast<long>(maps) * hw;
   const dim3 grid(static_cast<unsigned>((hw + kKpThreads - 1) / kKpThreads), static_cast<unsigned>(maps));
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (stage == 0) {
@@ -294,6 +446,25 @@ extern "C" int unetpp_keypoints_extract(int32_t stage, const float* heat, int32_
     hipLaunchKernelGGL(kp_peak_kernel, grid, dim3(kKpThreads), 0, st, heat, H, W, thr_per_map, label, best);
     hipLaunchKernelGGL(kp_select_kernel, dim3(static_cast<unsigned>(maps)), dim3(1024), 0, st, H, W, label, best, num,
                        max_regions, cand, points, counts);
+  } else if (stage == 3) {
+    hipLaunchKernelGGL(kp_dist_init_kernel, grid, dim3(kKpThreads), 0, st, H, W, label, dist, mapmax);
+  } else if (stage == 4) {
+    if (!changed || sweeps < 1) return UNETPP_EINVAL;
+    for (int s = 0; s < sweeps; ++s)
+      hipLaunchKernelGGL(kp_dist_sweep_kernel, grid, dim3(kKpThreads), 0, st, H, W, dist, changed);
+  } else if (stage == 5) {
+    hipLaunchKernelGGL(kp_dist_max_kernel, grid, dim3(kKpThreads), 0, st, H, W, dist, mapmax);
+    hipLaunchKernelGGL(kp_core_kernel, grid, dim3(kKpThreads), 0, st, H, W, dist, mapmax, label);
+  } else if (stage == 6) {
+    hipLaunchKernelGGL(kp_marker_kernel, grid, dim3(kKpThreads), 0, st, H, W, dist, label, marker);
+  } else if (stage == 7) {
+    if (!changed || sweeps < 1) return UNETPP_EINVAL;
+    for (int s = 0; s < sweeps; ++s) {  // pairs: the current state is always in `marker` between calls
+      hipLaunchKernelGGL(kp_flood_kernel, grid, dim3(kKpThreads), 0, st, H, W, dist, marker, label, changed);
+      hipLaunchKernelGGL(kp_flood_kernel, grid, dim3(kKpThreads), 0, st, H, W, dist, label, marker, changed);
+    }
+  } else if (stage == 8) {
+    hipLaunchKernelGGL(kp_region_kernel, grid, dim3(kKpThreads), 0, st, H, W, marker, label);
   } else {
     return UNETPP_EINVAL;
   }

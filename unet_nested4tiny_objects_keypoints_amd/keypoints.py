@@ -7,10 +7,11 @@ Here the maps never leave the GPU.
 
 **Parity unpinned.**  The reference file imports OpenCV at module level and OpenCV is absent from the build image, so
 no vectors could be generated from it; the kernels are checked against oracle/keypoints_oracle.py (a restatement from
-the source text).  One deliberate difference: the reference finds a map's regions with ``cv2.distanceTransform`` cores
-grown back by ``cv2.watershed`` (:100-144), which also splits blobs that touch; here a region is an 8-connected
-component of the same mask.  Separated blobs -- what the network is trained to produce -- give identical regions and
-peaks.  The reference's matcher ``match_distmin`` is unfinished and returns ``[]`` (:56-79): ``transfer_points`` returns
+the source text and, for the OpenCV calls of region_segment_ (:100-144), from their published algorithms: the 3x3
+chamfer ``cv2.distanceTransform`` in fixed point, cores above a tenth of its maximum, ``cv2.connectedComponents`` of the
+cores, ``cv2.watershed`` of the binary mask seeded with them).  ``segmentation="watershed"`` (default) is that region
+step: blobs that touch are split, a blob without a core is dropped; ``segmentation="components"`` keeps the round-2
+stand-in (a region = an 8-connected component of the mask).  The reference's matcher ``match_distmin`` is unfinished and returns ``[]`` (:56-79): ``transfer_points`` returns
 the extracted points in peak order instead of an empty tensor.
 """
 from __future__ import annotations
@@ -23,7 +24,7 @@ from . import ops
 
 
 class Heatmap:
-    def __init__(self, pattern, w, h, radius=3, match_method="match_distmin"):
+    def __init__(self, pattern, w, h, radius=3, match_method="match_distmin", segmentation="watershed"):
         # the argument checks of HeatmapPattern.__init__ (heatmap.py:32-49)
         if not isinstance(pattern, list):
             raise TypeError("'pattern' must be list.")
@@ -41,6 +42,9 @@ class Heatmap:
             raise TypeError("'match_method' must be str")
         self.pattern, self.w, self.h, self.radius = pattern, w, h, radius
         self.match_method = match_method
+        if segmentation not in ("watershed", "components"):
+            raise ValueError("'segmentation' must be 'watershed' or 'components'")
+        self.segmentation = segmentation
 
     @staticmethod
     def _cuda(t):
@@ -60,7 +64,7 @@ class Heatmap:
         pred = self._cuda(pred)
         if pred.dim() != 2:
             raise AssertionError("Heatmap assertion failed. It should be [H, W]")
-        points, counts = ops.keypoints_extract(pred.unsqueeze(0), int(num), float(threshold))
+        points, counts = ops.keypoints_extract(pred.unsqueeze(0), int(num), float(threshold), segmentation=self.segmentation)
         n = min(int(counts[0]), int(num))
         # origin size == map size here (the reference rescales by origin/self sizes that are the same numbers, :171-172)
         return [[int(x), int(y)] for x, y in points[0, :n].cpu().tolist()]
@@ -80,7 +84,8 @@ class Heatmap:
                 raise AssertionError("targets shape should be [N, C, 2] with the batch size of preds")
         n, c, h, w = preds.shape
         nums = [len(hmap) for hmap in self.pattern]
-        points, counts = ops.keypoints_extract(preds.view(n * c, h, w), max(nums), float(threshold))
+        points, counts = ops.keypoints_extract(preds.view(n * c, h, w), max(nums), float(threshold),
+                                               segmentation=self.segmentation)
         points, counts = points.view(n, c, max(nums), 2), counts.view(n, c)
         limit = torch.tensor(nums, dtype=torch.int32, device=points.device).view(1, c)
         found = torch.minimum(counts, limit)

@@ -699,15 +699,75 @@ def heatmap_pattern(points: torch.Tensor, pattern, height: int, width: int, radi
     return out
 
 
-def keypoints_extract(heat: torch.Tensor, num: int, threshold: float = 0.5, max_regions: int = 4096):
-    """heat [maps, H, W] fp32 on the GPU -> (points [maps, num, 2] as (x, y), -1 padded; counts [maps] regions found).
-    tools/misc/heatmap.py:148-200 with connected components as the region step; a map without any region is retried
-    once at 0.9 * threshold (heatmap.py:176-198).  max_regions sizes the fast ranking buffer only: maps with more
-    regions are selected exactly over all of them (no failure mode the reference does not have)."""
+def _keypoints_stages(heat, thr, num, max_regions, segmentation, ws, changed, points, counts, select=True):
+    """the staged C-ABI calls of one extraction (include/unetpp_hip.h: unetpp_keypoints_extract)"""
+    lib = _lib.lib()
+    maps, h, w = heat.shape
+    st = _stream()
+    args = (_ptr(heat), maps, h, w, _ptr(thr), num, max_regions)
+
+    def stage(k, what, sweeps=1):
+        check(lib.unetpp_keypoints_extract(k, *args, sweeps, _ptr(ws), _ptr(changed), _ptr(points), _ptr(counts), st), what)
+
+    def until_stable(k, what, sweeps):
+        for _ in range(4 * (h + w)):  # a sweep moves a label / a distance at least one pixel: bounded, normally 2-3 batches
+            changed.zero_()
+            stage(k, what, sweeps)
+            if int(changed.item()) == 0:
+                return
+        raise RuntimeError("keypoints_extract: %s did not converge" % what)
+
+    stage(0, "keypoints mask")
+    if segmentation == "watershed":
+        stage(3, "keypoints distance init")
+        until_stable(4, "keypoints distance sweeps", 8)
+        stage(5, "keypoints cores")
+    until_stable(1, "keypoints merge", 4)
+    if segmentation == "watershed":
+        stage(6, "keypoints markers")
+        until_stable(7, "keypoints flood", 4)
+        stage(8, "keypoints regions")
+    if select:
+        stage(2, "keypoints select")
+
+
+def keypoints_regions(heat: torch.Tensor, threshold: float = 0.5, segmentation: str = "watershed"):
+    """heat [maps, H, W] fp32 on the GPU -> (labels int32 [maps, H, W]: the raster index of the region's first (core) pixel,
+    -1 outside every region; distance int32 [maps, H, W]: the 3x3 chamfer distance in 16-bit fixed point, zeros for
+    "components").  The region step of the extraction alone (region_segment_, tools/misc/heatmap.py:100-144, returns
+    one boolean mask per region: ``labels == root`` here)."""
     lib = _lib.lib()
     _need(heat, "heat")
     if heat.dim() != 3:
         raise ValueError("heat must be [maps, H, W]")
+    if segmentation not in ("watershed", "components"):
+        raise ValueError("segmentation must be 'watershed' or 'components'")
+    maps, h, w = heat.shape
+    dev, hw = heat.device, h * w
+    ws = torch.zeros(int(lib.unetpp_keypoints_workspace_bytes(maps, h, w, 1)), dtype=torch.uint8, device=dev)
+    changed = torch.zeros(1, dtype=torch.int32, device=dev)
+    points = torch.empty(maps, 1, 2, dtype=torch.float32, device=dev)
+    counts = torch.empty(maps, dtype=torch.int32, device=dev)
+    thr = torch.full((maps,), float(threshold), dtype=torch.float32, device=dev)
+    _keypoints_stages(heat, thr, 1, 1, segmentation, ws, changed, points, counts, select=False)
+    ints = ws[maps * hw * 8 + maps * 16:].view(torch.int32)   # workspace: best u64 [maps*hw], cand u64 [maps*max_regions*2], label, dist, marker
+    return ints[:maps * hw].view(maps, h, w).clone(), ints[maps * hw:2 * maps * hw].view(maps, h, w).clone()
+
+
+def keypoints_extract(heat: torch.Tensor, num: int, threshold: float = 0.5, max_regions: int = 4096,
+                      segmentation: str = "watershed"):
+    """heat [maps, H, W] fp32 on the GPU -> (points [maps, num, 2] as (x, y), -1 padded; counts [maps] regions found).
+    tools/misc/heatmap.py:148-200; a map without any region is retried once at 0.9 * threshold (heatmap.py:176-198).
+    segmentation="watershed": the reference's region step (region_segment_, heatmap.py:100-144) -- chamfer distance
+    cores grown back through the binary mask, touching blobs split, coreless blobs dropped; "components": a region is
+    an 8-connected component of the mask (the round-2 stand-in).  max_regions sizes the fast ranking buffer only: maps
+    with more regions are selected exactly over all of them (no failure mode the reference does not have)."""
+    lib = _lib.lib()
+    _need(heat, "heat")
+    if heat.dim() != 3:
+        raise ValueError("heat must be [maps, H, W]")
+    if segmentation not in ("watershed", "components"):
+        raise ValueError("segmentation must be 'watershed' or 'components'")
     maps, h, w = heat.shape
     dev = heat.device
     ws = torch.empty(int(lib.unetpp_keypoints_workspace_bytes(maps, h, w, max_regions)), dtype=torch.uint8, device=dev)
@@ -717,18 +777,7 @@ def keypoints_extract(heat: torch.Tensor, num: int, threshold: float = 0.5, max_
     thr = torch.full((maps,), float(threshold), dtype=torch.float32, device=dev)
 
     def run():
-        st = _stream()
-        args = (_ptr(heat), maps, h, w, _ptr(thr), num, max_regions)
-        check(lib.unetpp_keypoints_extract(0, *args, 1, _ptr(ws), _ptr(changed), _ptr(points), _ptr(counts), st), "keypoints mask")
-        for _ in range(4 * (h + w)):  # a sweep moves a label at least one pixel: bounded, and normally 2-3 batches
-            changed.zero_()
-            check(lib.unetpp_keypoints_extract(1, *args, 4, _ptr(ws), _ptr(changed), _ptr(points), _ptr(counts), st),
-                  "keypoints merge")
-            if int(changed.item()) == 0:
-                break
-        else:
-            raise RuntimeError("keypoints_extract: label propagation did not converge")
-        check(lib.unetpp_keypoints_extract(2, *args, 1, _ptr(ws), _ptr(changed), _ptr(points), _ptr(counts), st), "keypoints select")
+        _keypoints_stages(heat, thr, num, max_regions, segmentation, ws, changed, points, counts)
 
     run()
     # one small read-back per call: are there maps without any region?  (the sweeps above already read a flag back
