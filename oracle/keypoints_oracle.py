@@ -17,9 +17,11 @@ file cannot be imported and no vectors can be generated from it.  What is restat
     through their blob, the background marker through the two-pixel ring that two dilations put around the mask) and
     marks a pixel whose labelled neighbours disagree as a watershed line -- restated here as synchronous breadth-first
     rounds (OpenCV pops one pixel at a time from a FIFO queue: the two differ, if at all, in which of two equidistant
-    pixels becomes the line).  Consequences the restatement keeps: blobs that touch through a thin neck are SPLIT, a blob
-    whose distance maximum is below a tenth of the map's has no core and is NOT a region, the outermost pixel layer of a
-    blob belongs to no region.  ``segmentation="components"`` is the round-2 stand-in (a region = an 8-connected component
+    pixels becomes the line; ``watershed_fifo`` below is the pixel-by-pixel statement, tests/test_keypoints.py compares
+    the two: a handful of border pixels per map, the same points).  Consequences the restatement keeps: blobs that touch
+    through a neck no deeper than a tenth of the map's largest distance are SPLIT, a blob whose own distance maximum is
+    below that tenth has no core and is NOT a region, the frame of the map (first / last row and column) belongs to no
+    region, non-core pixels of a blob next to the labelled ring become lines.  ``segmentation="components"`` is the round-2 stand-in (a region = an 8-connected component
     of the mask).  Kept as in the reference: regions ordered by their maximum (descending, stable in label order), the first `num`
     taken, each reported as (x, y) of the first pixel in raster order that attains the maximum; when no region exists
     the extraction is retried once at 0.9 * threshold (heatmap.py:176-198).
@@ -80,14 +82,13 @@ def chamfer_distance(mask: np.ndarray) -> np.ndarray:
 
 def watershed_regions(mask: np.ndarray):
     """region_segment_ (heatmap.py:100-144) on the median mask -> (labels int64 [H, W]: core label >= 1 inside a region,
-    0 elsewhere; number of regions).  Labels follow the raster order of each core's first pixel."""
+    0 elsewhere; the labels that own at least one pixel, ascending = raster order of each core's first pixel).
+    cv2.watershed frames the marker image with boundary pixels (-1) before it floods, so the outermost rows / columns
+    of a map carry no label and belong to no region; a core that lies in the frame only does not become a region."""
     h, w = mask.shape
-    dist_f = (chamfer_distance(mask).astype(np.float32) * np.float32(1.0 / 65536.0)).astype(np.float32)
-    thr = np.float32(0.1 * float(dist_f.max())) if mask.any() else np.float32(0)
-    core = mask & (dist_f > thr)
-    core_lab, count = ndimage.label(core, structure=np.ones((3, 3), dtype=int))
-    sure_bg = ndimage.binary_dilation(mask, structure=np.ones((3, 3), dtype=bool), iterations=2)
-    mk = np.where(core, core_lab + 1, np.where(sure_bg, 0, 1)).astype(np.int64)   # 1 = background marker, 0 = unknown
+    mk, _ = region_markers(mask)   # 1 = background marker, 0 = unknown
+    mk[0, :] = mk[-1, :] = -1
+    mk[:, 0] = mk[:, -1] = -1
     pad_m = np.zeros((h + 2, w + 2), dtype=np.int64)
     pad_v = np.full((h + 2, w + 2), -1, dtype=np.int64)   # value outside the image: matches nothing
     pad_v[1:-1, 1:-1] = mask
@@ -108,7 +109,72 @@ def watershed_regions(mask: np.ndarray):
             break
         mk = np.where(grow, np.where(lo == hi, lo, -1), mk)
     labels = np.where(mk >= 2, mk - 1, 0)
-    return labels, count
+    return labels, [int(v) for v in np.unique(labels[labels > 0])]
+
+
+def watershed_fifo(mask: np.ndarray, markers: np.ndarray) -> np.ndarray:
+    """cv2.watershed on the three-channel image of a binary mask, restated pixel by pixel from its published algorithm
+    (Meyer's flooding with one FIFO queue per grey-level difference; OpenCV modules/imgproc/src/segmentation.cpp):
+    the frame of the marker image is set to -1; every unlabelled pixel with a labelled 4-neighbour is queued, in raster
+    order, under the smallest difference to such a neighbour; then, always from the lowest non-empty queue, a pixel is
+    popped, takes the label its labelled neighbours (left, right, top, bottom) agree on or -1 where they differ, and --
+    unless it became -1 -- queues its still unlabelled neighbours under their difference to it.  SEQUENTIAL: the slow,
+    order-faithful statement the synchronous rounds of ``watershed_regions`` (and of the device kernel) are compared with
+    in tests/test_keypoints.py.  markers: > 0 labels, 0 unknown.  Returns the marker image after flooding."""
+    from collections import deque
+    h, w = mask.shape
+    val = np.where(mask, 255, 0).astype(np.int64)
+    m = markers.astype(np.int64).copy()
+    m[0, :] = m[-1, :] = -1
+    m[:, 0] = m[:, -1] = -1
+    IN_QUEUE = -2
+    queues = [deque() for _ in range(256)]
+    nbrs = ((0, -1), (0, 1), (-1, 0), (1, 0))   # left, right, top, bottom
+    for y in range(1, h - 1):
+        for x in range(1, w - 1):
+            if m[y, x] < 0:
+                m[y, x] = 0
+            if m[y, x] == 0:
+                idx = 256
+                for dy, dx in nbrs:
+                    if m[y + dy, x + dx] > 0:
+                        idx = min(idx, abs(int(val[y, x]) - int(val[y + dy, x + dx])))
+                if idx < 256:
+                    queues[idx].append((y, x))
+                    m[y, x] = IN_QUEUE
+    active = 0
+    while True:
+        if not queues[active]:
+            active = next((i for i in range(active + 1, 256) if queues[i]), 256)
+            if active == 256:
+                break
+        y, x = queues[active].popleft()
+        lab = 0
+        for dy, dx in nbrs:
+            t = m[y + dy, x + dx]
+            if t > 0:
+                lab = t if lab == 0 else (lab if t == lab else -1)
+        m[y, x] = lab
+        if lab == -1:
+            continue
+        for dy, dx in nbrs:
+            if m[y + dy, x + dx] == 0:
+                t = abs(int(val[y, x]) - int(val[y + dy, x + dx]))
+                queues[t].append((y + dy, x + dx))
+                active = min(active, t)
+                m[y + dy, x + dx] = IN_QUEUE
+    return m
+
+
+def region_markers(mask: np.ndarray):
+    """the marker image region_segment_ hands to cv2.watershed (heatmap.py:117-137): core labels + 1, background 1
+    beyond two 3x3 dilations of the mask, 0 (unknown) in between; and the number of cores"""
+    dist_f = (chamfer_distance(mask).astype(np.float32) * np.float32(1.0 / 65536.0)).astype(np.float32)
+    thr = np.float32(0.1 * float(dist_f.max())) if mask.any() else np.float32(0)
+    core = mask & (dist_f > thr)
+    core_lab, count = ndimage.label(core, structure=np.ones((3, 3), dtype=int))
+    sure_bg = ndimage.binary_dilation(mask, structure=np.ones((3, 3), dtype=bool), iterations=2)
+    return np.where(core, core_lab + 1, np.where(sure_bg, 0, 1)).astype(np.int64), count
 
 
 def _extract_once(pred: np.ndarray, num: int, threshold: float, segmentation: str = "watershed"):
@@ -116,11 +182,12 @@ def _extract_once(pred: np.ndarray, num: int, threshold: float, segmentation: st
     heat[heat < threshold] = 0
     mask = region_mask(pred.astype(np.float32), threshold)
     if segmentation == "watershed":
-        labels, count = watershed_regions(mask)
+        labels, present = watershed_regions(mask)
     else:
         labels, count = ndimage.label(mask, structure=np.ones((3, 3), dtype=int))
+        present = list(range(1, count + 1))
     regions = []
-    for lab in range(1, count + 1):  # scipy labels in raster order of each component's first pixel
+    for lab in present:  # scipy labels in raster order of each component's first pixel (np.unique(markers), heatmap.py:127)
         inside = np.where(labels == lab, heat, 0)
         regions.append((float(inside.max()), lab, inside))
     regions.sort(key=lambda r: r[0], reverse=True)  # stable: ties keep label order (heatmap.py:163)
@@ -128,7 +195,7 @@ def _extract_once(pred: np.ndarray, num: int, threshold: float, segmentation: st
     for peak, _, inside in regions[:num]:
         ys, xs = np.where(inside == peak)  # (a region whose values are all zero reports its first zero, as the reference)
         points.append([int(xs[0]), int(ys[0])])
-    return points, count
+    return points, len(present)
 
 
 def extract_points(pred: np.ndarray, num: int, threshold: float = 0.5, segmentation: str = "watershed"):

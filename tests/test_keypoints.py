@@ -8,8 +8,8 @@ import numpy as np
 import pytest
 import torch
 
-from oracle.keypoints_oracle import (DIAG_DIST, HV_DIST, chamfer_distance, create_heatmap_pattern, extract_points, region_mask,
-                                     transfer_points, watershed_regions)
+from oracle.keypoints_oracle import (DIAG_DIST, HV_DIST, chamfer_distance, create_heatmap_pattern, extract_points, region_markers,
+                                     region_mask, transfer_points, watershed_fifo, watershed_regions)
 from tests.helpers import load_golden
 
 PATTERN = [[0], [1, 2, 3], [4], [5, 6]]
@@ -77,7 +77,11 @@ def _touching_maps():
     corner[28:52, 28:52] = 0.7
     corner[10, 10] = 0.8
     corner[30, 38] = 0.9
+    edge = np.zeros((12, 20), dtype=np.float32)         # survives the median (replicated border), all core, but in the frame
+    edge[0, 3:15] = 0.9
+    edge[4:9, 19] = 0.8
     return {
+        "lines in the frame": (edge, 0.5),
         "squares touching at a corner": (corner, 0.5),
         "two discs that overlap": (_discs(64, 64, [(20, 30, 4.0, 1.0), (34, 30, 4.0, 0.9)]), 0.3),
         "thick blob next to a thin one": (_discs(64, 96, [(30, 30, 8.0, 1.0), (80, 12, 0.9, 0.9)]), 0.4),
@@ -132,10 +136,43 @@ def test_oracle_splits_touching_blobs_and_drops_coreless_ones():
     assert extract_points(heat, 4, thr) == [[30, 30]]                             # thinner than a tenth of the thickest: no core
     heat, thr = maps["three in a row"]
     assert extract_points(heat, 4, thr) == [[20, 20], [64, 20], [42, 20], [100, 8]]
-    labels, count = watershed_regions(region_mask(heat, thr))
-    assert count == 4 and set(np.unique(labels)) == {0, 1, 2, 3, 4}
+    labels, present = watershed_regions(region_mask(heat, thr))
+    assert present == [1, 2, 3, 4] and set(np.unique(labels)) == {0, 1, 2, 3, 4}
     heat, thr = maps["everything above the threshold"]
-    assert extract_points(heat, 2, thr) == [[0, 0]]                               # one region, plateau: first pixel
+    assert extract_points(heat, 2, thr, "components") == [[0, 0]]                 # one region, plateau: first pixel
+    assert extract_points(heat, 2, thr) == [[1, 1]]                               # cv2.watershed frames the map with -1
+    heat, thr = maps["blob on the border"]
+    assert extract_points(heat, 2, thr, "components") == [[0, 0], [31, 16]]
+    assert extract_points(heat, 2, thr) == [[1, 1], [30, 16]]
+    edge = np.zeros((12, 20), dtype=np.float32)                                   # a line along the first row survives the
+    edge[0, 3:15] = 0.9                                                           # median (replicated border) and is all core,
+    assert region_mask(edge, 0.5)[0, 4:14].all()                                  # but it lies in the frame: no region, and
+    assert extract_points(edge, 2, 0.5, "components") == [[4, 0]]                 # the retry finds none either
+    assert extract_points(edge, 2, 0.5) == []
+
+
+def test_synchronous_flood_against_the_sequential_watershed():
+    """The device floods in synchronous rounds; cv2.watershed pops one pixel at a time from FIFO queues (restated in
+    watershed_fifo).  Same regions up to a few pixels where two fronts meet in the same round -- and the same points."""
+    cases = dict(_touching_maps())
+    rb = _random_blob_maps(11, 2, 2, 96, 80)
+    for i in range(2):
+        for j in range(2):
+            cases["random blobs %d/%d" % (i, j)] = (rb[i, j], 0.5)
+    for name, (heat, thr) in cases.items():
+        mask = region_mask(heat, thr)
+        labels, present = watershed_regions(mask)
+        markers, _ = region_markers(mask)
+        flooded = watershed_fifo(mask, markers)
+        fifo = np.where(flooded >= 2, flooded - 1, 0)
+        assert [int(v) for v in np.unique(fifo[fifo > 0])] == present, name
+        differ = int((fifo != labels).sum())
+        assert differ <= max(4, int(0.01 * (labels > 0).sum())), (name, differ)
+        assert not ((fifo > 0) & (labels > 0) & (fifo != labels)).any(), name    # never a pixel in two different regions
+        hz = np.where(heat < thr, 0, heat)
+        for lab in present:                                                        # the same peak, at the same pixel
+            a, b = np.where(fifo == lab, hz, 0), np.where(labels == lab, hz, 0)
+            assert a.max() == b.max() and np.argmax(a) == np.argmax(b), (name, lab)
 
 
 # ------------------------------------------------------------------------------------------ GPU
@@ -206,12 +243,12 @@ def test_extraction_hip_equals_oracle(dev, seed, h, w, segmentation):
     assert hm.extract_points_(np.zeros((h, w), dtype=np.float32), 2) == []
 
 
-def _same_partition(got, want_labels, want_count):
-    """device labels (root index, -1 outside) describe the oracle's regions (1..count, 0 outside), in the same order"""
+def _same_partition(got, want_labels, present):
+    """device labels (root index, -1 outside) describe the oracle's regions (labels `present`, 0 outside), in the same order"""
     roots = np.unique(got[got >= 0])
-    assert len(roots) == want_count
-    for k, r in enumerate(roots):      # oracle labels follow the raster order of the cores' first pixels, as the roots do
-        np.testing.assert_array_equal(got == r, want_labels == k + 1)
+    assert len(roots) == len(present)
+    for lab, r in zip(present, roots):  # oracle labels follow the raster order of the cores' first pixels, as the roots do
+        np.testing.assert_array_equal(got == r, want_labels == lab)
     np.testing.assert_array_equal(got < 0, want_labels == 0)
 
 
@@ -230,12 +267,12 @@ def test_region_step_hip_equals_oracle(dev):
         labels, dist = ops.keypoints_regions(t, thr)
         mask = region_mask(heat, thr)
         np.testing.assert_array_equal(dist[0].cpu().numpy(), chamfer_distance(mask), err_msg=name)
-        want_labels, want_count = watershed_regions(mask)
-        _same_partition(labels[0].cpu().numpy(), want_labels, want_count)
+        want_labels, present = watershed_regions(mask)
+        _same_partition(labels[0].cpu().numpy(), want_labels, present)
         comp, _ = ops.keypoints_regions(t, thr, segmentation="components")
         from scipy import ndimage
         cl, cc = ndimage.label(mask, structure=np.ones((3, 3), dtype=int))
-        _same_partition(comp[0].cpu().numpy(), cl, cc)
+        _same_partition(comp[0].cpu().numpy(), cl, list(range(1, cc + 1)))
         for seg in ("watershed", "components"):
             points, counts = ops.keypoints_extract(t, 5, thr, segmentation=seg)
             ref = extract_points(heat, 5, thr, seg)
@@ -264,8 +301,8 @@ def test_extraction_has_no_region_limit(dev):
     heat = rng.uniform(0, 1, (2, h, w)).astype(np.float32)
     w_points, w_counts = ops.keypoints_extract(torch.from_numpy(heat).to(dev), num, thr)     # the reference's region step
     for m in range(2):
-        _, cores = watershed_regions(region_mask(heat[m], thr))
-        assert cores > 4096 and int(w_counts[m]) == cores
+        _, present = watershed_regions(region_mask(heat[m], thr))
+        assert len(present) > 4096 and int(w_counts[m]) == len(present)
         ref = extract_points(heat[m], num, thr)
         assert [[int(x), int(y)] for x, y in w_points[m].cpu().tolist()] == ref
     points, counts = ops.keypoints_extract(torch.from_numpy(heat).to(dev), num, thr, segmentation="components")

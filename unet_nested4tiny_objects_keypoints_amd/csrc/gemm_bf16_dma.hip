@@ -272,6 +272,11 @@ __global__ __launch_bounds__(64 * WAVES, RMW ? 2 : 3) void gemm_bf16_dma_kernel(
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (dma_lptr_t)(in_dst + blk * 1024), 16, static_cast<int>(voff[q]), soff, 0, 0);
     }
     }
+#if defined(UNETPP_DMA_EXP_NO_WDMA)        // (timing experiments: what the weight bytes cost a CU's memory path)
+    need_w = false;
+#elif defined(UNETPP_DMA_EXP_HALF_WDMA)
+    need_w = need_w && (p_chunk & 1) == 0;
+#endif
     if (need_w) dma_weights(w_buf, p_wimg, p_chunk);
   };
   // next chunk of the unit, or chunk 0 of the next unit; false when nothing is left

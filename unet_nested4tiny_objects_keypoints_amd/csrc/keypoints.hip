@@ -211,7 +211,8 @@ __global__ __launch_bounds__(kKpThreads) void kp_core_kernel(int H, int W, const
 }
 
 // markers (heatmap.py:131-137): a core pixel carries its component's root + 2; a pixel further than two 3x3 dilations
-// from the mask is background (1); the rest -- the blobs outside their cores and the ring around them -- is unknown (0)
+// from the mask is background (1); the rest -- the blobs outside their cores and the ring around them -- is unknown (0).
+// The frame of the map is a boundary (-1) from the start, as cv2.watershed makes it: it neither takes nor passes a label.
 __global__ __launch_bounds__(kKpThreads) void kp_marker_kernel(int H, int W, const int* __restrict__ dist,
                                                                const int* __restrict__ label, int* __restrict__ marker) {
   const long hw = static_cast<long>(H) * W;
@@ -219,9 +220,11 @@ __global__ __launch_bounds__(kKpThreads) void kp_marker_kernel(int H, int W, con
   if (i >= hw) return;
   const int* d = dist + static_cast<long>(blockIdx.y) * hw;
   const int l = label[static_cast<long>(blockIdx.y) * hw + i];
+  const int y = static_cast<int>(i / W), x = static_cast<int>(i % W);
   int mk = l + 2;
-  if (l < 0) {
-    const int y = static_cast<int>(i / W), x = static_cast<int>(i % W);
+  if (y == 0 || x == 0 || y == H - 1 || x == W - 1) {
+    mk = -1;
+  } else if (l < 0) {
     bool near = false;
     for (int dy = -2; dy <= 2; ++dy)
       for (int dx = -2; dx <= 2; ++dx) {
@@ -319,13 +322,16 @@ __global__ __launch_bounds__(1024) void kp_select_kernel(int H, int W, const int
   __shared__ unsigned long long red[1024 / 64];
   __shared__ unsigned long long chosen;
   const long hw = static_cast<long>(H) * W;
-  const int* lab = label + static_cast<long>(blockIdx.x) * hw;
+  (void)label;
   const unsigned long long* bst = best + static_cast<long>(blockIdx.x) * hw;
   unsigned long long* cd = cand + static_cast<long>(blockIdx.x) * max_regions * 2;  // (peak key, root)
   if (threadIdx.x == 0) n_cand = 0;
   __syncthreads();
+  // a root = the first pixel of a region that owns at least one pixel: every labelled pixel has put a non-zero key into
+  // best[its label] (kp_peak_kernel).  (Not `lab[i] == i`: a watershed region whose core starts in the frame of the map
+  // keeps its label, but the frame pixel itself belongs to no region.)
   for (long i = threadIdx.x; i < hw; i += blockDim.x) {
-    if (lab[i] == static_cast<int>(i)) {
+    if (bst[i] != 0ull) {
       const int slot = atomicAdd(&n_cand, 1);
       if (slot < max_regions) {
         cd[2 * slot] = bst[i];
@@ -357,7 +363,7 @@ __global__ __launch_bounds__(1024) void kp_select_kernel(int H, int W, const int
   for (int r = 0; r < num; ++r) {
     unsigned long long mine = 0ull;  // 0 = nothing (a real key has non-zero low half: ~root with root < 2^31)
     for (long i = threadIdx.x; i < hw; i += blockDim.x) {
-      if (lab[i] != static_cast<int>(i)) continue;
+      if (bst[i] == 0ull) continue;
       const unsigned long long key = (bst[i] & 0xFFFFFFFF00000000ull) | (0xFFFFFFFFull - static_cast<unsigned long long>(i));
       if (key < below && key > mine) mine = key;
     }

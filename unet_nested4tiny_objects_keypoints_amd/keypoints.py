@@ -10,7 +10,8 @@ no vectors could be generated from it; the kernels are checked against oracle/ke
 the source text and, for the OpenCV calls of region_segment_ (:100-144), from their published algorithms: the 3x3
 chamfer ``cv2.distanceTransform`` in fixed point, cores above a tenth of its maximum, ``cv2.connectedComponents`` of the
 cores, ``cv2.watershed`` of the binary mask seeded with them).  ``segmentation="watershed"`` (default) is that region
-step: blobs that touch are split, a blob without a core is dropped; ``segmentation="components"`` keeps the round-2
+step: blobs that touch through a thin neck are split, a blob without a core is dropped, the frame of the map (first /
+last row and column) belongs to no region, as ``cv2.watershed`` leaves it; ``segmentation="components"`` keeps the round-2
 stand-in (a region = an 8-connected component of the mask).  The reference's matcher ``match_distmin`` is unfinished and returns ``[]`` (:56-79): ``transfer_points`` returns
 the extracted points in peak order instead of an empty tensor.
 """
