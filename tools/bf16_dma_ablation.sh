@@ -16,6 +16,7 @@ for v in ${VARIANTS:-BASE NO_MFMA NO_EPI NO_INDMA NO_MFMA_NO_EPI STORE_LINEAR}; 
     NO_MFMA_NO_EPI) D="-DUNETPP_DMA_EXP_NO_MFMA -DUNETPP_DMA_EXP_NO_EPI";;
     STORE_LINEAR) D="-DUNETPP_DMA_EXP_STORE_LINEAR";;
     STORE_LINEAR_NO_MFMA) D="-DUNETPP_DMA_EXP_STORE_LINEAR -DUNETPP_DMA_EXP_NO_MFMA";;
+    NO_STORE) D="-DUNETPP_DMA_EXP_NO_STORE";;
     NO_WDMA) D="-DUNETPP_DMA_EXP_NO_WDMA";;
     HALF_WDMA) D="-DUNETPP_DMA_EXP_HALF_WDMA";;
 

@@ -23,13 +23,18 @@
 // gemm_bf16.hip), channel slices in multiples of 32, tensors below 2 GB.  Same weight image, same results bit for bit
 // (tests/test_gpu_bf16.py::test_bf16_dma_and_register_kernels_agree).
 //
-// What it showed (tools/bf16_dma_ablation.sh, 32 -> 32 at 512 x 512 x 8, HBM floor 33.5 us): 70 us as it stands; without
-// the MFMA phase 61; without the epilogue 43; loads alone (DMA + barriers) 33 us = 5.5 TB/s of patch reads.  Loads and
-// stores do not overlap inside a CU: reads + writes together move 7-9 B/clk/CU whatever the instruction stream looks
-// like -- the register kernel with 3x the instructions is within 8 % -- and neither contiguous 1 KB wave stores (62 us)
-// nor issuing the next DMA and the next unit's epilogue operands BEFORE a unit's stores (counted vmcnt, two operand
-// sets; 76 us at 228 registers) changes that.  The level-0 bf16 layers are bound by the CU's memory pipeline at about
-// 0.45-0.5 of the HBM floor with 8 x 32 patches (1.33x halo); what is left is bytes per pixel (larger patches), not issue.
+// What it showed (tools/bf16_dma_ablation.sh; corrected in round 5: the NO_EPI variant of rounds 3-4 dropped the epilogue
+// call and nothing else, so hipcc deleted every MFMA with it -- its rows were "no epilogue AND no matrix phase".  With
+// the accumulators kept live, profiles/r5/ablation_gemm_bf16_dma_stores_c3.txt / _c5.txt): 32 -> 32 at 512 x 512 x 8
+// (HBM floor 34 us) 73 us as it stands; without the output stores 61, without the whole epilogue 50, without the MFMAs
+// 67, without the input DMA 57.  [32 x 4] -> 32: 196 us; 187 / 170 / 156 / 128.  [64 x 5] -> 64 at 384 x 384 x 4
+// (configs[4]): 231 us; 222 / 217 / 164 / 156, without the weight DMA 199.  So: one-chunk launches lose a third to the
+// epilogue (half of it the stores themselves), long-K launches 6 %; there the input DMA and the matrix phase are the two
+// large terms and they overlap only partly -- a chunk's 75 KB arrive at ~16 GB/s per CU (4.2 TB/s over the chip, L2
+// hits included), which is the rate a plain streaming kernel gets from HBM, while its MFMAs need 1.9 us of the 4.6.
+// Neither contiguous 1 KB wave stores nor issuing the next DMA and the next unit's epilogue operands BEFORE a unit's
+// stores (counted vmcnt, two operand sets; 228 registers) changed the sum; what is left is bytes per pixel (halo,
+// weights per chunk), not issue order.
 //
 // Round 4, measured on ONE box with alternating libraries (tools/dma_ab.sh; boxes of the pool differ by up to 30 % on these
 // store-heavy launches, which is how the first of these looked like a 3-7 % gain when it was timed on another box):
@@ -43,8 +48,7 @@
 //     SLOWER on both bf16 steps -- once more: what a CU's memory path moves per unit is the bound, not when it moves it.
 // tools/dma_stamps.py (stamped build): per 32-channel chunk of [64 x 5] -> 64 at 384 x 384 x 4 wave 0 spends 600 cycles in
 // the cursor, 1 860 issuing its ten DMA pieces, 2 650 in LDS reads + MFMAs, 435 in the epilogue (per-chunk average) and
-// 2 450 in the barrier, most of which is the second wave of its SIMD running ITS MFMAs; without the epilogue the barrier
-// share halves -- the unit's 64 KB of output stores delay the next chunk's DMA in the CU's memory pipeline by ~9 us.
+// 2 450 in the barrier, most of which is the second wave of its SIMD running ITS MFMAs.
 #include <cstdlib>
 
 #include "bf16_common.h"
@@ -534,7 +538,9 @@ __global__ __launch_bounds__(64 * WAVES, RMW ? 2 : 3) void gemm_bf16_dma_kernel(
             }
             out = pack8(v);
           }
-#ifdef UNETPP_DMA_EXP_STORE_LINEAR   // timing only: every store instruction writes 1 KB contiguous (wrong layout)
+#if defined(UNETPP_DMA_EXP_NO_STORE)    // timing only: the whole epilogue (accumulators reset, values packed) without its stores
+          asm volatile("" ::"v"(out), "v"(optr + pbase + c0));
+#elif defined(UNETPP_DMA_EXP_STORE_LINEAR)   // timing only: every store instruction writes 1 KB contiguous (wrong layout)
           if (pix_ok && c0 < tc.n_cnt) *reinterpret_cast<u32x4*>(optr + tile_base + ((wave * 4 + mt * 2 + half) * 64 + lane) * 8) = out;
 #else
           if (pix_ok && c0 < tc.n_cnt) *reinterpret_cast<u32x4*>(optr + pbase + c0) = out;
@@ -634,6 +640,17 @@ __global__ __launch_bounds__(64 * WAVES, RMW ? 2 : 3) void gemm_bf16_dma_kernel(
       } else {
 #ifndef UNETPP_DMA_EXP_NO_EPI
         epilogue_direct();
+#else   // timing only.  The accumulators must stay live: until round 5 this variant dropped the call and nothing else, hipcc
+        // then deleted every MFMA of the kernel as dead code, and the "epilogue share" read off it (33-48 %) was the
+        // epilogue AND the matrix phase (profiles/r5/ablation_gemm_bf16_dma_stores_c5.txt has the corrected table)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            asm volatile("" : "+v"(acc[t][mt]));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][mt][r] = 0.f;
+          }
 #endif
       }
       step_unit(c_ug, c_index);
