@@ -144,7 +144,7 @@ const char* unetpp_last_kernel_name(void);
 /* Dispatcher switches for A/B measurements and for tests that hold two kernels against each other inside one process
  * (v9; replaces per-launch getenv).  `name` is the switch without its UNETPP_ prefix: BF16_NO_DMA, BF16_DMA_ALL,
  * BF16_DMA_MIN8, BF16_DMA_FORM, BF16_DMA_SMALL, BF16_DMA_STATS, BF16_DMA_POINTWISE, BF16_DMA_SPLIT, BF16_WGRAD_QUAD,
- * WINO_NO_LEAN, WINO_ONE_PER_CU, MEMSET_NODES, PW_NO_DMA, BF16_PW_PLAIN.  set != 0: the switch takes `value`; set == 0: back to the
+ * WINO_NO_LEAN, WINO_ONE_PER_CU, MEMSET_NODES, BF16_PW_PLAIN.  set != 0: the switch takes `value`; set == 0: back to the
  * dispatcher's built-in default.  The environment variable UNETPP_<name>, if present when the library first looks a
  * switch up, is the initial setting.  Process-wide; results never depend on a switch beyond the summation order of the
  * kernel it selects.  UNETPP_EINVAL for an unknown name. */

@@ -145,7 +145,6 @@ enum Opt {
   OPT_WINO_NO_LEAN,        // 1: the general Winograd instantiation for every launch
   OPT_WINO_ONE_PER_CU,     // 1: (stamped / experiment builds) one Winograd workgroup per CU
   OPT_MEMSET_NODES,        // 1: unused workspace rows cleared by hipMemsetAsync instead of zero_rows_kernel (graph probe only)
-  OPT_PW_NO_DMA,           // 1: fp32 pointwise GEMMs (transposed convolutions, 1x1) never take the LDS-DMA kernel
   OPT_BF16_PW_PLAIN,       // 0: plain-output bf16 pointwise launches on the two-per-CU instantiation (round-4 form)
   OPT_COUNT
 };
