@@ -56,9 +56,14 @@ out = (ctypes.c_uint64 * 16)()
 assert fn(out, 0) == 0
 waves = out[8]
 us = 1e3 * s.elapsed_time(e) / REPS
-total = sum(out[i] for i in range(8))
+total = sum(out[i] for i in range(16) if i != 8)
+if not WGRAD:
+    PHASES = PHASES + ["(wave count)", "epilogue: geometry + bias", "epilogue: output row 0", "epilogue: output row 1", "", "", "", ""]
+    PHASES[6] = "epilogue: zeroing, statistics"
 print("%d -> %d channels at %dx%d, batch %d: %.1f us per launch (stamped build), %d waves per launch" %
       (ci, co, hw, hw, B, us, waves // REPS))
 print("s_memtime ticks per wave per launch: %.0f (%.2f ticks/ns)" % (total / waves, total / waves / (us * 1e3)))
 for i, name in enumerate(PHASES):
+    if i == 8 or not name:
+        continue
     print("  %-34s %9.0f  %5.1f %%" % (name, out[i] / waves, 100.0 * out[i] / total))

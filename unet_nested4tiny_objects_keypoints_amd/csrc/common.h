@@ -45,6 +45,16 @@ __device__ __forceinline__ float xor_lane(float v) {
   return __builtin_bit_cast(float, r);
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15) in a fixed order; every lane of the row ends with the sum.
+// Four VALU instructions, no LDS crossbar: quad permutations, then the half-row and the row mirrored.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += xor_lane<1>(v);
+  v += xor_lane<2>(v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
 // slab groups of the weight-gradient finish kernels for n_split slabs: the smallest power of two >= n_split, at most 16
 inline int finish_log2_groups(int n_split) {
   int l = 0;

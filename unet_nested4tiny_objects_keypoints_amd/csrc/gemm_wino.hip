@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   constexpr int HWp = TW + 2, HHp = TH + 2;
   constexpr int NPIX = HWp * HHp;
   constexpr int TXN = TW / 2;        // 2x2 tiles per patch row (a power of two)
-  constexpr int IN_FLOATS = 4096;    // >= kMaxHaloPixels * WP (3400); also the 4 x 4 KB transpose scratch of the epilogue
+  constexpr int IN_FLOATS = 4096;    // >= kMaxHaloPixels * WP (3400) and the dummy staging items behind the patch
   constexpr int IN_ITEMS = (NPIX * 2 + kThreads - 1) / kThreads;  // 16-byte items, 2 per pixel (<= 3)
   constexpr int W_ITEMS = WIMG / 4 / kThreads;                    // 4
   static_assert(IN_ITEMS == 3 && W_ITEMS == 4, "the staging lambdas' default ranges");
@@ -145,12 +145,18 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   // per column
   constexpr int RUN0 = 4 * WNC * 2;
   __shared__ float stat_lds[BNF ? RUN0 + kBnFusedMaxCols * 2 : RUN0];
+  // The launch's bias vector (zeros past Ncols / without a bias), read by every epilogue: from global memory that read
+  // sat at the head of the epilogue with a full memory round trip in front of the first output value.
+  constexpr int kBiasCols = 512;
+  __shared__ __attribute__((aligned(16))) float bias_lds[kBiasCols];
 
   const unetpp_gemm_desc& d = a.d;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, t16 = lane & 15, g = lane >> 4;
 
   const UnitRange ur = my_contiguous_unit_range(a.total_blocks);
+  for (int i = tid; i < kBiasCols; i += kThreads)  // (a barrier follows in the prologue)
+    bias_lds[i] = (a.d.bias != nullptr && i < a.Ncols) ? a.d.bias[i] : 0.f;
   constexpr bool bn_fused = BNF;
   if constexpr (BNF) {
     for (int i = tid; i < kBnFusedMaxCols * 2; i += kThreads) stat_lds[RUN0 + i] = 0.f;  // (a barrier follows in the prologue)
@@ -255,9 +261,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     p_tx0 = ug.tx0;
     if constexpr (LEAN) {
       const int row0 = p_n * d.H;
+      // (tid "produced" here: hipcc would hoist the items' halo coordinates -- six per-thread invariants of this
+      // once-per-patch path -- out of the chunk loop into registers the MFMA phase needs, and spill them)
+      int te = tid;
+      asm volatile("" : "+v"(te));
 #pragma unroll
       for (int q = 0; q < IN_ITEMS; ++q) {
-        const int it = tid + q * kThreads;
+        const int it = te + q * kThreads;
         const int hp = it >> 1;
         const int hy = hp / HWp, hx = hp - hy * HWp;
         const int y = p_ty0 + hy - 1, x = p_tx0 + hx - 1;
@@ -416,8 +426,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     }
   };
 
+#ifdef UNETPP_WINO_STAMPS
+  unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_last = 0;
+#endif
   // ---- epilogue of a finished unit: output transform, bias / ReLU / gate / accumulate, BatchNorm partial sums ----
-  // Register rr of acc[xi][nh] of lane (t16, g) belongs to tile 16*wave + 4*g + rr and column t16 + 16*nh.
+  // The MFMAs take the weight fragment as their A operand and the transformed window as B, so register rr of acc[xi][nh]
+  // of lane (t16, g) belongs to THIS lane's tile (16 * wave + t16, the tile whose windows it transforms) and to column
+  // 16 * nh + 4 * g + rr: four consecutive output channels per accumulator, i.e. one 16-byte store per pixel and column
+  // half straight from the registers (the 4 k-slot lanes of a tile write 64 contiguous bytes).  Rounds 1-5 had tiles in
+  // the registers and one column per lane, and went through a 4 KB LDS transpose per wave (32 ds_write_b32 + 8
+  // ds_read_b128 per unit, their waits, and a workgroup barrier before the next staging could reuse the scratch).
   auto epilogue = [&]() {
     const UnitGeom& ug = c_ug;
     const TileCols tc = decode_tile(a, ug.group);
@@ -431,119 +450,128 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
                          (O.gate == nullptr || (reinterpret_cast<uintptr_t>(O.gate) & 15) == 0);
     const bool want_stats = d.stats_partial != nullptr;
     const float floor_v = O.relu ? 0.f : -__builtin_inff();
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    float s1[NH][4], s2[NH][4];
+#pragma unroll
+    for (int nh = 0; nh < NH; ++nh)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) s1[nh][rr] = s2[nh][rr] = 0.f;
     // bias folded into M[1][1]: its weight is +1 in all four outputs
+#ifndef UNETPP_WINO_EXP_GLOBAL_BIAS
+    if (d.bias != nullptr && tc.n0 + WNC <= kBiasCols) {  // uniform; n0 is a multiple of 4 (fast_args)
 #pragma unroll
-    for (int nh = 0; nh < NH; ++nh) {
-      const float bj = (d.bias != nullptr && t16 + 16 * nh < tc.n_cnt) ? d.bias[tc.n0 + t16 + 16 * nh] : 0.f;
+      for (int nh = 0; nh < NH; ++nh) acc[5][nh] += *reinterpret_cast<const f32x4*>(&bias_lds[tc.n0 + 16 * nh + 4 * g]);
+    } else
+#endif
+    if (d.bias != nullptr) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) acc[5][nh][rr] += bj;
+      for (int nh = 0; nh < NH; ++nh)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int col = 16 * nh + 4 * g + rr;
+          acc[5][nh][rr] += col < tc.n_cnt ? d.bias[tc.n0 + col] : 0.f;
+        }
     }
+    WINO_STAMP(9);  // 9: epilogue: geometry, bias
+    // this lane's tile inside the patch, and its first column
+    const unsigned ty2 = 2 * (my_tile / TXN), tx2 = 2 * (my_tile % TXN);
+    // 2x2 outputs of (nh, rr) for output row ap: y[0], y[1] = the two pixels of the row
+    auto out_row = [&](int ap, int nh, int rr, float (&y)[2]) {
+      float tb[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        tb[b] = (ap == 0) ? (acc[b][nh][rr] + acc[4 + b][nh][rr]) + acc[8 + b][nh][rr]
+                          : (acc[4 + b][nh][rr] - acc[8 + b][nh][rr]) - acc[12 + b][nh][rr];
+      y[0] = fmaxf((tb[0] + tb[1]) + tb[2], floor_v);
+      y[1] = fmaxf((tb[1] - tb[2]) - tb[3], floor_v);
+    };
     if (interior && vec_out && tc.n_cnt == 16 * NH) {
-      // ---- lean path (whole patch inside the image, all 32 columns, 16-byte stores): no per-element predicates.
-      // Transpose scratch per wave: [pixel slot (rr, bp, g)][32 columns], column half XOR (g>>1): the 64 lanes of a
-      // store hit 64 distinct banks. ----
-      float* scratch = in_tile + wave * 1024;  // in_tile is free between the barriers
-      const int sw_lane = g * 32 + (t16 ^ ((g >> 1) << 4));
+      // ---- lean path (whole patch inside the image, all columns, 16-byte stores): no per-element predicates ----
       const bool has_gate = gbase != nullptr, acc_out = O.accumulate != 0;  // uniform
+      const unsigned lane_off = ty2 * rs + tx2 * cs + 4 * g;
 #pragma unroll
       for (int ap = 0; ap < 2; ++ap) {  // output row inside the 2x2 tile
-        // The gate / previous-value reads of the four store passes are requested HERE, in front of the output transform:
-        // vmcnt counts in order, so a read issued between two stores would wait for the store before it (a memory round
-        // trip per pass, eight per unit: the input-gradient launches ran 10 % behind the forward ones for this).
-        const int q4 = (lane & 7) << 2;  // first column of this lane's 16-byte piece
-        unsigned off[4];
-        f32x4 gt[4], old[4];
+        // The gate / previous-value reads of the row's stores are requested HERE, in front of the output transform:
+        // vmcnt counts in order, so a read issued between two stores would wait for the store before it.
+        unsigned off[2][NH];
+        f32x4 gt[2][NH], old[2][NH];
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-          const int ps = (lane >> 3) + 8 * pass;  // pixel slot (rr, bp, g)
-          const int tile = 16 * wave + 4 * (ps & 3) + (ps >> 3);
-          const unsigned py = 2 * (tile / TXN) + ap, px = 2 * (tile % TXN) + ((ps >> 2) & 1);
-          off[pass] = py * rs + px * cs + q4;
-          if (NH == 1 && q4 >= 16) off[pass] = 0;  // NH = 1: these lanes store nothing; any valid address will do
-        }
+        for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+          for (int nh = 0; nh < NH; ++nh) off[bp][nh] = lane_off + ap * rs + bp * cs + 16 * nh;
         if (has_gate) {
 #pragma unroll
-          for (int pass = 0; pass < 4; ++pass) gt[pass] = *reinterpret_cast<const f32x4*>(gbase + off[pass]);
+          for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+            for (int nh = 0; nh < NH; ++nh) gt[bp][nh] = *reinterpret_cast<const f32x4*>(gbase + off[bp][nh]);
         }
         if (acc_out) {
 #pragma unroll
-          for (int pass = 0; pass < 4; ++pass) old[pass] = *reinterpret_cast<const f32x4*>(obase + off[pass]);
+          for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+            for (int nh = 0; nh < NH; ++nh) old[bp][nh] = *reinterpret_cast<const f32x4*>(obase + off[bp][nh]);
         }
+        f32x4 yv[2][NH];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
+        for (int nh = 0; nh < NH; ++nh)
 #pragma unroll
-          for (int nh = 0; nh < NH; ++nh) {
-            float tb[4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-              tb[b] = (ap == 0) ? (acc[b][nh][rr] + acc[4 + b][nh][rr]) + acc[8 + b][nh][rr]
-                                : (acc[4 + b][nh][rr] - acc[8 + b][nh][rr]) - acc[12 + b][nh][rr];
-            const float y0 = fmaxf((tb[0] + tb[1]) + tb[2], floor_v), y1 = fmaxf((tb[1] - tb[2]) - tb[3], floor_v);
+          for (int rr = 0; rr < 4; ++rr) {
+            float y[2];
+            out_row(ap, nh, rr, y);
             if (want_stats) {
-              s1[nh] += y0 + y1;
-              s2[nh] = fmaf(y0, y0, fmaf(y1, y1, s2[nh]));
+              s1[nh][rr] += y[0] + y[1];
+              s2[nh][rr] = fmaf(y[0], y[0], fmaf(y[1], y[1], s2[nh][rr]));
             }
-            scratch[(rr * 2 + 0) * 128 + (sw_lane ^ (nh << 4))] = y0;
-            scratch[(rr * 2 + 1) * 128 + (sw_lane ^ (nh << 4))] = y1;
+            yv[0][nh][rr] = y[0];
+            yv[1][nh][rr] = y[1];
           }
-        }
-        __builtin_amdgcn_wave_barrier();
         if (!has_gate && !acc_out) {  // plain stores on a path of their own: no load in it, so hipcc puts no vmcnt wait
-#pragma unroll                        // between the stores (on the shared path every store waits for all but three)
-          for (int pass = 0; pass < 4; ++pass) {
-            const int ps = (lane >> 3) + 8 * pass;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&scratch[ps * 32 + (q4 ^ (((ps & 3) >> 1) << 4))]);
-            if (q4 < 16 * NH) *reinterpret_cast<f32x4*>(obase + off[pass]) = v;
-          }
-          __builtin_amdgcn_wave_barrier();
+#pragma unroll                        // between the stores
+          for (int bp = 0; bp < 2; ++bp)
+#pragma unroll
+            for (int nh = 0; nh < NH; ++nh) *reinterpret_cast<f32x4*>(obase + off[bp][nh]) = yv[bp][nh];
+          WINO_STAMP(10 + ap);  // 10, 11: epilogue rows
           continue;
         }
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-          const int ps = (lane >> 3) + 8 * pass;
-          const int gg = ps & 3;
-          f32x4 v = *reinterpret_cast<const f32x4*>(&scratch[ps * 32 + (q4 ^ ((gg >> 1) << 4))]);
-          if (q4 >= 16 * NH) continue;  // NH = 1: only 16 columns exist
-          if (has_gate && !O.gate_sum) {
+        for (int bp = 0; bp < 2; ++bp)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (gt[pass][e] > 0.f) ? v[e] : 0.f;
-          }
-          if (acc_out) {
+          for (int nh = 0; nh < NH; ++nh) {
+            f32x4 v = yv[bp][nh];
+            if (has_gate && !O.gate_sum) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += old[pass][e];
-          }
-          if (has_gate && O.gate_sum) {
+              for (int e = 0; e < 4; ++e) v[e] = (gt[bp][nh][e] > 0.f) ? v[e] : 0.f;
+            }
+            if (acc_out) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (gt[pass][e] > 0.f) ? v[e] : 0.f;
+              for (int e = 0; e < 4; ++e) v[e] += old[bp][nh][e];
+            }
+            if (has_gate && O.gate_sum) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = (gt[bp][nh][e] > 0.f) ? v[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(obase + off[bp][nh]) = v;
           }
-          *reinterpret_cast<f32x4*>(obase + off[pass]) = v;
-        }
-        __builtin_amdgcn_wave_barrier();
+        WINO_STAMP(10 + ap);
       }
     } else {
       // ---- general path (ragged patches, partial or unaligned column tiles): one predicated dword per value ----
 #pragma unroll
       for (int ap = 0; ap < 2; ++ap) {
+        const unsigned py = ty2 + ap;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int tile = 16 * wave + 4 * g + rr;
-          const int py = 2 * (tile / TXN) + ap, px0 = 2 * (tile % TXN);
+        for (int nh = 0; nh < NH; ++nh)
 #pragma unroll
-          for (int nh = 0; nh < NH; ++nh) {
-            float tb[4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-              tb[b] = (ap == 0) ? (acc[b][nh][rr] + acc[4 + b][nh][rr]) + acc[8 + b][nh][rr]
-                                : (acc[4 + b][nh][rr] - acc[8 + b][nh][rr]) - acc[12 + b][nh][rr];
-            const float y[2] = {fmaxf((tb[0] + tb[1]) + tb[2], floor_v), fmaxf((tb[1] - tb[2]) - tb[3], floor_v)};
+          for (int rr = 0; rr < 4; ++rr) {
+            float y[2];
+            out_row(ap, nh, rr, y);
+            const int col = 16 * nh + 4 * g + rr;
 #pragma unroll
             for (int bp = 0; bp < 2; ++bp) {
               float v = y[bp];
-              if ((t16 + 16 * nh < tc.n_cnt) && (ug.ty0 + py < d.H) && (ug.tx0 + px0 + bp < d.W)) {
-                s1[nh] += v;
-                s2[nh] = fmaf(v, v, s2[nh]);
-                const unsigned off = py * rs + (px0 + bp) * cs + t16 + 16 * nh;
+              if ((col < tc.n_cnt) && (ug.ty0 + py < d.H) && (ug.tx0 + tx2 + bp < d.W)) {
+                s1[nh][rr] += v;
+                s2[nh][rr] = fmaf(v, v, s2[nh][rr]);
+                const unsigned off = py * rs + (tx2 + bp) * cs + col;
                 if (gbase != nullptr && !O.gate_sum) v = (gbase[off] > 0.f) ? v : 0.f;
                 if (O.accumulate) v += obase[off];
                 if (gbase != nullptr && O.gate_sum) v = (gbase[off] > 0.f) ? v : 0.f;
@@ -551,7 +579,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
               }
             }
           }
-        }
       }
     }
 #pragma unroll
@@ -559,19 +586,19 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 #pragma unroll
       for (int nh = 0; nh < NH; ++nh) acc[xi][nh] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (want_stats) {
-      // Per-wave sums go to LDS here; flush_stats() adds the four waves and writes the row AFTER the barrier that
-      // follows every epilogue anyway (the next epilogue is at least one more barrier away).
+      // Sum over the wave's 16 tiles (the 16 lanes of a k-slot row: DPP adds in a fixed order, every lane ends with the
+      // row's sum); per-wave sums go to LDS here, flush_stats() adds the four waves and writes the row behind a barrier.
 #pragma unroll
-      for (int nh = 0; nh < NH; ++nh) {
-        s1[nh] += __shfl_xor(s1[nh], 16);
-        s2[nh] += __shfl_xor(s2[nh], 16);
-        s1[nh] += __shfl_xor(s1[nh], 32);
-        s2[nh] += __shfl_xor(s2[nh], 32);
-        if (g == 0) {
-          stat_lds[(wave * WNC + t16 + 16 * nh) * 2 + 0] = s1[nh];
-          stat_lds[(wave * WNC + t16 + 16 * nh) * 2 + 1] = s2[nh];
+      for (int nh = 0; nh < NH; ++nh)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          s1[nh][rr] = row16_sum(s1[nh][rr]);
+          s2[nh][rr] = row16_sum(s2[nh][rr]);
+          if (t16 == 0) {
+            stat_lds[(wave * WNC + 16 * nh + 4 * g + rr) * 2 + 0] = s1[nh][rr];
+            stat_lds[(wave * WNC + 16 * nh + 4 * g + rr) * 2 + 1] = s2[nh][rr];
+          }
         }
-      }
     }
   };
   auto flush_stats = [&]() {
@@ -596,8 +623,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   };
 
 #ifdef UNETPP_WINO_STAMPS
-  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long st_last = clock64();
+  st_last = clock64();
 #endif
   // ---- pipeline: at the top of chunk c the registers hold the inputs of chunk c+1 (loaded a whole chunk ago); they
   // go to the other LDS buffer, its weight image follows by DMA, the inputs of chunk c+2 are requested, and then the
@@ -751,12 +777,12 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       // and the wait below -- left alone, the scheduler puts the reads straight in front of the wait again
       WINO_FENCE();
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 4; ++q) {  // A = weight fragment, B = transformed window: the accumulator holds this lane's tile
         const int xi = (4 * g + q) & 15;
         const f32x4 up = us[cs][q >> 1];
-        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi], up[(q & 1) * 2], acc[xi][0], 0, 0, 0);
+        acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(up[(q & 1) * 2], V[xi], acc[xi][0], 0, 0, 0);
         if (NH == 2)
-          acc[xi][NH - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[xi], up[(q & 1) * 2 + 1], acc[xi][NH - 1], 0, 0, 0);
+          acc[xi][NH - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(up[(q & 1) * 2 + 1], V[xi], acc[xi][NH - 1], 0, 0, 0);
       }
       staging_piece(gc);
       WINO_FENCE();
@@ -789,7 +815,11 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     // precisely so that they would have more than a chunk to arrive (and which the explicit vmcnt(IN_ITEMS) leaves in
     // flight).  What the barrier has to order is complete in every wave without it: its fragment reads of the current
     // buffers and its staging stores (lgkmcnt(0)), its share of the next weight image (vmcnt(IN_ITEMS)).
+#ifdef UNETPP_WINO_EXP_NO_DMA_WAIT  // experiment: the barrier does not wait for this chunk's weight DMA (wrong results)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(IN_ITEMS + W_ITEMS) : "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(IN_ITEMS) : "memory");
+#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #else
@@ -813,11 +843,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
           acc[xi][nh] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #else
-      epilogue();  // the current buffers are its scratch; stores drain while the next unit computes
+      epilogue();  // stores drain while the next unit computes
 #endif
       WINO_STAMP(6);  // 6: epilogue
-      __syncthreads();   // before the next chunk's staging overwrites that scratch
-      flush_stats();
+      if (d.stats_partial != nullptr) {  // uniform: the per-wave sums are in LDS; the next epilogue is a chunk barrier away
+        __syncthreads();
+        flush_stats();
+      }
       WINO_STAMP(7);  // 7: barrier after the epilogue
       step_unit(c_ug);
       c_chunk = 0;
@@ -831,7 +863,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
   }
 #ifdef UNETPP_WINO_STAMPS
   if (lane == 0) {
-    for (int i = 0; i < 8; ++i) atomicAdd(&g_wino_stamps[i], st_acc[i]);
+    for (int i = 0; i < 16; ++i)
+      if (i != 8) atomicAdd(&g_wino_stamps[i], st_acc[i]);
     atomicAdd(&g_wino_stamps[8], 1ull);
   }
 #endif
