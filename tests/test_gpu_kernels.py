@@ -322,19 +322,20 @@ def test_pointwise_fast_and_generic_agree(dev, shape, mode):
     for fast in (True, False):
         ops.USE_FAST_GEMM = fast
         try:
-            part = None
-            if mode == "sliced":
-                wide = torch.full((b, h, w, co + 12), 7.0, device=dev)
-                outs = [V(wide, c_off=8, c_len=co)]
-            else:
-                wide = nhwc(prev)
-                kw = {"relu": {"relu": True}, "gate": {"gate": nhwc(gate), "accumulate": True},
-                      "gate_sum": {"gate": nhwc(gate), "accumulate": True, "gate_sum": True},
-                      "accumulate": {"accumulate": True}}.get(mode, {})
-                outs = [V(wide, **kw)]
-                if mode == "stats":
-                    part = torch.empty(ops.gemm_pixel_blocks(b, h, w) * co * 2, device=dev)
-            ops.gemm_fwd(b, h, w, 1, [V(nhwc(s)) for s in srcs], outs, wp, bias.cuda(), part)
+            with ops._lib.debug_switch("PW_DIRECT", 0):   # (gemm_pw.hip sums K in another order: test_pointwise_direct_kernel)
+                part = None
+                if mode == "sliced":
+                    wide = torch.full((b, h, w, co + 12), 7.0, device=dev)
+                    outs = [V(wide, c_off=8, c_len=co)]
+                else:
+                    wide = nhwc(prev)
+                    kw = {"relu": {"relu": True}, "gate": {"gate": nhwc(gate), "accumulate": True},
+                          "gate_sum": {"gate": nhwc(gate), "accumulate": True, "gate_sum": True},
+                          "accumulate": {"accumulate": True}}.get(mode, {})
+                    outs = [V(wide, **kw)]
+                    if mode == "stats":
+                        part = torch.empty(ops.gemm_pixel_blocks(b, h, w) * co * 2, device=dev)
+                ops.gemm_fwd(b, h, w, 1, [V(nhwc(s)) for s in srcs], outs, wp, bias.cuda(), part)
         finally:
             ops.USE_FAST_GEMM = True
         res.append((wide, part))
@@ -346,6 +347,96 @@ def test_pointwise_fast_and_generic_agree(dev, shape, mode):
         assert bool((got[..., :8] == 7.0).all()) and bool((got[..., 8 + co:] == 7.0).all())
         got = got[..., 8:8 + co]
     assert rel_err(nchw(got), ref.float()) < TOL
+
+
+@pytest.mark.parametrize("case", [
+    # (B, H, W, cin per input view, cout per output view, form)
+    (2, 16, 32, [64], [32] * 4, "deconv_fwd"),        # level 0 of the depth-4 network: K 64, N 128
+    (1, 16, 16, [128], [64] * 4, "deconv_fwd"),       # level 1: K 128, N 256 = two column passes, one 128 KB image
+    (2, 8, 16, [32], [32] * 4, "deconv_fwd"),         # K 32
+    (1, 32, 48, [16], [32] * 4, "deconv_fwd"),        # K 16, three tiles per row (division instead of a shift)
+    (2, 16, 32, [32] * 4, [64], "deconv_dgrad"),      # K 128 (four phase views), N 64, gate on the sum + accumulate
+    (1, 16, 16, [64] * 4, [128], "deconv_dgrad"),     # K 256 = two K chunks
+    (1, 8, 16, [128] * 4, [64], "deconv_dgrad"),      # K 512 = four K chunks
+    (2, 16, 16, [32, 32], [64], "plain"),             # 1x1 convolution over a virtual concatenation
+    (2, 16, 16, [32, 16], [64], "plain"),             # K = 48: three 16-channel groups -> gemm_fast
+    (1, 32, 64, [64], [16], "relu"),
+    (1, 16, 16, [32], [48], "plain"),                 # three 16-column blocks: not a block count of the kernel -> gemm_fast
+    (2, 16, 32, [16], [32], "gate"),
+    (2, 16, 32, [64], [64], "accumulate"),
+    (1, 16, 16, [32], [32], "sliced"),
+    (1, 64, 64, [256], [128], "plain"),               # 128 KB image, one workgroup of sixteen waves per CU
+])
+def test_pointwise_direct_kernel(dev, case):
+    """gemm_pw.hip (weights resident in LDS, activations loaded straight into the MFMA operand registers, register-direct
+    16-byte stores) in every form the network launches -- transposed convolution forward into four phase views and its
+    input gradient out of them, 1x1 convolutions with ReLU / gate / accumulate / sliced outputs -- against the float64
+    statement and against gemm_fast_kernel<1> (same arithmetic in another summation order: 2e-6 of the largest value)."""
+    from unet_nested4tiny_objects_keypoints_amd import _lib, engine, ops
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    b, h, w, cins, couts, form = case
+    g = torch.Generator().manual_seed(33)
+    ci, co = sum(cins), sum(couts)
+
+    def run(direct):
+        with _lib.debug_switch("PW_DIRECT", 1 if direct else 0):
+            if form == "deconv_fwd":
+                x = torch.randn(b, ci, h, w, generator=torch.Generator().manual_seed(1))
+                wt = torch.randn(ci, couts[0], 2, 2, generator=torch.Generator().manual_seed(2)) * 0.2
+                bias = torch.randn(couts[0], generator=torch.Generator().manual_seed(3))
+                ref = F.conv_transpose2d(x.double(), wt.double(), bias.double(), stride=2)
+                up = torch.full((b, 2 * h, 2 * w, couts[0]), float("nan"), device=dev)
+                ops.gemm_fwd(b, h, w, 1, [V(nhwc(x))], engine._phase_views(up), engine.pack_deconv_fwd(wt.cuda()),
+                             engine.tile_bias4(bias.cuda()))
+                return nchw(up), ref
+            if form == "deconv_dgrad":
+                cu = cins[0]
+                x = torch.randn(b, co, h, w, generator=torch.Generator().manual_seed(1), dtype=torch.float64, requires_grad=True)
+                wt = torch.randn(co, cu, 2, 2, generator=torch.Generator().manual_seed(2), dtype=torch.float64) * 0.2
+                dy = torch.randn(b, cu, 2 * h, 2 * w, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+                F.conv_transpose2d(x, wt, None, stride=2).backward(dy)
+                gate = torch.randn(b, co, h, w, generator=torch.Generator().manual_seed(4))
+                prev = torch.randn(b, co, h, w, generator=torch.Generator().manual_seed(5))
+                ref = (prev.double() + x.grad) * (gate > 0)
+                dx = nhwc(prev)
+                ops.gemm_fwd(b, h, w, 1, engine._phase_views(nhwc(dy.float())),
+                             [V(dx, accumulate=True, gate=nhwc(gate), gate_sum=True)], engine.pack_deconv_dgrad(wt.float().cuda()))
+                return nchw(dx), ref
+            srcs = [torch.randn(b, c, h, w, generator=torch.Generator().manual_seed(10 + i)) for i, c in enumerate(cins)]
+            wt = torch.randn(co, ci, 1, 1, generator=torch.Generator().manual_seed(2)) * 0.3
+            bias = torch.randn(co, generator=torch.Generator().manual_seed(3))
+            gate = torch.randn(b, co, h, w, generator=torch.Generator().manual_seed(4))
+            prev = torch.randn(b, co, h, w, generator=torch.Generator().manual_seed(5))
+            ref = F.conv2d(torch.cat(srcs, 1).double(), wt.double(), bias.double())
+            if form == "relu":
+                ref = F.relu(ref)
+            elif form == "gate":
+                ref = prev.double() + ref * (gate > 0)
+            elif form == "accumulate":
+                ref = prev.double() + ref
+            if form == "sliced":
+                wide = torch.full((b, h, w, co + 12), 7.0, device=dev)
+                outs = [V(wide, c_off=8, c_len=co)]
+            else:
+                wide = nhwc(prev)
+                outs = [V(wide, **{"relu": {"relu": True}, "gate": {"gate": nhwc(gate), "accumulate": True},
+                                   "accumulate": {"accumulate": True}}.get(form, {}))]
+            ops.gemm_fwd(b, h, w, 1, [V(nhwc(s)) for s in srcs], outs, engine.pack_conv_fwd(wt.cuda()), bias.cuda())
+            if form == "sliced":
+                assert bool((wide[..., :8] == 7.0).all()) and bool((wide[..., 8 + co:] == 7.0).all())
+                wide = wide[..., 8:8 + co]
+            return nchw(wide), ref
+
+    got, ref = run(True)
+    name = _lib.lib().unetpp_last_kernel_name().decode()
+    def blocks_ok(c):
+        return (c // 16) in (1, 2, 4, 8) or (c // 16) % 8 == 0
+    takes = blocks_ok(ci) and blocks_ok(co)
+    assert name == ("gemm_pw_kernel" if takes else "gemm_fast_kernel<1>"), name
+    assert rel_err(got, ref.float()) < TOL
+    other, _ = run(False)
+    assert _lib.lib().unetpp_last_kernel_name().decode() == "gemm_fast_kernel<1>"
+    assert (got - other).abs().max().item() <= 2e-6 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("shape", [(2, 16, 16, [8], 8), (1, 32, 32, [32, 32, 32], 32), (2, 24, 40, [3], 4),

@@ -156,6 +156,8 @@ enum Opt {
   OPT_WINO_ONE_PER_CU,     // 1: (stamped / experiment builds) one Winograd workgroup per CU
   OPT_MEMSET_NODES,        // 1: unused workspace rows cleared by hipMemsetAsync instead of zero_rows_kernel (graph probe only)
   OPT_BF16_PW_PLAIN,       // 0: plain-output bf16 pointwise launches on the two-per-CU instantiation (round-4 form)
+  OPT_PW_DIRECT,           // 0: fp32 pointwise GEMMs back on gemm_fast_kernel<1> (tests compare the two kernels)
+  OPT_PW_NT,               // fp32 pointwise GEMM: 1 / 0 = non-temporal / plain stores whatever the output size
   OPT_COUNT
 };
 bool opt_is_set(Opt o);
@@ -163,6 +165,9 @@ long opt_value(Opt o, long dflt);   // dflt when unset
 
 // gemm_fast.hip: register-prefetched kernel for plain aligned views (needs d->weight_image)
 int launch_gemm_fast(const unetpp_gemm_desc* d, hipStream_t st);
+// gemm_pw.hip: fp32 pointwise GEMM with the weights resident in LDS and the activations loaded straight into the MFMA
+// operand registers (fa = the descriptor's fast_args); returns 1 when the descriptor is not one it takes
+int launch_gemm_pw(const unetpp_gemm_desc* d, const struct FastArgs& fa, hipStream_t st);
 // gemm_wino.hip: Winograd F(2x2,3x3) kernel for taps == 9 without UNETPP_GEMM_DIRECT (needs its own weight image)
 bool wino_applies(const unetpp_gemm_desc* d);
 int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st, long* bn_rows);  // *bn_rows = rows of BatchNorm sums written, when per workgroup

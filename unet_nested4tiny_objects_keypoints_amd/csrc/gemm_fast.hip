@@ -406,6 +406,10 @@ int launch_gemm_fast(const unetpp_gemm_desc* d, hipStream_t st) {
   FastArgs a;
   if (!fast_args(d, a, KC) || d->weight_image == nullptr) return UNETPP_EINVAL;
   if (d->stats_partial != nullptr && d->n_out != 1) return UNETPP_EINVAL;
+  if (d->taps == 1) {  // plain aligned pointwise launches whose weights fit LDS: gemm_pw.hip
+    const int pw = launch_gemm_pw(d, a, st);
+    if (pw != 1) return pw;
+  }
   // persistent grid: at most 3 workgroups per CU (the kernel's LDS/VGPR budget), a multiple of 8
   const int cus = device_cu_count();
   if (cus <= 0) return UNETPP_ELAUNCH;
