@@ -439,6 +439,59 @@ def test_pointwise_direct_kernel(dev, case):
     assert (got - other).abs().max().item() <= 2e-6 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("case", [
+    # (B, H, W, cin, cout of the transposed convolution | [cin per x view], cout of a 1x1 convolution), target_blocks
+    (2, 16, 32, 64, 32, 256),        # level 0: one 64 x 128 block, eight pixel ranges per workgroup
+    (2, 16, 32, 64, 32, 3),          # three workgroups: uneven row shares
+    (1, 16, 16, 128, 64, 256),       # level 1: 2 x 2 blocks, two pixel ranges each
+    (1, 8, 8, 256, 128, 256),        # level 2: 16 blocks = two workgroup rows, one pixel range each
+    (1, 4, 12, 64, 32, 1024),        # more workgroups than image rows: empty pixel ranges contribute zeros
+    (2, 8, 16, [32, 32], 128, 256),  # 1x1 convolution over a virtual concatenation, plain dy view
+    (1, 8, 8, 64, 16, 256),          # N = 64: not a block shape of the kernel -> wgrad_dma_kernel<1>
+])
+def test_pointwise_wgrad_direct_kernel(dev, case):
+    """wgrad_pw.hip (both operands loaded straight into the MFMA operand registers, pixels as the contraction index)
+    against float64 autograd: transposed-convolution weight / bias gradients at the three block structures of the
+    network's levels, uneven and empty pixel ranges, and a 1x1 convolution over two x views."""
+    from unet_nested4tiny_objects_keypoints_amd import _lib, engine, ops
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    b, h, w, ci, co, target_blocks = case
+    g = torch.Generator().manual_seed(17)
+    if isinstance(ci, list):
+        xs = [torch.randn(b, c, h, w, generator=g, dtype=torch.float64) for c in ci]
+        wt = torch.randn(co, sum(ci), 1, 1, generator=g, dtype=torch.float64, requires_grad=True)
+        bias = torch.zeros(co, dtype=torch.float64, requires_grad=True)
+        dy = torch.randn(b, co, h, w, generator=g, dtype=torch.float64)
+        F.conv2d(torch.cat(xs, 1), wt, bias).backward(dy)
+        dw, db = torch.empty(co, sum(ci), 1, 1, device=dev), torch.empty(co, device=dev)
+        ops.wgrad(b, h, w, 1, [V(nhwc(x.float())) for x in xs], [V(nhwc(dy.float()))], dw, (0, 1, sum(ci), 0), db,
+                  target_blocks=target_blocks)
+        k, n = sum(ci), co
+    else:
+        x = torch.randn(b, ci, h, w, generator=g, dtype=torch.float64)
+        wt = torch.randn(ci, co, 2, 2, generator=g, dtype=torch.float64, requires_grad=True)
+        bias = torch.zeros(co, dtype=torch.float64, requires_grad=True)
+        dy = torch.randn(b, co, 2 * h, 2 * w, generator=g, dtype=torch.float64)
+        F.conv_transpose2d(x, wt, bias, stride=2).backward(dy)
+        dw, db = torch.empty(ci, co, 2, 2, device=dev), torch.empty(co, device=dev)
+        ops.wgrad(b, h, w, 1, [V(nhwc(x.float()))], engine._phase_views(nhwc(dy.float())), dw, (0, 4 * co, 4, 1), db,
+                  n_inner=co, target_blocks=target_blocks)
+        k, n = ci, 4 * co
+    name = _lib.lib().unetpp_last_kernel_name().decode()
+    assert name == ("wgrad_pw_kernel" if (k % 64 == 0 and n % 128 == 0) else "wgrad_dma_kernel<1>"), name
+    assert rel_err(dw.cpu(), wt.grad.float()) < TOL
+    assert rel_err(db.cpu(), bias.grad.float()) < TOL
+    with _lib.debug_switch("PW_DIRECT", 0):   # the LDS-staged kernel on the same operands: same sums up to their order
+        dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
+        if isinstance(ci, list):
+            ops.wgrad(b, h, w, 1, [V(nhwc(x.float())) for x in xs], [V(nhwc(dy.float()))], dw2, (0, 1, sum(ci), 0), db2)
+        else:
+            ops.wgrad(b, h, w, 1, [V(nhwc(x.float()))], engine._phase_views(nhwc(dy.float())), dw2, (0, 4 * co, 4, 1), db2, n_inner=co)
+        assert _lib.lib().unetpp_last_kernel_name().decode() == "wgrad_dma_kernel<1>"
+    assert (dw - dw2).abs().max().item() <= 2e-5 * wt.grad.abs().max().item()
+    assert (db - db2).abs().max().item() <= 2e-5 * bias.grad.abs().max().item()
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, [8], 8), (1, 32, 32, [32, 32, 32], 32), (2, 24, 40, [3], 4),
                                    (1, 8, 8, [40, 5], 33), (3, 64, 64, [16], 16), (2, 32, 64, [1], 32),
                                    (1, 24, 40, [3], 8)])

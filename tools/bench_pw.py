@@ -57,7 +57,7 @@ for i in range(3):
                                                                 [V(dx, accumulate=True, gate=gt, gate_sum=True)], wd)
                       for _, up, dx, gt in sets])
     dw, db = torch.empty_like(w), torch.empty_like(bias)
-    # the weight gradient (a finish launch follows the main one: the timer reports them under the main kernel's name)
+    # the weight gradient: main launch (ops.LaunchTimer) and the whole call with its finish launch (events around it)
     tw = ops.LaunchTimer()
     tw.want_regions = False
     for x, up, _, _ in sets:
@@ -72,9 +72,20 @@ for i in range(3):
     lw, _ = tw.summary()
     t_w = 1e3 * sum(d["ms"] for d in lw.values()) / REPS
     n_w = "+".join(lw.keys())
+    pairs = []
+    for r in range(REPS):
+        x, up, _, _ = sets[r % SETS]
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        ops.wgrad(B, hw, hw, 1, [V(x)], engine._phase_views(up), dw, (0, 4 * co, 4, 1), db, n_inner=co)
+        s1.record()
+        pairs.append((s0, s1))
+    torch.cuda.synchronize()
+    t_wf = 1e3 * sum(a.elapsed_time(b) for a, b in pairs) / REPS
+    n_w += " (+finish %.1f)" % t_wf
     print("%-8s %5d %5d %5d | %-22s %9.1f %7.2f | %-22s %9.1f %7.2f | %-22s %9.1f" % (
         "level %d" % i, hw, ci, co, n_f, t_f, byts / t_f * 1e-6, n_d, t_d, (byts + 8.0 * B * hw * hw * ci) / t_d * 1e-6, n_w, t_w))
-    for k, v in enumerate((t_f, t_d, t_w)):
+    for k, v in enumerate((t_f, t_d, t_wf)):
         tot[k] += v * (3 - i)  # launches per step: three transposed convolutions at level 0, two at level 1, one at level 2
     del sets
     torch.cuda.empty_cache()

@@ -184,6 +184,10 @@ bool wgrad_bf16_quads(const unetpp_wgrad_desc* d);  // the bf16 kernel will give
 int launch_wgrad_fast(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_tiles_cols, int k_tiles, hipStream_t st);
 // wgrad_dma.hip: LDS-DMA staged kernel for views without load transforms; returns 1 when it does not apply
 int launch_wgrad_dma(const unetpp_wgrad_desc* d, int Ktot, int Ncols, int n_tiles_cols, int k_tiles, hipStream_t st);
+// wgrad_pw.hip: pointwise fp32 weight gradient with both operands loaded straight into the MFMA operand registers (64-channel
+// x 128-column blocks of dW per wave); launch returns 1 when it does not apply, wgrad_pw_pairs 0
+int wgrad_pw_pairs(const unetpp_wgrad_desc* d);
+int launch_wgrad_pw(const unetpp_wgrad_desc* d, hipStream_t st);
 // wgrad_wino.hip: Winograd F(2x2,3x3) weight gradient (16 transform-domain planes per slab); launch returns 1 when
 // it does not apply
 bool wgrad_wino_applies(const unetpp_wgrad_desc* d);

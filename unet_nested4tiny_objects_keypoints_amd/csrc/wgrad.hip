@@ -315,6 +315,8 @@ extern "C" int32_t unetpp_wgrad_slab_planes(const unetpp_wgrad_desc* d) {
 
 extern "C" int32_t unetpp_wgrad_pairs_per_workgroup(const unetpp_wgrad_desc* d) {
   if (d == nullptr) return 0;
+  const int pw = wgrad_pw_pairs(d);
+  if (pw > 0) return pw;
   return wgrad_bf16_quads(d) ? 4 : 1;
 }
 
@@ -352,6 +354,10 @@ extern "C" int unetpp_wgrad(const unetpp_wgrad_desc* d, void* stream) {
   const int small = launch_small_cin_wgrad(d, st);  // 1..4-channel first layer
   if (small != 1) return small;
   if (d->flags & UNETPP_GEMM_BF16) return launch_wgrad_bf16(d, a.Ktot, a.Ncols, a.n_tiles_cols, k_tiles, st);
+  {
+    const int pw = launch_wgrad_pw(d, st);  // plain pointwise launches in 64 x 128 blocks: operands straight into registers
+    if (pw != 1) return pw;
+  }
   {
     const int wino = launch_wgrad_wino(d, a.Ktot, a.Ncols, a.n_tiles_cols, k_tiles, st);  // 16-plane slabs
     if (wino != 1) return wino;
