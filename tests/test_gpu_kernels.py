@@ -366,6 +366,9 @@ def test_pointwise_fast_and_generic_agree(dev, shape, mode):
     (2, 16, 32, [64], [64], "accumulate"),
     (1, 16, 16, [32], [32], "sliced"),
     (1, 64, 64, [256], [128], "plain"),               # 128 KB image, one workgroup of sixteen waves per CU
+    (1, 8, 16, [256], [128] * 4, "deconv_fwd"),       # level 2: K 256, N 512 = 512 KB of weights: beyond the LDS -> gemm_fast
+    (1, 8, 16, [128] * 4, [256], "deconv_dgrad"),     # K 512, N 256: the same
+    (2, 16, 16, [64], [192], "relu"),                 # 12 column blocks: no block count of the kernel -> gemm_fast
 ])
 def test_pointwise_direct_kernel(dev, case):
     """gemm_pw.hip (weights resident in LDS, activations loaded straight into the MFMA operand registers, register-direct
@@ -431,7 +434,7 @@ def test_pointwise_direct_kernel(dev, case):
     name = _lib.lib().unetpp_last_kernel_name().decode()
     def blocks_ok(c):
         return (c // 16) in (1, 2, 4, 8) or (c // 16) % 8 == 0
-    takes = blocks_ok(ci) and blocks_ok(co)
+    takes = blocks_ok(ci) and blocks_ok(co) and (ci * co + co) * 4 <= 148 * 1024
     assert name == ("gemm_pw_kernel" if takes else "gemm_fast_kernel<1>"), name
     assert rel_err(got, ref.float()) < TOL
     other, _ = run(False)

@@ -250,6 +250,9 @@ int launch_gemm_pw(const unetpp_gemm_desc* d, const FastArgs& fa, hipStream_t st
   const int qc = block_count(a.K >> 4), ncbp = block_count(a.N >> 4);
   if (qc == 0 || ncbp == 0) return 1;
   const size_t lds_bytes = (static_cast<size_t>(a.K) * a.N + a.N) * sizeof(float);
+  // (Weights beyond the LDS -- level 2 of the base-32 network: 512 KB -- were tried as column groups, one 128 KB group per
+  // workgroup of sixteen waves: 139 / 147 us against gemm_fast_kernel<1>'s 112 / 122, profiles/r6/bench_pw_column_groups.txt:
+  // two tiles per wave do not pay for staging the group.)
   if (lds_bytes > 148 * 1024) return 1;
   a.n_kchunk = (a.K >> 4) / qc;
   a.n_pass = (a.N >> 4) / ncbp;
