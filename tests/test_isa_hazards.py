@@ -47,6 +47,21 @@ def test_no_kernel_spills_vector_registers_or_uses_scratch():
     assert not bad, bad
 
 
+def test_every_ablation_build_keeps_the_matrix_work_it_claims_to_keep():
+    """tools/ablation_audit.py over every experiment switch of the kernel sources (UNETPP_*_EXP_*: the seams
+    wino_experiments.h / dma_experiments.h and the switches still inline in gemm_bf16.hip, wgrad_bf16.hip, wgrad_wino.hip):
+    each variant compiles, and a variant that is not named NO_MFMA / NO_COMPUTE has the v_mfma count of the normal build.
+    Rounds 3-4 drew conclusions from a "no epilogue" build whose MFMAs hipcc had deleted as dead code."""
+    import ablation_audit
+
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    lines, bad, broken = ablation_audit.audit()
+    assert len(lines) >= 25, lines
+    assert not broken, broken
+    assert not bad, bad
+
+
 def test_checker_sees_a_hazard_across_a_loop_back_edge(tmp_path):
     """The checker's own known-answer test: an inline-asm packed add at the TOP of a loop that overwrites the C operand
     of the MFMA at the BOTTOM of the previous iteration is only visible when the back edge is followed; an s_waitcnt

@@ -17,6 +17,7 @@ CSRC = os.path.join(ROOT, "unet_nested4tiny_objects_keypoints_amd", "csrc")
 SLP_OFF = {"gemm_wino.hip", "wgrad_wino.hip"}
 NEEDS = {"UNETPP_WINO_EXP_": ["UNETPP_WINO_EXP"]}   # variants that only exist under an umbrella macro
 WANT_FEWER_MFMA = ("NO_MFMA", "NO_COMPUTE")
+SEAMS = {"wino_experiments.h": "gemm_wino.hip", "dma_experiments.h": "gemm_bf16_dma.hip"}  # switches kept in a header of their own
 
 
 def counts(path, defines):
@@ -37,35 +38,46 @@ def counts(path, defines):
             "ds_read": len(re.findall(r"\bds_read", text))}
 
 
-def main():
-    jobs = []
+def audit(workers=8):
+    """-> (report lines, variants that silently lose MFMAs, variants that do not compile)"""
+    per_source = {}
     for f in sorted(os.listdir(CSRC)):
-        if not f.endswith(".hip"):
+        if not (f.endswith(".hip") or f in SEAMS):
             continue
         src = open(os.path.join(CSRC, f)).read()
-        macros = sorted(set(re.findall(r"UNETPP_[A-Z0-9_]*EXP_[A-Z0-9_]+", src)))
+        macros = set(re.findall(r"#\s*(?:el)?if(?:n?def| defined\()?\s*\(?(UNETPP_[A-Z0-9_]*EXP_[A-Z0-9_]+)", src))
         if macros:
-            jobs.append((f, []))
-            for m in macros:
-                extra = [u for k, us in NEEDS.items() if m.startswith(k) for u in us]
-                jobs.append((f, extra + [m]))
-    with ThreadPoolExecutor(max_workers=6) as ex:
+            per_source.setdefault(SEAMS.get(f, f), set()).update(macros)
+    jobs = []
+    for f, macros in sorted(per_source.items()):
+        jobs.append((f, []))
+        for m in sorted(macros):
+            extra = [u for k, us in NEEDS.items() if m.startswith(k) for u in us]
+            jobs.append((f, extra + [m]))
+    with ThreadPoolExecutor(max_workers=workers) as ex:
         res = list(ex.map(lambda j: counts(os.path.join(CSRC, j[0]), j[1]), jobs))
-    base, bad = {}, 0
+    base, bad, broken, lines = {}, [], [], []
     for (f, d), c in zip(jobs, res):
         if not d:
             base[f] = c
         name = d[-1] if d else "(normal build)"
         if c is None:
-            print("%-22s %-34s does not compile" % (f, name))
+            lines.append("%-22s %-34s does not compile" % (f, name))
+            broken.append((f, name))
             continue
         note = ""
         if d and c["mfma"] < base[f]["mfma"] and not any(w in name for w in WANT_FEWER_MFMA):
             note = "   <-- MFMAs removed although the variant does not say so"
-            bad += 1
-        print("%-22s %-34s v_mfma %5d  stores %4d  lds-dma %4d  ds_read %5d%s" % (f, name, c["mfma"], c["store"], c["dma"], c["ds_read"], note))
-    print("variants that silently lose MFMAs:", bad)
-    return 1 if bad else 0
+            bad.append((f, name))
+        lines.append("%-22s %-34s v_mfma %5d  stores %4d  lds-dma %4d  ds_read %5d%s" % (f, name, c["mfma"], c["store"], c["dma"], c["ds_read"], note))
+    return lines, bad, broken
+
+
+def main():
+    lines, bad, broken = audit()
+    print("\n".join(lines))
+    print("variants that silently lose MFMAs:", len(bad), " variants that do not compile:", len(broken))
+    return 1 if (bad or broken) else 0
 
 
 if __name__ == "__main__":

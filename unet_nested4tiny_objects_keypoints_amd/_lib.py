@@ -16,7 +16,8 @@ LIB_PATH = os.environ.get("UNETPP_LIB", os.path.join(_PKG_DIR, "libunetpp_hip.so
 CSRC = os.path.join(_PKG_DIR, "csrc")
 INCLUDE = os.path.join(_REPO, "include")
 SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_pw.hip", "gemm_wino.hip", "gemm_bf16.hip", "gemm_bf16_dma.hip", "wgrad_bf16.hip", "pointwise_bf16.hip", "keypoints.hip", "weight_image.hip", "wgrad.hip", "wgrad_fast.hip", "wgrad_dma.hip", "wgrad_pw.hip", "wgrad_wino.hip", "first_layer.hip", "pointwise.hip", "caller.hip")
-HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h", "lds_asm.h", "bf16_common.h", "dropout.h", "bn_fused.h")
+HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h", "lds_asm.h", "bf16_common.h", "dropout.h", "bn_fused.h",
+           "wino_experiments.h", "dma_experiments.h")
 MAX_VIEWS = 8
 ABI_VERSION = 9
 # packed-f32 VALU (SLP-vectorised add pairs) costs issue slots beside MFMAs: keep the Winograd transforms scalar

@@ -55,6 +55,7 @@
 #include "common.h"
 #include "gemm_units.h"
 #include "lds_asm.h"
+#include "dma_experiments.h"
 
 namespace unetpp {
 namespace {
@@ -262,9 +263,7 @@ __global__ __launch_bounds__(64 * WAVES, RMW ? 2 : 3) void gemm_bf16_dma_kernel(
   };
   auto dma_chunk = [&](int in_buf, int w_buf, bool need_in, bool need_w) {
     unsigned char* in_dst = smem + in_buf * IN_BYTES;
-#ifdef UNETPP_DMA_EXP_NO_INDMA
-    need_in = false;
-#endif
+    if constexpr (dma_exp::kNoInDma) need_in = false;  // (ablation builds: dma_experiments.h)
     if (need_in) {  // uniform
     const unetpp_view& V = d.in[p_s];
     const __amdgpu_buffer_rsrc_t rsrc =
@@ -276,11 +275,8 @@ __global__ __launch_bounds__(64 * WAVES, RMW ? 2 : 3) void gemm_bf16_dma_kernel(
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (dma_lptr_t)(in_dst + blk * 1024), 16, static_cast<int>(voff[q]), soff, 0, 0);
     }
     }
-#if defined(UNETPP_DMA_EXP_NO_WDMA)        // (timing experiments: what the weight bytes cost a CU's memory path)
-    need_w = false;
-#elif defined(UNETPP_DMA_EXP_HALF_WDMA)
-    need_w = need_w && (p_chunk & 1) == 0;
-#endif
+    if constexpr (dma_exp::kNoWDma) need_w = false;
+    if constexpr (dma_exp::kHalfWDma) need_w = need_w && (p_chunk & 1) == 0;
     if (need_w) dma_weights(w_buf, p_wimg, p_chunk);
   };
   // next chunk of the unit, or chunk 0 of the next unit; false when nothing is left
@@ -538,13 +534,13 @@ __global__ __launch_bounds__(64 * WAVES, RMW ? 2 : 3) void gemm_bf16_dma_kernel(
             }
             out = pack8(v);
           }
-#if defined(UNETPP_DMA_EXP_NO_STORE)    // timing only: the whole epilogue (accumulators reset, values packed) without its stores
-          asm volatile("" ::"v"(out), "v"(optr + pbase + c0));
-#elif defined(UNETPP_DMA_EXP_STORE_LINEAR)   // timing only: every store instruction writes 1 KB contiguous (wrong layout)
-          if (pix_ok && c0 < tc.n_cnt) *reinterpret_cast<u32x4*>(optr + tile_base + ((wave * 4 + mt * 2 + half) * 64 + lane) * 8) = out;
-#else
-          if (pix_ok && c0 < tc.n_cnt) *reinterpret_cast<u32x4*>(optr + pbase + c0) = out;
-#endif
+          if constexpr (dma_exp::kNoStore) {
+            asm volatile("" ::"v"(out), "v"(optr + pbase + c0));
+          } else if constexpr (dma_exp::kStoreLinear) {
+            if (pix_ok && c0 < tc.n_cnt) *reinterpret_cast<u32x4*>(optr + tile_base + ((wave * 4 + mt * 2 + half) * 64 + lane) * 8) = out;
+          } else {
+            if (pix_ok && c0 < tc.n_cnt) *reinterpret_cast<u32x4*>(optr + pbase + c0) = out;
+          }
         }
       }
     }
@@ -596,9 +592,8 @@ __global__ __launch_bounds__(64 * WAVES, RMW ? 2 : 3) void gemm_bf16_dma_kernel(
       constexpr int step = decltype(sc)::v, cs = step & 1, ns = cs ^ 1;
       if constexpr (step + 1 < TAPS * 2) issue_frag(IC<step + 1>{}, fr[ns], in_base, w_base);
       __builtin_amdgcn_sched_barrier(0);
-#ifndef UNETPP_DMA_EXP_NO_MFMA   // (UNETPP_DMA_EXP_*: timing experiments of tools/bf16_dma_ablation.sh, wrong results)
 #pragma unroll
-      for (int ct = 0; ct < NT; ++ct) {
+      for (int ct = 0; ct < (dma_exp::kNoMfma ? 0 : NT); ++ct) {
         if constexpr (STATS) {
           acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fr[cs].a0),
                                                                __builtin_bit_cast(bf16x8, fr[cs].b[ct]), acc[ct][0], 0, 0, 0);
@@ -611,7 +606,6 @@ __global__ __launch_bounds__(64 * WAVES, RMW ? 2 : 3) void gemm_bf16_dma_kernel(
                                                                __builtin_bit_cast(bf16x8, fr[cs].a1), acc[ct][1], 0, 0, 0);
         }
       }
-#endif
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (step + 1 < TAPS * 2) wait_frag(fr[ns]);
     });
@@ -638,20 +632,20 @@ __global__ __launch_bounds__(64 * WAVES, RMW ? 2 : 3) void gemm_bf16_dma_kernel(
         __syncthreads();  // the transposing epilogue uses the buffer just computed from as scratch: all waves are done with it
         epilogue_stats(smem + in_cur * IN_BYTES);
       } else {
-#ifndef UNETPP_DMA_EXP_NO_EPI
-        epilogue_direct();
-#else   // timing only.  The accumulators must stay live: until round 5 this variant dropped the call and nothing else, hipcc
-        // then deleted every MFMA of the kernel as dead code, and the "epilogue share" read off it (33-48 %) was the
-        // epilogue AND the matrix phase (profiles/r5/ablation_gemm_bf16_dma_stores_c5.txt has the corrected table)
+        if constexpr (!dma_exp::kNoEpi) {
+          epilogue_direct();
+        } else {  // The accumulators must stay live: until round 5 this variant dropped the call and nothing else, hipcc
+          // then deleted every MFMA of the kernel as dead code, and the "epilogue share" read off it (33-48 %) was the
+          // epilogue AND the matrix phase (profiles/r5/ablation_gemm_bf16_dma_stores_c5.txt has the corrected table)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+          for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
-            asm volatile("" : "+v"(acc[t][mt]));
+            for (int mt = 0; mt < 2; ++mt) {
+              asm volatile("" : "+v"(acc[t][mt]));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][mt][r] = 0.f;
-          }
-#endif
+              for (int r = 0; r < 16; ++r) acc[t][mt][r] = 0.f;
+            }
+        }
       }
       step_unit(c_ug, c_index);
       c_chunk = 0;

@@ -40,6 +40,7 @@
 #include "common.h"
 #include "gemm_units.h"
 #include "lds_asm.h"
+#include "wino_experiments.h"
 
 namespace unetpp {
 namespace {
@@ -97,13 +98,7 @@ constexpr int WIMG = 4096;  // floats of one (column tile, chunk) weight image
 
 // In-kernel phase stamps (profiling builds only: -DUNETPP_WINO_STAMPS, see tools/wino_stamps.py): every wave adds the
 // s_memtime cycles it spent in each phase of its (unit, chunk) stream to a global table.
-#ifdef UNETPP_WINO_NO_FENCE  // A/B switch: leave the placement of the LDS reads to the scheduler
-#define WINO_FENCE() \
-  do {               \
-  } while (0)
-#else
 #define WINO_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 #ifdef UNETPP_WINO_STAMPS
 __device__ unsigned long long g_wino_stamps[16];
 #define WINO_STAMP(i)                          \
@@ -211,10 +206,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       v_bytes = d.N * V.Hs * V.Ws * V.C * 4;  // <= 2 GB (launcher)
       v_pitch = V.C * 4;
       v_origin = V.c_off * 4;
-#ifdef UNETPP_WINO_EXP_DENSE  // experiment: 32-byte pixel pitch = every fetched cache line is used completely (wrong data)
-      v_pitch = 32;
-      v_origin = 0;
-#endif
       if constexpr (FOLD) {
         v_scale = V.scale;
         v_shift = V.shift;
@@ -295,12 +286,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     if constexpr (LEAN) {  // byte offsets; padding pixels and the dummy items of the last pass are out of range = zeros
 #pragma unroll
       for (int q = 0; q < IN_ITEMS; ++q)
-#ifdef UNETPP_WINO_EXP_SAME_LINE  // experiment: every load of the launch hits the same few cache lines
-        voff[q] = static_cast<unsigned>(cc * 4 + (pix[q] & 1) * 32);
-#else
         voff[q] = static_cast<unsigned>(pix[q] * v_pitch + v_origin + cc * 4) |
                   (static_cast<unsigned>(pix[q] >> 31) & kOutOfRange);  // arithmetic on purpose: see prefetch_unit
-#endif
       return;
     }
 #pragma unroll
@@ -456,13 +443,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) s1[nh][rr] = s2[nh][rr] = 0.f;
     // bias folded into M[1][1]: its weight is +1 in all four outputs
-#ifndef UNETPP_WINO_EXP_GLOBAL_BIAS
     if (d.bias != nullptr && tc.n0 + WNC <= kBiasCols) {  // uniform; n0 is a multiple of 4 (fast_args)
 #pragma unroll
       for (int nh = 0; nh < NH; ++nh) acc[5][nh] += *reinterpret_cast<const f32x4*>(&bias_lds[tc.n0 + 16 * nh + 4 * g]);
-    } else
-#endif
-    if (d.bias != nullptr) {
+    } else if (d.bias != nullptr) {
 #pragma unroll
       for (int nh = 0; nh < NH; ++nh)
 #pragma unroll
@@ -644,25 +628,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 
   int c_chunk = 0, c_unit = 0;  // compute side: chunk of unit c_ug currently in LDS
   int cur = 0;                  // buffer being computed from
-#ifdef UNETPP_WINO_STAGGER
-  // experiment (tools/ab_multi.sh): the two workgroups of a CU run the same program on equal units from the same start, so
-  // their staging / barrier / epilogue phases can coincide; one of the two starts N x 1024 cycles late.  Which two share
-  // a CU is not defined by HIP: UNETPP_WINO_STAGGER_BY = 0 second half of the grid, 1 every other block of an XCD
-  // (blocks b and b + 8 share an XCD), 2 the parity of the hardware wave slot (HW_REG_HW_ID[3:0]: the first workgroup of
-  // a SIMD sits in slot 0, the second in slot 1)
-#ifndef UNETPP_WINO_STAGGER_BY
-#define UNETPP_WINO_STAGGER_BY 0
-#endif
-  {
-    bool late;
-    if (UNETPP_WINO_STAGGER_BY == 0) late = blockIdx.x >= (gridDim.x >> 1);
-    else if (UNETPP_WINO_STAGGER_BY == 1) late = ((blockIdx.x >> 3) & 1) != 0;
-    else late = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) != 0;
-    if (late) {
-      for (int i = 0; i < UNETPP_WINO_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
-    }
-  }
-#endif
   while (true) {
     // ---- this chunk's first LDS operands are requested before the staging work below, which covers their latency
     const unsigned in_b = lds_offset(in_tile) + a_base * 4, w_b = lds_offset(w_tile) + b_base * 4;
@@ -707,23 +672,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     auto staging_piece = [&](auto gc) {
       constexpr int g = decltype(gc)::v;
       if constexpr (!LEAN) return;
-#ifdef UNETPP_WINO_EXP_NO_STAGING
-      if constexpr (g == 2) advance();
-#else
-#ifndef UNETPP_WINO_EXP_NO_STORE
-      if constexpr (g == 0) store_chunk(other);
-#endif
-#ifndef UNETPP_WINO_EXP_NO_DMA
-      if constexpr (g == 0) dma_weights(other + IN_FLOATS, dma_source());
-#endif
+      if constexpr (wino_exp::kNoStaging) {  // (ablation builds: wino_experiments.h)
+        if constexpr (g == 2) advance();
+        return;
+      }
+      if constexpr (g == 0 && !wino_exp::kNoStore) store_chunk(other);
+      if constexpr (g == 0 && !wino_exp::kNoDma) dma_weights(other + IN_FLOATS, dma_source());
       if constexpr (g == 1) {
         advance();
         load_coeffs();
       }
-#ifndef UNETPP_WINO_EXP_NO_LOADS
-      if constexpr (g == 2) load_inputs();
-#endif
-#endif
+      if constexpr (g == 2 && !wino_exp::kNoLoads) load_inputs();
     };
 
     // ---- per channel s the 4x4 window -> B^T d B in registers -> 32 MFMAs; every accumulator is touched once per
@@ -733,12 +692,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     if constexpr (LEAN) {
       lds_wait8x2(dp);
       lds_wait(us[0][0], us[0][1]);
-#ifdef UNETPP_WINO_EXP_NO_XFORM   // inner-loop ablation: the window values go to the MFMAs untransformed (wrong results)
-#pragma unroll
-      for (int k = 0; k < 16; ++k) V[k] = dp[k >> 1][k & 1];
-#else
       wino_input_transform_pk(dp, V);
-#endif
     } else {
       lds_wait16(dd);
       lds_wait(us[0][0], us[0][1]);
@@ -747,25 +701,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     static_for<8>([&](auto gc) {  // group g = steps 4g .. 4g+3 of the chunk's 32 ([s][xi]); 8 MFMAs each
       constexpr int g = decltype(gc)::v, cs = g & 1, ns = cs ^ 1;
       if constexpr (g + 1 < 8) {
-#ifdef UNETPP_WINO_EXP_NO_WREAD   // inner-loop ablation: the first group's weight fragments for every group (wrong results)
-        us[ns][0] = us[cs][0];
-        us[ns][1] = us[cs][1];
-#else
         lds_read2st64_b64<4 * (g + 1), 4 * (g + 1) + 1>(us[ns][0], w_b);
         lds_read2st64_b64<4 * (g + 1) + 2, 4 * (g + 1) + 3>(us[ns][1], w_b);
-#endif
       }
       if constexpr (g == 0) {  // the second channel's window, needed from group 4 on
         if constexpr (LEAN) {
-#ifdef UNETPP_WINO_EXP_NO_INREAD   // inner-loop ablation: the first channel's window again (wrong results)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) dpn[e] = dp[e];
-#else
           static_for<8>([&](auto ic) {
             constexpr int e = decltype(ic)::v, j = 2 * (e & 1);
             lds_read2_b32<j * WP + 1, (j + 1) * WP + 1>(dpn[e], row_b[e >> 1]);
           });
-#endif
         } else {
           static_for<16>([&](auto ic) {
             constexpr int e = decltype(ic)::v;
@@ -793,40 +737,24 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       if constexpr (g + 1 < 8) lds_wait(us[ns][0], us[ns][1]);
       if constexpr (g == 3) {
         WINO_STAMP(2);  // 2: first half of the MFMA phase
-#ifdef UNETPP_WINO_EXP_NO_XFORM
-        if constexpr (LEAN) {
-#pragma unroll
-          for (int k = 0; k < 16; ++k) V[k] = dpn[k >> 1][k & 1];
-        } else
-#else
         if constexpr (LEAN) wino_input_transform_pk(dpn, V);
-        else
-#endif
-          wino_input_transform(ddn, V);  // (inside group 4's fences it interleaves with the MFMAs, and is 1 % slower)
+        else wino_input_transform(ddn, V);  // (inside group 4's fences it interleaves with the MFMAs, and is 1 % slower)
       }
     });
     __builtin_amdgcn_s_setprio(0);
     WINO_STAMP(4);  // 4: second half of the MFMA phase
-#ifndef UNETPP_WINO_EXP_NO_BARRIER
-#ifndef UNETPP_WINO_FENCED_BARRIER   // (-DUNETPP_WINO_FENCED_BARRIER: the __syncthreads() form of rounds 1-4, for A/B runs)
-    // Raw barrier (round 5: 19.765 -> 19.715 ms per step, same box, alternating; profiles/r5/ab_wino_raw_barrier.txt).  __syncthreads() carries a workgroup fence for which hipcc emits `s_waitcnt vmcnt(0) lgkmcnt(0)` in
+    // Raw barrier: __syncthreads() carries a workgroup fence for which hipcc emits `s_waitcnt vmcnt(0) lgkmcnt(0)` in
     // front of the s_barrier of THIS loop (the epilogue's global stores of an earlier iteration may be outstanding): that
     // also drains the three input loads of the chunk after next, which were requested in MFMA group 2 of this very chunk
     // precisely so that they would have more than a chunk to arrive (and which the explicit vmcnt(IN_ITEMS) leaves in
     // flight).  What the barrier has to order is complete in every wave without it: its fragment reads of the current
     // buffers and its staging stores (lgkmcnt(0)), its share of the next weight image (vmcnt(IN_ITEMS)).
-#ifdef UNETPP_WINO_EXP_NO_DMA_WAIT  // experiment: the barrier does not wait for this chunk's weight DMA (wrong results)
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(IN_ITEMS + W_ITEMS) : "memory");
-#else
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(IN_ITEMS) : "memory");
-#endif
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#else
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_ITEMS) : "memory");  // this wave's share of the next weight image is in
-    __syncthreads();  // all waves: done reading the current buffers, next buffers written
-#endif
-#endif
+    // (round 5: 19.765 -> 19.715 ms per step against the __syncthreads() form, profiles/r5/ab_wino_raw_barrier.txt)
+    if constexpr (!wino_exp::kNoBarrier) {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(IN_ITEMS) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
     WINO_STAMP(5);  // 5: barrier
     if (c_chunk + 1 == a.n_chunks) {
       // Collect the prefetched inputs BEFORE the epilogue issues its stores: vmcnt counts in order, so a wait for
@@ -834,17 +762,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
       // for the unit's stores to reach memory.  The loads are a whole MFMA phase old here.
 #pragma unroll
       for (int q = 0; q < IN_ITEMS; ++q) asm volatile("" : "+v"(reg_in[q]));
-#ifdef UNETPP_WINO_EXP_NO_EPILOGUE  // experiment builds only (tools/README.md): where does a unit's time go
+      if constexpr (wino_exp::kNoEpilogue) {  // (ablation builds: the accumulators stay live, nothing else happens)
 #pragma unroll
-      for (int xi = 0; xi < 16; ++xi)
+        for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
-        for (int nh = 0; nh < NH; ++nh) {
-          asm volatile("" : "+v"(acc[xi][nh]));
-          acc[xi][nh] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#else
-      epilogue();  // stores drain while the next unit computes
-#endif
+          for (int nh = 0; nh < NH; ++nh) {
+            asm volatile("" : "+v"(acc[xi][nh]));
+            acc[xi][nh] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      } else {
+        epilogue();  // stores drain while the next unit computes
+      }
       WINO_STAMP(6);  // 6: epilogue
       if (d.stats_partial != nullptr) {  // uniform: the per-wave sums are in LDS; the next epilogue is a chunk barrier away
         __syncthreads();
