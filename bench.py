@@ -369,6 +369,12 @@ OTHER_CONFIGS = (
 )
 
 
+# Per-GPU batches beside the continuity entries above (BASELINE names no batch for these two configurations): short
+# untimed-kernel runs (no launch events) whose value / ms_per_step / peak memory go under `batch_sweep` of the entry
+BATCH_SWEEP = {0: (16,), 1: (8, 16)}
+HBM_GB = 288.0
+
+
 def is_headline(args):
     """the default workload (configs[1]); runs with other shapes asked for on the command line stay single-config"""
     return (args.dtype, args.size, args.batch, float(args.feature_scale), args.depth, args.in_channels, args.n_classes) == \
@@ -394,7 +400,7 @@ def other_entry(name, o, r, world):
     if kern is not None:  # the five kernels with the most device time
         kern = dict(sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])[:5])
     return {"config": name, "workload": workload_name(o), "dtype": o.dtype, "value": round(r["value"], 2),
-            "unit": "images/sec", "n_gpus": world, "steps": o.steps, "warmup": o.warmup, "prewarm_steps": o.prewarm,
+            "peak_mem_gb": r["peak_mem_gb"], "unit": "images/sec", "n_gpus": world, "steps": o.steps, "warmup": o.warmup, "prewarm_steps": o.prewarm,
             "step_runner": r["step_runner"], "ms_per_step": round(r["ms_per_step"], 3), "host_enqueue_ms_median": r["host_enqueue_ms"], "fwd_ms_per_img": round(r["fwd_ms_per_img"], 4),
             "per_gpu_batch": o.batch, "global_batch": world * o.batch, "roofline": roof, "kernels": kern,
             "replicas_bit_identical": r["replicas_identical"]}
@@ -409,6 +415,7 @@ def measure(args, ctx):
 
     n_cls = args.n_classes
     fs = int(args.feature_scale) if float(args.feature_scale).is_integer() else args.feature_scale
+    torch.cuda.reset_peak_memory_stats(dev)
     torch.manual_seed(0)
     model = UNet_Nested(in_channels=args.in_channels, n_classes=n_cls, feature_scale=fs, depth=args.depth).to(dev).train()
     if args.dtype == "bf16":
@@ -517,6 +524,7 @@ def measure(args, ctx):
         fwd_ms_per_img = 1e3 * (time.perf_counter() - t1) / (reps * args.batch)
     model.train()
 
+    peak_mem_gb = torch.cuda.max_memory_allocated(dev) / 1e9
     dp_info = None if averager is None else {"grad_allreduce_buckets": len(averager.buckets_last_step),
                                              "grad_bucket_bytes": averager.bucket_bytes,
                                              "gradient_bytes": 4 * averager.flat.numel()}
@@ -591,9 +599,46 @@ def measure(args, ctx):
                             "us_per_img": round(t_img_us, 2), "floor_compute_us": round(floor_c, 2),
                             "floor_hbm_us": round(floor_h, 2), "bound": "mfma" if floor_c >= floor_h else "hbm",
                             "frac": round(max(floor_c, floor_h) / t_img_us, 4)}
-    return {"step_runner": "hip_graph" if graphed else "eager", "host_enqueue_ms": round(sorted(host_ms)[len(host_ms) // 2], 3), "value": value, "ms_per_step": ms_per_step, "fwd_ms_per_img": fwd_ms_per_img, "roofline": roofline,
+    return {"peak_mem_gb": round(peak_mem_gb, 2), "step_runner": "hip_graph" if graphed else "eager", "host_enqueue_ms": round(sorted(host_ms)[len(host_ms) // 2], 3), "value": value, "ms_per_step": ms_per_step, "fwd_ms_per_img": fwd_ms_per_img, "roofline": roofline,
             "roofline_x00": roofline_x00, "kernels": kernels, "dp": dp_info,
             "replicas_identical": replicas_identical, "n_cls": n_cls, "fs": fs}
+
+
+def sweep_and_graph_check(index, o, entry_, ctx):
+    """Single-GPU extras of an `other_configs` entry: (1) the same step at larger per-GPU batches (BATCH_SWEEP), 12 timed steps
+    each without launch events, with the peak device memory, and the largest batch the 288 GB would hold by that memory's
+    slope; (2) for configs[3], whose host enqueue time sits beside its step time, the same step replayed from a HIP graph:
+    when the replay is more than 2 % faster the eager line is host-bound and says so."""
+    out = {}
+    rows = [{"per_gpu_batch": o.batch, "value": entry_["value"], "ms_per_step": entry_["ms_per_step"], "peak_mem_gb": entry_["peak_mem_gb"]}]
+    for b in BATCH_SWEEP.get(index, ()):
+        q = argparse.Namespace(**dict(vars(o), batch=b, steps=12, warmup=4, prewarm=4, no_launch_timing=True, events_after=True, graphed=False))
+        try:
+            r = measure(q, ctx)
+            rows.append({"per_gpu_batch": b, "value": round(r["value"], 2), "ms_per_step": round(r["ms_per_step"], 3),
+                         "peak_mem_gb": r["peak_mem_gb"]})
+        except Exception as exc:   # (out of memory ends the sweep, not the line)
+            rows.append({"per_gpu_batch": b, "error": "%s: %s" % (type(exc).__name__, str(exc)[:120])})
+            break
+    ok = [r_ for r_ in rows if "error" not in r_]
+    out["batch_sweep"] = rows
+    if len(ok) >= 2:
+        slope = (ok[-1]["peak_mem_gb"] - ok[0]["peak_mem_gb"]) / (ok[-1]["per_gpu_batch"] - ok[0]["per_gpu_batch"])
+        fixed = ok[0]["peak_mem_gb"] - slope * ok[0]["per_gpu_batch"]
+        if slope > 0:
+            out["largest_batch_that_fits_estimate"] = int((0.92 * HBM_GB - fixed) / slope)
+            out["largest_batch_note"] = "from the measured peak device memory per image (%.2f GB) against 92 %% of %d GB; measured batches: %s" % (
+                slope, HBM_GB, [r_["per_gpu_batch"] for r_ in ok])
+        out["best_batch"] = max(ok, key=lambda r_: r_["value"])["per_gpu_batch"]
+    if index == 0 and not getattr(o, "graphed", False):
+        q = argparse.Namespace(**dict(vars(o), steps=20, warmup=5, prewarm=5, no_launch_timing=True, events_after=True, graphed=True))
+        try:
+            r = measure(q, ctx)
+            out["graphed_ms_per_step"] = round(r["ms_per_step"], 3)
+            out["host_bound"] = bool(r["ms_per_step"] < 0.98 * entry_["ms_per_step"])
+        except Exception as exc:
+            out["graphed_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:120])
+    return out
 
 
 def main():
@@ -669,6 +714,8 @@ def main():
                 if distributed:
                     raise  # ranks would fall out of step: better no line than a hung job
                 entry_ = {"config": name, "error": "%s: %s" % (type(exc).__name__, exc)}
+            if entry_ is not None and "error" not in entry_ and not distributed and os.environ.get("UNETPP_BENCH_NO_SWEEP") != "1":
+                entry_.update(sweep_and_graph_check(OTHER_CONFIGS.index((name, over)), o, entry_, ctx))
             if entry_ is not None:
                 others.append(entry_)
     if others_first:
