@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define UNETPP_ABI_VERSION 9
+#define UNETPP_ABI_VERSION 10
 #define UNETPP_MAX_VIEWS 8
 
 #define UNETPP_OK 0
@@ -144,11 +144,16 @@ const char* unetpp_last_kernel_name(void);
 /* Dispatcher switches for A/B measurements and for tests that hold two kernels against each other inside one process
  * (v9; replaces per-launch getenv).  `name` is the switch without its UNETPP_ prefix: BF16_NO_DMA, BF16_DMA_ALL,
  * BF16_DMA_MIN8, BF16_DMA_FORM, BF16_DMA_SMALL, BF16_DMA_STATS, BF16_DMA_POINTWISE, BF16_DMA_SPLIT, BF16_WGRAD_QUAD,
- * WINO_NO_LEAN, WINO_ONE_PER_CU, MEMSET_NODES, BF16_PW_PLAIN.  set != 0: the switch takes `value`; set == 0: back to the
+ * WINO_NO_LEAN, WINO_ONE_PER_CU, MEMSET_NODES, BF16_PW_PLAIN, PW_DIRECT (0: fp32 pointwise launches back on the LDS-staged
+ * kernels), PW_NT (fp32 pointwise GEMM: 1 / 0 = non-temporal / plain stores whatever the output size).  set != 0: the switch takes `value`; set == 0: back to the
  * dispatcher's built-in default.  The environment variable UNETPP_<name>, if present when the library first looks a
  * switch up, is the initial setting.  Process-wide; results never depend on a switch beyond the summation order of the
  * kernel it selects.  UNETPP_EINVAL for an unknown name. */
 int unetpp_debug_set(const char* name, int64_t value, int32_t set);
+/* The current state of a switch (v10): returns 1 and stores its value in *value when the switch is set (by
+ * unetpp_debug_set or by its environment variable), 0 when it is unset (*value untouched), UNETPP_EINVAL for an unknown
+ * name.  Lets a scoped override put back what it found. */
+int unetpp_debug_get(const char* name, int64_t* value);
 
 /* Data-parallel co-scheduling knob (v8).  Every hot kernel is a persistent launch sized to fill all CUs at 2-3 workgroups
  * per CU, so a collective kernel (RCCL all-reduce of a gradient bucket on a side stream, trainer/trainer.py:338's

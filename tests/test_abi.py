@@ -41,7 +41,7 @@ def test_exported_symbols_are_plain_c(built_lib):
     out = subprocess.run(["nm", "-D", "--defined-only", built_lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
     assert set(_declared_functions()) <= exported
-    assert built_lib.lib().unetpp_abi_version() == built_lib.ABI_VERSION == 9
+    assert built_lib.lib().unetpp_abi_version() == built_lib.ABI_VERSION == 10
     assert built_lib.lib().unetpp_build_arch() == b"gfx950"
 
 
@@ -140,8 +140,17 @@ def test_no_launch_path_reads_the_environment(built_lib):
             assert "getenv(" not in code, fn
         assert "g_bn_rows" not in code and "note_bn_rows" not in code, fn
     lib = built_lib.lib()
+    import ctypes
+    v = ctypes.c_int64(-1)
+    assert lib.unetpp_debug_get(b"BF16_DMA_FORM", ctypes.byref(v)) == 0 and v.value == -1   # unset: value untouched
     assert lib.unetpp_debug_set(b"BF16_DMA_FORM", 8, 1) == 0
+    assert lib.unetpp_debug_get(b"BF16_DMA_FORM", ctypes.byref(v)) == 1 and v.value == 8
+    with built_lib.debug_switch("BF16_DMA_FORM", 4):     # a scoped override puts back what it found
+        assert lib.unetpp_debug_get(b"BF16_DMA_FORM", ctypes.byref(v)) == 1 and v.value == 4
+    assert lib.unetpp_debug_get(b"BF16_DMA_FORM", ctypes.byref(v)) == 1 and v.value == 8
     assert lib.unetpp_debug_set(b"BF16_DMA_FORM", 0, 0) == 0
+    assert lib.unetpp_debug_get(b"BF16_DMA_FORM", ctypes.byref(v)) == 0
+    assert lib.unetpp_debug_get(b"NO_SUCH_SWITCH", ctypes.byref(v)) < 0
     assert lib.unetpp_debug_set(b"NO_SUCH_SWITCH", 1, 1) < 0
     assert lib.unetpp_debug_set(None, 1, 1) < 0
 

@@ -220,6 +220,65 @@ def test_bf16_pointwise_into_an_odd_number_of_column_tiles_is_reproducible(dev, 
         assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), "launch %d" % i
 
 
+@pytest.mark.parametrize("case", [
+    # every launch class of gemm_bf16_dma.hip in which a wave's block index runs past its operand and repeats a block
+    # ("same bytes to the same place"): (taps, form, B, H, W, cins, cout, mode)
+    (9, 4, 4, 96, 96, (32,), 32, "relu"),        # 22 input blocks over 4 waves (waves 2, 3 repeat), 18 weight blocks (waves 2, 3 repeat)
+    (9, 4, 4, 96, 96, (32,), 32, "stats"),       # the statistics instantiation of the same
+    (9, 4, 2, 96, 96, (64, 64), 64, "dgrad"),    # read-modify-write epilogue, two column groups
+    (9, 8, 4, 128, 128, (64,), 64, "relu"),      # 8-wave form: 39 input blocks (wave 7 repeats), 36 weight blocks (waves 4-7 repeat)
+    (9, 8, 4, 128, 128, (128,), 32, "relu"),     # 8-wave form with the weight image resident: 18-block slots
+    (1, 4, 4, 128, 128, (64,), 32, "relu"),      # pointwise into ONE column tile: 2-block weight slot (the round-5 bug)
+    (1, 4, 4, 128, 128, (128,), 64, "dgrad"),    # pointwise, two column tiles per unit, read-modify-write
+])
+def test_bf16_dma_block_repeats_are_reproducible(dev, case):
+    """The round-5 bug class (a DMA whose block index is "repeated" to a place outside its slot lands in the buffer the
+    running chunk reads; timing decides) cannot be seen by one launch.  Every launch class of gemm_bf16_dma.hip that repeats
+    a block -- its two static_asserts and the `wave % WBLK` fallback are the list -- is launched twenty times over
+    hundreds of units, alternately back to back and from an idle device, and each result must be bit-identical to the
+    register-staged kernel's."""
+    from unet_nested4tiny_objects_keypoints_amd import engine, ops
+    from unet_nested4tiny_objects_keypoints_amd._lib import debug_switch
+    from unet_nested4tiny_objects_keypoints_amd.ops import V
+    taps, form, b, h, w, cins, cout, mode = case
+    g = torch.Generator().manual_seed(91)
+    ci = sum(cins)
+    if mode == "dgrad":    # K = cout -> the views of cins
+        wt = (torch.randn(cout, ci, 3 if taps == 9 else 1, 3 if taps == 9 else 1, generator=g) * 0.05).to(dev)
+        dy = torch.randn(b, h, w, cout, generator=g).to(BF).to(dev)
+        old = [torch.randn(b, h, w, c, generator=g).to(BF).to(dev) for c in cins]
+        gates = [torch.randn(b, h, w, c, generator=g).to(BF).to(dev) for c in cins]
+
+        def run():
+            outs = [o.clone() for o in old]
+            views = [V(o, accumulate=True, gate=gates[i], gate_sum=True) if i % 2 == 0 else V(o, accumulate=True) for i, o in enumerate(outs)]
+            ops.gemm_fwd(b, h, w, taps, [V(dy)], views, engine.pack_conv_dgrad(wt))
+            return outs
+    else:
+        xs = [torch.randn(b, h, w, c, generator=g).to(BF).to(dev) for c in cins]
+        wt = (torch.randn(cout, ci, 3 if taps == 9 else 1, 3 if taps == 9 else 1, generator=g) * (2.0 / (taps * ci)) ** 0.5).to(dev)
+        bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+
+        def run():
+            y = torch.full((b, h, w, cout), float("nan"), dtype=BF, device=dev)
+            part = torch.zeros(ops.gemm_pixel_blocks(b, h, w) * cout * 2, device=dev) if mode == "stats" else None
+            ops.gemm_fwd(b, h, w, taps, [V(x) for x in xs], [V(y, relu=(mode == "relu"))], engine.pack_conv_fwd(wt), bias, part)
+            return [y] + ([part] if part is not None else [])
+    bits = lambda t: t.view(torch.int16) if t.dtype == BF else t   # noqa: E731
+    with debug_switch("BF16_NO_DMA", 1):
+        ref = run()
+        torch.cuda.synchronize()
+        assert ops._lib.lib().unetpp_last_kernel_name() == (b"gemm_bf16_kernel<%d>" % taps)
+    with debug_switch("BF16_DMA_FORM", form), debug_switch("BF16_DMA_ALL", 1):
+        for i in range(20):
+            if i % 2:
+                torch.cuda.synchronize()      # every other launch starts on an idle device
+            got = run()
+            assert ops._lib.lib().unetpp_last_kernel_name() == (b"gemm_bf16_dma_kernel<%d>" % taps)
+            for a_, b_ in zip(got, ref):
+                assert torch.equal(bits(a_), bits(b_)), "launch %d" % i
+
+
 def test_conv3x3_bf16_input_gradient_targets(dev):
     """dgrad form: rotated weights, three output views: plain store, accumulate, accumulate + gate of the sum."""
     from unet_nested4tiny_objects_keypoints_amd import engine, ops

@@ -19,7 +19,7 @@ SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_pw.hip", "gemm_wino.hip", "gem
 HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h", "lds_asm.h", "bf16_common.h", "dropout.h", "bn_fused.h",
            "wino_experiments.h", "dma_experiments.h")
 MAX_VIEWS = 8
-ABI_VERSION = 9
+ABI_VERSION = 10
 # packed-f32 VALU (SLP-vectorised add pairs) costs issue slots beside MFMAs: keep the Winograd transforms scalar
 EXTRA_FLAGS = {"gemm_wino.hip": ("-fno-slp-vectorize",), "wgrad_wino.hip": ("-fno-slp-vectorize",)}
 GEMM_DIRECT = 1  # unetpp_gemm_desc.flags: direct summation only (no Winograd)
@@ -99,6 +99,7 @@ SIGNATURES = {
     "unetpp_last_kernel_name": (C.c_char_p, []),
     "unetpp_set_reserved_cus": (_I32, [_I32]),
     "unetpp_debug_set": (C.c_int, [C.c_char_p, _I64, _I32]),
+    "unetpp_debug_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64)]),
     "unetpp_usable_cus": (_I32, [C.POINTER(C.c_int32)]),
     "unetpp_gemm_pixel_blocks": (_I64, [_I32, _I32, _I32]),
     "unetpp_gemm_stats_rows": (_I64, [_I32, _I32, _I32]),
@@ -232,17 +233,23 @@ def check(status: int, what: str) -> None:
 class debug_switch:
     """with debug_switch("BF16_DMA_FORM", 8): ...  -- a dispatcher switch of the library (unetpp_debug_set) for the
     duration of a block; tests use it to hold two kernels against each other inside one process, tools for A/B runs.
-    Leaves the switch UNSET on exit (the dispatcher's default; an environment setting made before the library's first
-    lookup is not restored)."""
+    On exit the switch goes back to what it was on entry (unetpp_debug_get): unset, or the value an enclosing block or the
+    UNETPP_<name> environment variable had given it.  Process-wide: not for concurrent use from several threads."""
 
     def __init__(self, name: str, value: int):
         self.name, self.value = name.encode(), int(value)
+        self._before = None
 
     def __enter__(self):
+        old = C.c_int64(0)
+        state = lib().unetpp_debug_get(self.name, C.byref(old))
+        if state < 0:
+            check(state, "unetpp_debug_get")
+        self._before = (state == 1, int(old.value))
         check(lib().unetpp_debug_set(self.name, self.value, 1), "unetpp_debug_set")
         return self
 
     def __exit__(self, *exc):
-        check(lib().unetpp_debug_set(self.name, 0, 0), "unetpp_debug_set")
+        was_set, value = self._before
+        check(lib().unetpp_debug_set(self.name, value if was_set else 0, 1 if was_set else 0), "unetpp_debug_set")
         return False
-

@@ -261,6 +261,18 @@ extern "C" int unetpp_debug_set(const char* name, int64_t value, int32_t set) {
   return UNETPP_EINVAL;
 }
 
+extern "C" int unetpp_debug_get(const char* name, int64_t* value) {
+  if (name == nullptr) return UNETPP_EINVAL;
+  opts_from_environment();
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (strcmp(name, kOptNames[i]) == 0) {
+      if (!g_opts[i].set.load(std::memory_order_acquire)) return 0;
+      if (value != nullptr) *value = g_opts[i].value.load(std::memory_order_relaxed);
+      return 1;
+    }
+  return UNETPP_EINVAL;
+}
+
 extern "C" int32_t unetpp_set_reserved_cus(int32_t n) {
   opts_from_environment();
   if (n >= 0) {

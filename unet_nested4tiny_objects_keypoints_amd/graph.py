@@ -49,6 +49,7 @@ from __future__ import annotations
 import collections
 import copy
 import ctypes
+import os
 import warnings
 from typing import Optional
 
@@ -59,27 +60,44 @@ _HIP_NODE_TYPES = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph",
                    12: "memcpy_from_symbol", 13: "memcpy_to_symbol"}
 
 
+def _loaded_hip_runtime():
+    """The libamdhip64 image THIS process captured the graph with (the one torch loaded), opened by its exact path with
+    RTLD_NOLOAD: the image ships two HIP runtimes (torch/lib and /opt/rocm/lib), and a hipGraph_t handed to the other
+    one is a foreign pointer."""
+    path = None
+    with open("/proc/self/maps") as f:
+        for ln in f:
+            if "libamdhip64.so" in ln:
+                path = ln.split()[-1]
+                break
+    if path is None:
+        raise RuntimeError("no libamdhip64.so is loaded in this process (is torch's HIP runtime initialised?)")
+    return ctypes.CDLL(path, mode=getattr(os, "RTLD_NOLOAD", 4) | getattr(os, "RTLD_NOW", 2))
+
+
 def graph_topology(raw_graph: int, dot_path: Optional[str] = None) -> dict:
     """Nodes and edges of a hipGraph_t (the integer torch.cuda.CUDAGraph.raw_cuda_graph() returns), read back through the
     HIP runtime this process already has loaded.  ``chain`` is True when the graph is one path: a single root, a single
     leaf, edges = nodes - 1, no fork, no join."""
-    hip = ctypes.CDLL("libamdhip64.so")
+    hip = _loaded_hip_runtime()
     g = ctypes.c_void_p(raw_graph)
+
+    def ok(status, what):
+        if status != 0:
+            raise RuntimeError("%s failed with hipError %d" % (what, status))
     n = ctypes.c_size_t(0)
-    if hip.hipGraphGetNodes(g, None, ctypes.byref(n)) != 0:
-        raise RuntimeError("hipGraphGetNodes failed")
+    ok(hip.hipGraphGetNodes(g, None, ctypes.byref(n)), "hipGraphGetNodes (count)")
     nodes = (ctypes.c_void_p * max(1, n.value))()
-    hip.hipGraphGetNodes(g, nodes, ctypes.byref(n))
+    ok(hip.hipGraphGetNodes(g, nodes, ctypes.byref(n)), "hipGraphGetNodes")
     e = ctypes.c_size_t(0)
-    if hip.hipGraphGetEdges(g, None, None, ctypes.byref(e)) != 0:
-        raise RuntimeError("hipGraphGetEdges failed")
+    ok(hip.hipGraphGetEdges(g, None, None, ctypes.byref(e)), "hipGraphGetEdges (count)")
     src, dst = (ctypes.c_void_p * max(1, e.value))(), (ctypes.c_void_p * max(1, e.value))()
-    hip.hipGraphGetEdges(g, src, dst, ctypes.byref(e))
+    ok(hip.hipGraphGetEdges(g, src, dst, ctypes.byref(e)), "hipGraphGetEdges")
     kinds = collections.Counter()
     kind_of = {}
     for i in range(n.value):
         t = ctypes.c_int(-1)
-        hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t))
+        ok(hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t)), "hipGraphNodeGetType")
         kind_of[nodes[i]] = _HIP_NODE_TYPES.get(t.value, "type%d" % t.value)
         kinds[kind_of[nodes[i]]] += 1
     succ, pred = collections.Counter(src[i] for i in range(e.value)), collections.Counter(dst[i] for i in range(e.value))
@@ -107,6 +125,14 @@ class GraphedTrainStep:
                  debug_dot: Optional[str] = None, _threaded_backward: bool = False):
         if not inputs.is_cuda or not target.is_cuda:
             raise RuntimeError("GraphedTrainStep needs GPU tensors: this path has no CPU fallback")
+        if capture_optimizer:
+            # The state tensors a captured optimizer created in the warm-up are graph addresses; they are put back to ZERO
+            # before the first replay (_restore).  That is the optimizer's fresh state only when "zeros, then one update"
+            # equals its first step: Adam / AdamW, SGD with dampening 0 (momentum_buffer = grad on the first step).
+            for grp in optimizer.param_groups:
+                if grp.get("dampening", 0) != 0:
+                    raise ValueError("capture_optimizer=True needs an optimizer whose zeroed state is its fresh state: "
+                                     "SGD with dampening != 0 initialises momentum_buffer = grad, not (1 - dampening) * grad")
         if not model.training:
             raise RuntimeError("GraphedTrainStep captures a TRAINING step: call model.train() first")
         if getattr(model, "_grad_sink", None) is not None:

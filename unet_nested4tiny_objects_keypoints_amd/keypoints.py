@@ -14,6 +14,14 @@ step: blobs that touch through a thin neck are split, a blob without a core is d
 last row and column) belongs to no region, as ``cv2.watershed`` leaves it; ``segmentation="components"`` keeps the round-2
 stand-in (a region = an 8-connected component of the mask).  The reference's matcher ``match_distmin`` is unfinished and returns ``[]`` (:56-79): ``transfer_points`` returns
 the extracted points in peak order instead of an empty tensor.
+
+Known differences of ``"watershed"`` from ``cv2.watershed`` (none of them can be pinned without OpenCV): (1) there is no
+level-255 phase -- unknown pixels of a hole narrower than 5 px that is enclosed by core pixels (mask value 0, reachable only
+from labelled mask pixels) stay outside the region, where OpenCV floods them with the surrounding label; (2) the flood
+runs in synchronous rounds instead of OpenCV's FIFO queue, which can move the boundary line between two touching blobs by
+a pixel; (3) the core threshold float32(0.1 * max) assumes the float64 product of NumPy < 2 and OpenCV's fixed-point
+(non-IPP) distance path.  Peaks sit inside cores, so (1) and (2) do not move a reported point unless the map's maximum
+over a region lies on such a pixel.
 """
 from __future__ import annotations
 

@@ -710,11 +710,17 @@ def _keypoints_stages(heat, thr, num, max_regions, segmentation, ws, changed, po
         check(lib.unetpp_keypoints_extract(k, *args, sweeps, _ptr(ws), _ptr(changed), _ptr(points), _ptr(counts), st), what)
 
     def until_stable(k, what, sweeps):
-        for _ in range(4 * (h + w)):  # a sweep moves a label / a distance at least one pixel: bounded, normally 2-3 batches
+        # A sweep moves a label / a distance at least one pixel along its path, and a path through a mask is at most
+        # h * w / 2 pixels long (a one-pixel serpentine): that many sweeps bound the loop.  Every batch ends in a blocking
+        # read-back, so the batches double (normally 2-3 of them suffice).
+        done, limit = 0, h * w // 2 + sweeps
+        while done < limit:
             changed.zero_()
             stage(k, what, sweeps)
+            done += sweeps
             if int(changed.item()) == 0:
                 return
+            sweeps = min(2 * sweeps, 256)
         raise RuntimeError("keypoints_extract: %s did not converge" % what)
 
     stage(0, "keypoints mask")
