@@ -183,7 +183,8 @@ def test_bf16_dma_and_register_kernels_agree_on_transposed_convolutions(dev, b, 
                      engine.pack_deconv_dgrad(wt))
         return [dx]
     for fn in (fwd, dgrad):
-        (dma, dma_name), (reg, reg_name) = _both_kernels(fn)
+        with ops._lib.debug_switch("PW_DIRECT", 0):   # (gemm_pw_bf16.hip: test_bf16_pointwise_direct_kernel)
+            (dma, dma_name), (reg, reg_name) = _both_kernels(fn)
         assert dma_name == b"gemm_bf16_dma_kernel<1>" and reg_name == b"gemm_bf16_kernel<1>"
         assert torch.equal(dma[0].view(torch.int16), reg[0].view(torch.int16))
 
@@ -207,17 +208,18 @@ def test_bf16_pointwise_into_an_odd_number_of_column_tiles_is_reproducible(dev, 
         y = torch.full((b, h, w, co), float("nan"), dtype=BF, device=dev)
         ops.gemm_fwd(b, h, w, 1, [ops.V(x)], [ops.V(y)], engine.pack_conv_fwd(wt), bias)
         return y
-    with debug_switch("BF16_NO_DMA", 1):
+    with debug_switch("BF16_NO_DMA", 1), debug_switch("PW_DIRECT", 0):
         ref = run()
         assert ops._lib.lib().unetpp_last_kernel_name() == b"gemm_bf16_kernel<1>"
     want = F.conv2d(rb(x.permute(0, 3, 1, 2).cpu()), rb(wt.cpu()), bias.double().cpu())
     close_bf16(ref.permute(0, 3, 1, 2), want, "register kernel vs the float64 statement on the same bf16 operands")
-    for i in range(20):
-        if i % 2:
-            torch.cuda.synchronize()      # every other launch starts on an idle device
-        got = run()
-        assert ops._lib.lib().unetpp_last_kernel_name() == b"gemm_bf16_dma_kernel<1>"
-        assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), "launch %d" % i
+    with debug_switch("PW_DIRECT", 0):    # (the default pointwise kernel is gemm_pw_bf16.hip since round 6: no LDS-DMA in it)
+        for i in range(20):
+            if i % 2:
+                torch.cuda.synchronize()      # every other launch starts on an idle device
+            got = run()
+            assert ops._lib.lib().unetpp_last_kernel_name() == b"gemm_bf16_dma_kernel<1>"
+            assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), "launch %d" % i
 
 
 @pytest.mark.parametrize("case", [
@@ -265,11 +267,11 @@ def test_bf16_dma_block_repeats_are_reproducible(dev, case):
             ops.gemm_fwd(b, h, w, taps, [V(x) for x in xs], [V(y, relu=(mode == "relu"))], engine.pack_conv_fwd(wt), bias, part)
             return [y] + ([part] if part is not None else [])
     bits = lambda t: t.view(torch.int16) if t.dtype == BF else t   # noqa: E731
-    with debug_switch("BF16_NO_DMA", 1):
+    with debug_switch("BF16_NO_DMA", 1), debug_switch("PW_DIRECT", 0):
         ref = run()
         torch.cuda.synchronize()
         assert ops._lib.lib().unetpp_last_kernel_name() == (b"gemm_bf16_kernel<%d>" % taps)
-    with debug_switch("BF16_DMA_FORM", form), debug_switch("BF16_DMA_ALL", 1):
+    with debug_switch("BF16_DMA_FORM", form), debug_switch("BF16_DMA_ALL", 1), debug_switch("PW_DIRECT", 0):
         for i in range(20):
             if i % 2:
                 torch.cuda.synchronize()      # every other launch starts on an idle device
@@ -277,6 +279,61 @@ def test_bf16_dma_block_repeats_are_reproducible(dev, case):
             assert ops._lib.lib().unetpp_last_kernel_name() == (b"gemm_bf16_dma_kernel<%d>" % taps)
             for a_, b_ in zip(got, ref):
                 assert torch.equal(bits(a_), bits(b_)), "launch %d" % i
+
+
+@pytest.mark.parametrize("case", [
+    # (B, Hs, Ws, cin, cout of the transposed convolution)
+    (2, 16, 32, 64, 32),      # level 0 of configs[3]: K 64, N 128
+    (1, 16, 16, 128, 64),     # level 1 / level 0 of configs[4]: K 128, N 256 (64 KB of weights: eight waves per workgroup)
+    (1, 16, 48, 32, 32),      # K 32, three tiles per row
+    (1, 8, 16, 256, 128),     # K 256, N 512: 256 KB of weights -> the LDS-DMA kernel
+])
+def test_bf16_pointwise_direct_kernel(dev, case):
+    """gemm_pw_bf16.hip (weights resident in LDS, activations straight into the MFMA operand registers, eight consecutive
+    output channels per lane) on the transposed convolution forward (four phase views) and its input gradient (gate on the
+    accumulated sum): against the float64 statement on the same bf16 operands (fp32 sums, one rounding), and against
+    gemm_bf16_dma_kernel<1> within two units in the last place of the largest value."""
+    from unet_nested4tiny_objects_keypoints_amd import engine, ops
+    from unet_nested4tiny_objects_keypoints_amd._lib import debug_switch
+    b, hs, ws, ci, co = case
+    g = torch.Generator().manual_seed(52)
+    x = torch.randn(b, hs, ws, ci, generator=g).to(BF).to(dev)
+    wt = (torch.randn(ci, co, 2, 2, generator=g) * 0.1).to(dev)
+    bias = (torch.randn(co, generator=g) * 0.1).to(dev)
+    d_up = torch.randn(b, 2 * hs, 2 * ws, co, generator=g).to(BF).to(dev)
+    old = torch.randn(b, hs, ws, ci, generator=g).to(BF).to(dev)
+
+    def fwd():
+        up = torch.full((b, 2 * hs, 2 * ws, co), float("nan"), dtype=BF, device=dev)
+        ops.gemm_fwd(b, hs, ws, 1, [ops.V(x)], engine._phase_views(up), engine.pack_deconv_fwd(wt), engine.tile_bias4(bias))
+        return up
+
+    def dgrad():
+        dx = old.clone()
+        ops.gemm_fwd(b, hs, ws, 1, engine._phase_views(d_up), [ops.V(dx, accumulate=True, gate=x, gate_sum=True)],
+                     engine.pack_deconv_dgrad(wt))
+        return dx
+    takes = ci * 4 * co * 2 + 4 * co * 4 <= 148 * 1024
+    xf = x.double().permute(0, 3, 1, 2).cpu()
+    want_f = F.conv_transpose2d(xf, rb(wt.cpu()), bias.double().cpu(), stride=2)
+    dy = d_up.double().permute(0, 3, 1, 2).cpu()
+    xg = xf.clone().requires_grad_(True)
+    F.conv_transpose2d(xg, rb(wt.cpu()), None, stride=2).backward(dy)
+    want_d = (old.double().permute(0, 3, 1, 2).cpu() + xg.grad) * (xf > 0)
+    for fn, want in ((fwd, want_f), (dgrad, want_d)):
+        got = fn()
+        name = ops._lib.lib().unetpp_last_kernel_name()
+        assert name == (b"gemm_pw_bf16_kernel" if takes else b"gemm_bf16_dma_kernel<1>"), name
+        if not takes:
+            continue   # (the LDS-DMA kernel has its own tests)
+        close_bf16(got.permute(0, 3, 1, 2), want, fn.__name__)
+        with debug_switch("PW_DIRECT", 0):
+            other = fn()
+            assert ops._lib.lib().unetpp_last_kernel_name() == b"gemm_bf16_dma_kernel<1>"
+        diff = (got.float() - other.float()).abs()
+        # (the other kernel sums in another order and, when it accumulates, rounds its own contribution to bf16 before it
+        # adds the previous value: the two agree to a unit in the last place of the largest value, not bit for bit)
+        assert float(diff.max()) <= 2.0 ** -6 * float(want.abs().max())
 
 
 def test_conv3x3_bf16_input_gradient_targets(dev):

@@ -168,6 +168,8 @@ int launch_gemm_fast(const unetpp_gemm_desc* d, hipStream_t st);
 // gemm_pw.hip: fp32 pointwise GEMM with the weights resident in LDS and the activations loaded straight into the MFMA
 // operand registers (fa = the descriptor's fast_args); returns 1 when the descriptor is not one it takes
 int launch_gemm_pw(const unetpp_gemm_desc* d, const struct FastArgs& fa, hipStream_t st);
+// gemm_pw_bf16.hip: the bf16-storage twin of gemm_pw.hip (fa = bf16_gemm_args of the descriptor)
+int launch_gemm_pw_bf16(const unetpp_gemm_desc* d, const struct FastArgs& fa, hipStream_t st);
 // gemm_wino.hip: Winograd F(2x2,3x3) kernel for taps == 9 without UNETPP_GEMM_DIRECT (needs its own weight image)
 bool wino_applies(const unetpp_gemm_desc* d);
 int launch_gemm_wino(const unetpp_gemm_desc* d, hipStream_t st, long* bn_rows);  // *bn_rows = rows of BatchNorm sums written, when per workgroup

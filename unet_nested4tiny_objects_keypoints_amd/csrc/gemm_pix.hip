@@ -23,6 +23,7 @@
 #include <mutex>
 
 #include "common.h"
+#include "gemm_units.h"
 
 namespace unetpp {
 namespace {
@@ -332,6 +333,13 @@ int gemm_fwd_dispatch(const unetpp_gemm_desc* d, void* stream, long* bn_rows) {
   if (d->stats_partial != nullptr && d->n_out != 1) return UNETPP_EINVAL;
   if (d->flags & UNETPP_GEMM_BF16) {  // bf16 storage: the MFMA kernel, or the VALU first layer (fp32 input, bf16 output)
     if (d->weight_image != nullptr) {
+      if (d->taps == 1) {  // plain pointwise launches whose weights fit LDS: gemm_pw_bf16.hip
+        FastArgs fa;
+        if (bf16_gemm_args(d, fa)) {
+          const int pw = launch_gemm_pw_bf16(d, fa, static_cast<hipStream_t>(stream));
+          if (pw != 1) return pw;
+        }
+      }
       const int dma = launch_gemm_bf16_dma(d, static_cast<hipStream_t>(stream));
       return dma != 1 ? dma : launch_gemm_bf16(d, static_cast<hipStream_t>(stream));
     }
