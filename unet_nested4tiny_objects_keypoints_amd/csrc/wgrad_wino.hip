@@ -156,13 +156,59 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
     asm volatile("" : "+v"(v));
     return v;
   };
-  auto issue_tile = [&](unsigned tile, float* buf) {  // tile < 2^31 (launcher); uniform: the decode runs on the SALU
-    __builtin_amdgcn_s_setprio(3);
-    unsigned b = __builtin_amdgcn_readfirstlane(tile);
-    const int txi = static_cast<int>(b % static_cast<unsigned>(a.tiles_x));
+  // interior patches: a slot that is never loaded (columns 34, 35 of a row; channel quads past a narrow view) carries the
+  // out-of-range marker in its delta, so issuing an item is the DMA instruction alone: constant vector offset, the
+  // patch origin in the scalar offset (round 6: the select + add + produced-in-place copy per item, ten items per patch,
+  // and the two divisions of the tile decode were ~80 vector instructions per patch beside MFMAs that do not overlap them)
+  unsigned xdelta_i[X_ITEMS], ydelta_i[DY_ITEMS];
+#pragma unroll
+  for (int q = 0; q < X_ITEMS; ++q) xdelta_i[q] = ((x_valid >> q) & 1u) ? xdelta[q] : 0x80000000u;
+#pragma unroll
+  for (int q = 0; q < DY_ITEMS; ++q) ydelta_i[q] = nx_ok ? ydelta[q] : 0x80000000u;
+  // border patches of images that are whole patches wide and high (W % 32 == 0, H % 8 == 0: every level of the network):
+  // an x slot lies outside the image only in the first / last halo column or row of a patch at the matching image
+  // edge -- four bits per item (hx == 0, hx == 33, hy == 0, hy == 9), tested against the patch's four edge flags
+  unsigned edge_bits = 0;
+#pragma unroll
+  for (int q = 0; q < X_ITEMS; ++q) {
+    const int hp = (tid >> 3) + q * (kWThreads >> 3);
+    const int hy = hp / kXRow, hx = hp - hy * kXRow;
+    edge_bits |= static_cast<unsigned>((hx == 0) | ((hx == kHWp - 1) << 1) | ((hy == 0) << 2) | ((hy == kHHp - 1) << 3)) << (4 * q);
+  }
+  const bool whole_patches = (d.W & (kTW - 1)) == 0 && (d.H & (kTH - 1)) == 0;
+  // The tiles of a workgroup are blockIdx.x, + gridDim.x, ...: the (image, patch row, patch column) cursor of the next
+  // tile to issue is stepped by the decomposed stride on the scalar unit instead of being divided out per tile.
+  int c_tx, c_ty, c_n, s_tx, s_ty, s_n;
+  {
+    unsigned b = blockIdx.x;
+    c_tx = static_cast<int>(b % static_cast<unsigned>(a.tiles_x));
     b /= static_cast<unsigned>(a.tiles_x);
-    const int tyi = static_cast<int>(b % static_cast<unsigned>(a.tiles_y));
-    const int n = static_cast<int>(b / static_cast<unsigned>(a.tiles_y));
+    c_ty = static_cast<int>(b % static_cast<unsigned>(a.tiles_y));
+    c_n = static_cast<int>(b / static_cast<unsigned>(a.tiles_y));
+    b = gridDim.x;
+    s_tx = static_cast<int>(b % static_cast<unsigned>(a.tiles_x));
+    b /= static_cast<unsigned>(a.tiles_x);
+    s_ty = static_cast<int>(b % static_cast<unsigned>(a.tiles_y));
+    s_n = static_cast<int>(b / static_cast<unsigned>(a.tiles_y));
+    c_tx = __builtin_amdgcn_readfirstlane(c_tx);
+    c_ty = __builtin_amdgcn_readfirstlane(c_ty);
+    c_n = __builtin_amdgcn_readfirstlane(c_n);
+    s_tx = __builtin_amdgcn_readfirstlane(s_tx);
+    s_ty = __builtin_amdgcn_readfirstlane(s_ty);
+    s_n = __builtin_amdgcn_readfirstlane(s_n);
+  }
+  auto issue_tile = [&](unsigned, float* buf) {  // the tiles are issued in order: the cursor names the one meant
+    __builtin_amdgcn_s_setprio(3);
+    const int txi = c_tx, tyi = c_ty, n = c_n;
+    {  // step the cursor (all uniform)
+      c_tx += s_tx;
+      const int cx = c_tx >= a.tiles_x ? 1 : 0;
+      c_tx -= cx * a.tiles_x;
+      c_ty += s_ty + cx;
+      const int cy = c_ty >= a.tiles_y ? 1 : 0;
+      c_ty -= cy * a.tiles_y;
+      c_n += s_n + cy;
+    }
     const int ty0 = tyi * kTH, tx0 = txi * kTW;
     const char* xb = reinterpret_cast<const char*>(X.ptr + view_pixel_offset(X, n, ty0 - 1, tx0 - 1) + c0);
     const char* yb = reinterpret_cast<const char*>(DY.ptr + view_pixel_offset(DY, n, ty0, tx0) + nc0);
@@ -191,16 +237,28 @@ __global__ __launch_bounds__(kWThreads, 2) void wgrad_wino_kernel(const WWinoArg
         if (interior) {
 #pragma unroll
           for (int q = 0; q < X_ITEMS; ++q) {
-            if (q * 8 + wave < XG) {  // wave uniform: the last item ends after 45 groups
-              const unsigned off = in_block(((x_valid >> q) & 1u) ? xorg + xdelta[q] : 0x80000000u);
+            if (q * 8 + wave < XG)  // wave uniform: the last item ends after 45 groups
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lptr_t)(buf + (q * 8 + wave) * GX), 16, static_cast<int>(xdelta_i[q]),
+                                                       static_cast<int>(xorg), 0, 0);
+          }
+#pragma unroll
+          for (int q = 0; q < DY_ITEMS; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lptr_t)(buf + X_FLOATS + (q * 8 + wave) * GY), 16, static_cast<int>(ydelta_i[q]),
+                                                     static_cast<int>(yorg), 0, 0);
+        } else if (whole_patches) {
+          const unsigned em = static_cast<unsigned>((tx0 == 0) | ((tx0 + kTW == d.W) << 1) | ((ty0 == 0) << 2) | ((ty0 + kTH == d.H) << 3)) * 0x111111u;
+          const unsigned hit = edge_bits & em;
+#pragma unroll
+          for (int q = 0; q < X_ITEMS; ++q) {
+            if (q * 8 + wave < XG) {
+              const unsigned off = ((hit >> (4 * q)) & 15u) ? 0x80000000u : xorg + xdelta_i[q];  // (xorg may be "negative": it wraps back)
               __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lptr_t)(buf + (q * 8 + wave) * GX), 16, static_cast<int>(off), 0, 0, 0);
             }
           }
 #pragma unroll
-          for (int q = 0; q < DY_ITEMS; ++q) {
-            const unsigned off = in_block(nx_ok ? yorg + ydelta[q] : 0x80000000u);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lptr_t)(buf + X_FLOATS + (q * 8 + wave) * GY), 16, static_cast<int>(off), 0, 0, 0);
-          }
+          for (int q = 0; q < DY_ITEMS; ++q)  // (the dy patch has no halo: inside the image)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (lptr_t)(buf + X_FLOATS + (q * 8 + wave) * GY), 16, static_cast<int>(ydelta_i[q]),
+                                                     static_cast<int>(yorg), 0, 0);
         } else {
           const int pix = static_cast<int>(in_block(static_cast<unsigned>(tid))) >> 3;  // pixel slot of item 0; item q sits 64 slots on
 #pragma unroll
