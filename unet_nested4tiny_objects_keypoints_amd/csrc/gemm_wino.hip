@@ -252,13 +252,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     p_tx0 = ug.tx0;
     if constexpr (LEAN) {
       const int row0 = p_n * d.H;
-      // (tid "produced" here: hipcc would hoist the items' halo coordinates -- six per-thread invariants of this
-      // once-per-patch path -- out of the chunk loop into registers the MFMA phase needs, and spill them)
-      int te = tid;
-      asm volatile("" : "+v"(te));
 #pragma unroll
       for (int q = 0; q < IN_ITEMS; ++q) {
-        const int it = te + q * kThreads;
+        const int it = tid + q * kThreads;
         const int hp = it >> 1;
         const int hy = hp / HWp, hx = hp - hy * HWp;
         const int y = p_ty0 + hy - 1, x = p_tx0 + hx - 1;
@@ -494,20 +490,35 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 #pragma unroll
             for (int nh = 0; nh < NH; ++nh) old[bp][nh] = *reinterpret_cast<const f32x4*>(obase + off[bp][nh]);
         }
+        // Output transform on column PAIRS (v_pk_add_f32 / v_pk_max_f32; same association order as out_row, so the same bits).
         f32x4 yv[2][NH];
+        const f32x2 floor2 = {floor_v, floor_v};
 #pragma unroll
-        for (int nh = 0; nh < NH; ++nh)
+        for (int nh = 0; nh < NH; ++nh) {
+          f32x2 y[2][2];  // [pixel of the row][column pair]
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            float y[2];
-            out_row(ap, nh, rr, y);
-            if (want_stats) {
-              s1[nh][rr] += y[0] + y[1];
-              s2[nh][rr] = fmaf(y[0], y[0], fmaf(y[1], y[1], s2[nh][rr]));
+          for (int cp = 0; cp < 2; ++cp) {
+            f32x2 tb[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              const f32x2 m0 = cp ? acc[b][nh].hi : acc[b][nh].lo, m1 = cp ? acc[4 + b][nh].hi : acc[4 + b][nh].lo;
+              const f32x2 m2 = cp ? acc[8 + b][nh].hi : acc[8 + b][nh].lo, m3 = cp ? acc[12 + b][nh].hi : acc[12 + b][nh].lo;
+              tb[b] = (ap == 0) ? (m0 + m1) + m2 : (m1 - m2) - m3;
             }
-            yv[0][nh][rr] = y[0];
-            yv[1][nh][rr] = y[1];
+            y[0][cp] = __builtin_elementwise_max((tb[0] + tb[1]) + tb[2], floor2);
+            y[1][cp] = __builtin_elementwise_max((tb[1] - tb[2]) - tb[3], floor2);
           }
+          yv[0][nh] = f32x4{y[0][0].x, y[0][0].y, y[0][1].x, y[0][1].y};
+          yv[1][nh] = f32x4{y[1][0].x, y[1][0].y, y[1][1].x, y[1][1].y};
+          if (want_stats) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const float y0 = yv[0][nh][rr], y1 = yv[1][nh][rr];
+              s1[nh][rr] += y0 + y1;
+              s2[nh][rr] = fmaf(y0, y0, fmaf(y1, y1, s2[nh][rr]));
+            }
+          }
+        }
         if (!has_gate && !acc_out) {  // plain stores on a path of their own: no load in it, so hipcc puts no vmcnt wait
 #pragma unroll                        // between the stores
           for (int bp = 0; bp < 2; ++bp)
