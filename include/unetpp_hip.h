@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define UNETPP_ABI_VERSION 10
+#define UNETPP_ABI_VERSION 11
 #define UNETPP_MAX_VIEWS 8
 
 #define UNETPP_OK 0
@@ -226,6 +226,18 @@ int unetpp_wgrad_finish(const float* slabs, int32_t n_split, int32_t taps, int32
 int unetpp_pack_weight(float* dst, const float* src, int32_t T, int32_t K, int32_t Ncols,
                        int64_t d_t, int64_t d_k, int64_t d_n, int64_t s_t, int64_t s_k, int64_t s_n,
                        int32_t flip, void* stream);
+/* Many strided copies in ONE launch: dst[o*dst_stride + i] = src[o*src_stride + i], o < n_outer, i < n_inner (floats;
+ * n_outer*n_inner < 2^31 per job; 16-byte pieces when pointers, n_inner and strides allow).  The job table lives in
+ * DEVICE memory; max_elems = the largest n_outer*n_inner of the table (sizes the grid).  Host-side re-layouts of a pass
+ * that are not weight images: the bias of a 2x2 transposed convolution repeated for its four pixel phases (the GEMM
+ * column is phase*co + c: src_stride 0, n_outer 4), the input-gradient weights of the dense skips grouped by producer
+ * (channel slices of the consumers' conv1 weights, the torch.cat of models/unet.py:198-202, stacked along the output-channel axis). */
+typedef struct unetpp_copy_job {
+  const float* src;
+  float* dst;
+  int64_t n_outer, n_inner, src_stride, dst_stride;
+} unetpp_copy_job;
+int unetpp_copy_jobs(const unetpp_copy_job* jobs_device, int32_t n_jobs, int64_t max_elems, void* stream);
 
 /* ---- BatchNorm2d, training mode (models/unet.py:133) -------------------------------------- */
 /* partial [n_blocks][C][2] (sum, sumsq) -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale;
@@ -308,6 +320,20 @@ int unetpp_bilinear2x_bwd(const float* dy, int32_t N, int32_t H, int32_t W, int3
 int64_t unetpp_focal_bce_blocks(int64_t n);
 int unetpp_focal_bce(const float* pred, const float* target, int64_t n, int64_t rows, float gamma, float* grad,
                      float* partial, float* loss, void* stream);
+/* The trainer's loop over the deep-supervision heads (trainer/trainer.py:122-135: criterion on every head, mean over
+ * heads) in one pass over the target: loss[1 + h] = FocalLoss_BCE_2d(pred[h], target) exactly as unetpp_focal_bce
+ * computes it, loss[0] = (0 + loss[1] + ... + loss[n_heads]) * (1 / n_heads) in that order (float32, what the loop body's
+ * tensor arithmetic does), grad[h] = d loss[0] / d pred[h] = (d loss[1 + h] / d pred[h]) * (1 / n_heads) -- the product
+ * autograd forms from the same two float32 factors.  1 <= n_heads <= UNETPP_MAX_HEADS; partial[n_heads *
+ * unetpp_focal_bce_blocks(n)] is workspace; every pred[h] / grad[h] (grad[h] may be NULL) 16-byte aligned, n elements. */
+#define UNETPP_MAX_HEADS 8
+typedef struct unetpp_focal_heads {
+  const float* pred[UNETPP_MAX_HEADS];
+  float* grad[UNETPP_MAX_HEADS];
+  int32_t n_heads, reserved;
+} unetpp_focal_heads;
+int unetpp_focal_bce_heads(const unetpp_focal_heads* heads, const float* target, int64_t n, int64_t rows, float gamma,
+                           float* partial, float* loss, void* stream);
 /* create_heatmap (tools/misc/helper.py:87-172): key points [N][P][2] as (x, y), P >= 6 -> float32 [N,4,H,W]:
  * ch0 = point 0, ch1 = points 1..3 summed / max, ch2 = point 4, ch3 = points 5..P-1 summed / max, each map
  * exp(-0.5 sqrt(dx^2 + dy^2) / radius) (the reference uses radius 3).  workspace: unetpp_heatmap_workspace_bytes(). */

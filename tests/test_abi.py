@@ -41,7 +41,7 @@ def test_exported_symbols_are_plain_c(built_lib):
     out = subprocess.run(["nm", "-D", "--defined-only", built_lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
     assert set(_declared_functions()) <= exported
-    assert built_lib.lib().unetpp_abi_version() == built_lib.ABI_VERSION == 10
+    assert built_lib.lib().unetpp_abi_version() == built_lib.ABI_VERSION == 11
     assert built_lib.lib().unetpp_build_arch() == b"gfx950"
 
 

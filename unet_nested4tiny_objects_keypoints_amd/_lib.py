@@ -19,7 +19,7 @@ SOURCES = ("gemm_pix.hip", "gemm_fast.hip", "gemm_pw.hip", "gemm_pw_bf16.hip", "
 HEADERS = ("common.h", "gemm_units.h", "wgrad_reduce.h", "lds_asm.h", "bf16_common.h", "dropout.h", "bn_fused.h",
            "wino_experiments.h", "dma_experiments.h")
 MAX_VIEWS = 8
-ABI_VERSION = 10
+ABI_VERSION = 11
 # packed-f32 VALU (SLP-vectorised add pairs) costs issue slots beside MFMAs: keep the Winograd transforms scalar
 EXTRA_FLAGS = {"gemm_wino.hip": ("-fno-slp-vectorize",), "wgrad_wino.hip": ("-fno-slp-vectorize",)}
 GEMM_DIRECT = 1  # unetpp_gemm_desc.flags: direct summation only (no Winograd)
@@ -79,6 +79,25 @@ class PackJob(C.Structure):
     ]
 
 
+class CopyJob(C.Structure):
+    """mirror of struct unetpp_copy_job"""
+    _fields_ = [
+        ("src", C.c_void_p), ("dst", C.c_void_p),
+        ("n_outer", C.c_int64), ("n_inner", C.c_int64), ("src_stride", C.c_int64), ("dst_stride", C.c_int64),
+    ]
+
+
+MAX_HEADS = 8
+
+
+class FocalHeads(C.Structure):
+    """mirror of struct unetpp_focal_heads"""
+    _fields_ = [
+        ("pred", C.c_void_p * MAX_HEADS), ("grad", C.c_void_p * MAX_HEADS),
+        ("n_heads", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
 class WgradDesc(C.Structure):
     """mirror of struct unetpp_wgrad_desc"""
     _fields_ = [
@@ -131,6 +150,8 @@ SIGNATURES = {
     "unetpp_sum_partials": (C.c_int, [_P, _I64, _I64, _P, _P]),
     "unetpp_focal_bce_blocks": (_I64, [_I64]),
     "unetpp_focal_bce": (C.c_int, [_P, _P, _I64, _I64, _F, _P, _P, _P, _P]),
+    "unetpp_focal_bce_heads": (C.c_int, [C.POINTER(FocalHeads), _P, _I64, _I64, _F, _P, _P, _P]),
+    "unetpp_copy_jobs": (C.c_int, [_P, _I32, _I64, _P]),
     "unetpp_heatmap_workspace_bytes": (_I64, [_I32, _I32, _I32]),
     "unetpp_create_heatmap": (C.c_int, [_P, _I32, _I32, _I32, _I32, _F, _P, _P, _P]),
     "unetpp_bilinear2x_fwd": (C.c_int, [_P, _I32, _I32, _I32, _I32, _P, _P]),

@@ -14,37 +14,31 @@ namespace {
 constexpr int kLossThreads = 256;
 constexpr int kLossPerThread = 8;  // elements per thread: 2 x float4
 
-__global__ __launch_bounds__(kLossThreads) void focal_bce_kernel(const float* __restrict__ pred,
-                                                                const float* __restrict__ target, long n, float gamma,
-                                                                float inv_rows, float* __restrict__ grad,
-                                                                float* __restrict__ partial) {
-  __shared__ float red[kLossThreads / 64];
-  const long base = (blockIdx.x * static_cast<long>(kLossThreads) + threadIdx.x) * kLossPerThread;
+// The elements of one thread (2 x float4 at `base`): the gradient (times `scale`: 1 for a single head, 1 / heads under
+// the trainer's mean over heads -- a second float32 product, as autograd forms it) and the thread's part of the loss sum.
+// t[2][4]: the thread's targets, read once for all heads.
+__device__ __forceinline__ float focal_thread(const float* __restrict__ pred, float* __restrict__ grad,
+                                              const float (&t)[kLossPerThread / 4][4], long base, long n, float gamma,
+                                              float inv_rows, float scale) {
   const bool cube = gamma == 3.f;
   float sum = 0.f;
 #pragma unroll
   for (int h = 0; h < kLossPerThread / 4; ++h) {
     const long i = base + 4 * h;
     if (i >= n) break;
-    float p[4], t[4], g[4];
+    float p[4], g[4];
     const bool vec = (i + 4 <= n);
     if (vec) {
-      const f32x4 pv = *reinterpret_cast<const f32x4*>(pred + i), tv = *reinterpret_cast<const f32x4*>(target + i);
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(pred + i);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        p[e] = pv[e];
-        t[e] = tv[e];
-      }
+      for (int e = 0; e < 4; ++e) p[e] = pv[e];
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        p[e] = (i + e < n) ? pred[i + e] : 0.f;
-        t[e] = (i + e < n) ? target[i + e] : 0.f;
-      }
+      for (int e = 0; e < 4; ++e) p[e] = (i + e < n) ? pred[i + e] : 0.f;
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float d = p[e] - t[e];
+      const float d = p[e] - t[h][e];
       const float err = (1.f - fabsf(d)) + 1e-20f;
       const float u = 1.f - err;
       const float lg = logf(err);
@@ -53,7 +47,7 @@ __global__ __launch_bounds__(kLossThreads) void focal_bce_kernel(const float* __
       const float le = -ug * lg;
       const float dl_de = gamma * ug1 * lg - ug / err;
       const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-      g[e] = -dl_de * sgn * inv_rows;
+      g[e] = (-dl_de * sgn * inv_rows) * scale;
       if (i + e < n) sum += le;
     }
     if (grad != nullptr) {
@@ -66,11 +60,62 @@ __global__ __launch_bounds__(kLossThreads) void focal_bce_kernel(const float* __
       }
     }
   }
+  return sum;
+}
+
+__device__ __forceinline__ void focal_read_target(const float* __restrict__ target, long base, long n,
+                                                  float (&t)[kLossPerThread / 4][4]) {
+#pragma unroll
+  for (int h = 0; h < kLossPerThread / 4; ++h) {
+    const long i = base + 4 * h;
+    if (i + 4 <= n) {
+      const f32x4 tv = *reinterpret_cast<const f32x4*>(target + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[h][e] = tv[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[h][e] = (i + e < n) ? target[i + e] : 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kLossThreads) void focal_bce_kernel(const float* __restrict__ pred,
+                                                                const float* __restrict__ target, long n, float gamma,
+                                                                float inv_rows, float* __restrict__ grad,
+                                                                float* __restrict__ partial) {
+  __shared__ float red[kLossThreads / 64];
+  const long base = (blockIdx.x * static_cast<long>(kLossThreads) + threadIdx.x) * kLossPerThread;
+  float t[kLossPerThread / 4][4];
+  focal_read_target(target, base, n, t);
+  float sum = focal_thread(pred, grad, t, base, n, gamma, inv_rows, 1.f);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_rows;
+}
+
+// All deep-supervision heads against one target: the target is read once, partial[h * gridDim.x + block] as
+// focal_bce_kernel writes partial[block] for head h (same per-thread order, same wave and block sums).
+__global__ __launch_bounds__(kLossThreads) void focal_bce_heads_kernel(const unetpp_focal_heads hd,
+                                                                      const float* __restrict__ target, long n, float gamma,
+                                                                      float inv_rows, float scale,
+                                                                      float* __restrict__ partial) {
+  __shared__ float red[UNETPP_MAX_HEADS][kLossThreads / 64];
+  const long base = (blockIdx.x * static_cast<long>(kLossThreads) + threadIdx.x) * kLossPerThread;
+  float t[kLossPerThread / 4][4];
+  focal_read_target(target, base, n, t);
+  for (int h = 0; h < hd.n_heads; ++h) {
+    float sum = focal_thread(hd.pred[h], hd.grad[h], t, base, n, gamma, inv_rows, scale);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((threadIdx.x & 63) == 0) red[h][threadIdx.x >> 6] = sum;
+  }
+  __syncthreads();
+  if (static_cast<int>(threadIdx.x) < hd.n_heads) {
+    const float* r = red[threadIdx.x];
+    partial[static_cast<long>(threadIdx.x) * gridDim.x + blockIdx.x] = ((r[0] + r[1]) + (r[2] + r[3])) * inv_rows;
+  }
 }
 
 // one block: loss = sum of the per-block partials, fixed order (1024 strided sums, then an LDS tree)
@@ -86,6 +131,31 @@ __global__ __launch_bounds__(1024) void focal_bce_finish_kernel(const float* __r
     __syncthreads();
   }
   if (threadIdx.x == 0) loss[0] = red[0];
+}
+
+// one block: every head's loss as focal_bce_finish_kernel sums it, then the trainer's mean over heads in ITS order:
+// avg = 0; avg = avg + loss_h (h = 0, 1, ...); avg = 1.0 * avg / heads -- float32 tensor arithmetic, the division by a
+// Python scalar being a product with float32(1 / heads).
+__global__ __launch_bounds__(1024) void focal_bce_heads_finish_kernel(const float* __restrict__ partial, long n_blocks,
+                                                                      int n_heads, float inv_heads, float* __restrict__ loss) {
+  __shared__ float red[1024];
+  float avg = 0.f;
+  for (int h = 0; h < n_heads; ++h) {
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n_blocks; i += 1024) s += partial[h * n_blocks + i];
+    __syncthreads();  // (the previous head's red[0] has been read)
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w >= 1; w >>= 1) {
+      if (static_cast<int>(threadIdx.x) < w) red[threadIdx.x] += red[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      loss[1 + h] = red[0];
+      avg = avg + red[0];
+    }
+  }
+  if (threadIdx.x == 0) loss[0] = (1.0f * avg) * inv_heads;
 }
 
 // grid (blocks per image, N): unnormalised maps of the 4 channels + per-block maxima of channels 1 and 3
@@ -185,6 +255,29 @@ extern "C" int unetpp_focal_bce(const float* pred, const float* target, int64_t 
                      1.f / static_cast<float>(rows), grad, partial);
   hipLaunchKernelGGL(focal_bce_finish_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), partial,
                      static_cast<long>(blocks), loss);
+  return launch_status();
+}
+
+extern "C" int unetpp_focal_bce_heads(const unetpp_focal_heads* heads, const float* target, int64_t n, int64_t rows,
+                                      float gamma, float* partial, float* loss, void* stream) {
+  if (heads == nullptr || target == nullptr || partial == nullptr || loss == nullptr || n < 1 || rows < 1) return UNETPP_EINVAL;
+  if (heads->n_heads < 1 || heads->n_heads > UNETPP_MAX_HEADS) return UNETPP_EINVAL;
+  uintptr_t bits = reinterpret_cast<uintptr_t>(target);
+  for (int h = 0; h < heads->n_heads; ++h) {
+    if (heads->pred[h] == nullptr) return UNETPP_EINVAL;
+    bits |= reinterpret_cast<uintptr_t>(heads->pred[h]) | reinterpret_cast<uintptr_t>(heads->grad[h]);
+  }
+  if ((bits & 15) != 0) return UNETPP_EINVAL;
+  const int64_t blocks = unetpp_focal_bce_blocks(n);
+  if (blocks > 0x7fffffffLL) return UNETPP_EINVAL;
+  unetpp_focal_heads hd = *heads;
+  for (int h = hd.n_heads; h < UNETPP_MAX_HEADS; ++h) hd.pred[h] = nullptr, hd.grad[h] = nullptr;
+  const float inv_heads = 1.0f / static_cast<float>(hd.n_heads);
+  hipLaunchKernelGGL(focal_bce_heads_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kLossThreads), 0,
+                     static_cast<hipStream_t>(stream), hd, target, static_cast<long>(n), gamma,
+                     1.f / static_cast<float>(rows), inv_heads, partial);
+  hipLaunchKernelGGL(focal_bce_heads_finish_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), partial,
+                     static_cast<long>(blocks), hd.n_heads, inv_heads, loss);
   return launch_status();
 }
 

@@ -293,6 +293,31 @@ __global__ void pack_weight_kernel(float* __restrict__ dst, const float* __restr
   dst[t * d_t + k * d_k + nn * d_n] = src[tt * s_t + k * s_k + nn * s_n];
 }
 
+// Many small strided copies in ONE launch (grid.y = job): dst[o * dst_stride + i] = src[o * src_stride + i], o < n_outer,
+// i < n_inner.  The host-side re-layouts a pass needs before its GEMMs -- the four-phase bias rows of the transposed
+// convolutions (src_stride 0), the grouped input-gradient weights (slices of the consumers' conv1 weights, concatenated
+// along the output-channel axis) -- were one 4-5 us launch each (7 + 6 per step at depth 4, 10 + 10 at depth 5).
+__global__ __launch_bounds__(256) void copy_jobs_kernel(const unetpp_copy_job* __restrict__ jobs) {
+  const unetpp_copy_job j = jobs[blockIdx.y];
+  const unsigned inner = static_cast<unsigned>(j.n_inner);
+  const bool vec = ((j.n_inner | j.src_stride | j.dst_stride) & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(j.src) | reinterpret_cast<uintptr_t>(j.dst)) & 15) == 0;
+  const unsigned step = gridDim.x * 256u;
+  if (vec) {
+    const unsigned inner4 = inner >> 2, total4 = static_cast<unsigned>(j.n_outer) * inner4;
+    for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total4; e += step) {
+      const unsigned o = e / inner4, i = e - o * inner4;
+      *reinterpret_cast<f32x4*>(j.dst + o * j.dst_stride + 4 * i) = *reinterpret_cast<const f32x4*>(j.src + o * j.src_stride + 4 * i);
+    }
+  } else {
+    const unsigned total = static_cast<unsigned>(j.n_outer) * inner;
+    for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += step) {
+      const unsigned o = e / inner, i = e - o * inner;
+      j.dst[o * j.dst_stride + i] = j.src[o * j.src_stride + i];
+    }
+  }
+}
+
 }  // namespace
 }  // namespace unetpp
 
@@ -412,5 +437,14 @@ extern "C" int unetpp_pack_weight(float* dst, const float* src, int32_t T, int32
   const unsigned blocks = static_cast<unsigned>((total + 255) / 256);
   hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dst, src, T,
                      K, Ncols, d_t, d_k, d_n, s_t, s_k, s_n, flip);
+  return launch_status();
+}
+
+extern "C" int unetpp_copy_jobs(const unetpp_copy_job* jobs_device, int32_t n_jobs, int64_t max_elems, void* stream) {
+  // (the jobs live in device memory: their fields are the caller's contract -- n_outer * n_inner < 2^31 per job)
+  if (jobs_device == nullptr || n_jobs < 1 || n_jobs > 65535 || max_elems < 1 || max_elems >= 0x7fffffffLL) return UNETPP_EINVAL;
+  const int64_t want = (max_elems + 1023) / 1024;  // 256 threads x one 16-byte piece
+  hipLaunchKernelGGL(copy_jobs_kernel, dim3(static_cast<unsigned>(want < 512 ? want : 512), static_cast<unsigned>(n_jobs)),
+                     dim3(256), 0, static_cast<hipStream_t>(stream), jobs_device);
   return launch_status();
 }

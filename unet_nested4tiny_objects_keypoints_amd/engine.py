@@ -29,6 +29,8 @@ USE_GROUPED_DGRAD = os.environ.get("UNETPP_NO_GROUPED_DGRAD") is None
 # bf16 storage: encoder blocks whose first-stage tensor is at most this large write a1 = relu(bn(y1)) instead of folding it
 # into conv2's load (see _pair_fwd); 0 = never.  Same box, alternating: configs[4] 11.16 -> 10.98 ms per step at 80 MB (11.02
 # at 20-40 MB), configs[3] 7.37 -> 7.34-7.35 ms at 20-200 MB
+# A/B switch (measurements only): the bias rows / grouped weights by one launch each instead of the plan's copy launch
+USE_PLAN_COPIES = os.environ.get("UNETPP_NO_PLAN_COPIES") is None
 _A1_MATERIALIZE_BYTES = int(float(os.environ.get("UNETPP_BF16_A1_MAX_MB", "80")) * (1 << 20))
 
 
@@ -84,8 +86,17 @@ def pack_deconv_dgrad(w):
 
 
 def tile_bias4(b):
+    """the bias of a 2x2 transposed convolution once per pixel phase (GEMM column = phase * co + c).  Under a pack plan the
+    buffer is persistent and all of a pass's rows are written by the plan's one copy launch (ops.PackPlan.copy_for)."""
     co = b.numel()
-    dst = _empty(4 * co, b)
+    plan = ops.current_plan()
+    if plan is not None and USE_PLAN_COPIES and b.is_contiguous():
+        dst, ready = plan.copy_for(("bias4", b.data_ptr()), plan.phase, (b.data_ptr(), co),
+                                   lambda: (_empty(4 * co, b), [b], [(b, 0, 0, 4, co, 0, co)]))
+        if ready:
+            return dst
+    else:
+        dst = _empty(4 * co, b)
     ops.pack_weight(dst, b, 4, 1, co, (co, 0, 1), (0, 0, 1))
     return dst
 
@@ -444,24 +455,39 @@ def _up_bwd(upmod, is_deconv, u: _UpRec, d_up, d_src, accumulate, gate, b, grads
         ops.bilinear2x_bwd(d_interp, d_src, accumulate, gate)  # (gate: bf16 storage only, see backward_impl)
 
 
-def _grouped_weights(model, refresh=False):
+def _grouped_weights(model, refresh=False, plan=None):
     """{(i, jj): [sum of consumer widths, f_i, 3, 3]}: for every skip tensor X[i][jj] the input-channel slices that read it
     in conv1 of its consumers (i, jj+1), (i, jj+2), ..., concatenated along the OUTPUT-channel axis -- as a convolution
     weight its input gradient is the sum of the consumers' contributions.  Buffers are kept (stable addresses: the
-    pack plan prepacks their images with everything else) and refilled from the current parameters when `refresh`."""
+    pack plan prepacks their images with everything else) and refilled from the current parameters when `refresh`:
+    by one torch.cat each the first time, from then on by the plan's one copy launch at ``plan.begin("bwd")`` (the slices
+    are strided copies: ops.PackPlan.copy_for; 6 launches per step at depth 4, 10 at depth 5 otherwise)."""
     cache = getattr(model, "_grouped_dgrad_w", None)
     d = model.depth
     if cache is None or refresh:
         fresh = {}
         for i in range(d - 1):
             for jj in range(d - 1 - i):
-                parts = []
-                for jc in range(jj + 1, d - i):
-                    w = getattr(getattr(model, "up_concat%d%d" % (i, jc)).conv.conv1, "0").weight.detach()
-                    f = w.shape[0]
-                    parts.append(w[:, (1 + jj) * f:(2 + jj) * f])
+                ws = [getattr(getattr(model, "up_concat%d%d" % (i, jc)).conv.conv1, "0").weight.detach()
+                      for jc in range(jj + 1, d - i)]
+                f = ws[0].shape[0]
+                parts = [w[:, (1 + jj) * f:(2 + jj) * f] for w in ws]
                 old = None if cache is None else cache.get((i, jj))
-                if old is not None and old.device == parts[0].device and old.dtype == parts[0].dtype:
+                if old is not None and not (old.device == parts[0].device and old.dtype == parts[0].dtype):
+                    old = None
+                if plan is not None and all(w.is_contiguous() and w.dtype == torch.float32 for w in ws):
+                    key, sig = ("grouped", i, jj), tuple(w.data_ptr() for w in ws)
+                    if old is not None and plan.knows_copy(key, "bwd", sig + (old.data_ptr(),)):
+                        plan.copy_for(key, "bwd", sig + (old.data_ptr(),), None)   # (marks the entry used)
+                        fresh[(i, jj)] = old
+                        continue
+                    buf = old if old is not None else torch.empty((len(ws) * f, f) + tuple(ws[0].shape[2:]),
+                                                                   dtype=ws[0].dtype, device=ws[0].device)
+                    t = ws[0].shape[2] * ws[0].shape[3]
+                    items = [(w, (1 + jj) * f * t, q * f * f * t, f, f * t, w.shape[1] * t, f * t) for q, w in enumerate(ws)]
+                    plan.copy_for(key, "bwd", sig + (buf.data_ptr(),), lambda: (buf, list(ws), items))
+                    old = buf
+                if old is not None:
                     torch.cat(parts, 0, out=old)
                     fresh[(i, jj)] = old
                 else:
@@ -474,8 +500,8 @@ def _grouped_weights(model, refresh=False):
 def backward_impl(model, s: _Saved, d_outs, want_input_grad: bool, grad_sink=None):
     """Returns (dict param -> grad, dx NHWC or None).  grad_sink(list of (param, grad)) is called each time a
     node's parameter gradients are final (used by the data-parallel bucketed all-reduce)."""
-    if USE_GROUPED_DGRAD:
-        _grouped_weights(model, refresh=True)   # before the pack plan packs this pass's weight images
+    if USE_GROUPED_DGRAD:   # before the pack plan packs this pass's weight images
+        _grouped_weights(model, refresh=True, plan=_plan_of(model) if (USE_PACK_PLAN and USE_PLAN_COPIES) else None)
     if not USE_PACK_PLAN:
         return _backward_impl(model, s, d_outs, want_input_grad, grad_sink)
     plan = _plan_of(model)

@@ -55,6 +55,8 @@ from typing import Optional
 
 import torch
 
+from .step import loss_and_backward
+
 _HIP_NODE_TYPES = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event",
                    7: "event_record", 8: "ext_sem_signal", 9: "ext_sem_wait", 10: "mem_alloc", 11: "mem_free",
                    12: "memcpy_from_symbol", 13: "memcpy_to_symbol"}
@@ -228,14 +230,7 @@ class GraphedTrainStep:
         """train_step's sequence (step.py) on the static tensors"""
         self.optimizer.zero_grad(set_to_none=True)
         outputs = self.model(self._x)
-        if isinstance(outputs, tuple):
-            avgloss = 0
-            for output in outputs:
-                avgloss = avgloss + self.criterion(output, self._t)
-            avgloss = 1.0 * avgloss / len(outputs)
-        else:
-            avgloss = self.criterion(outputs, self._t)
-        avgloss.backward()
+        avgloss = loss_and_backward(self.criterion, outputs, self._t)
         if with_optimizer:
             self.optimizer.step()
         return outputs, avgloss

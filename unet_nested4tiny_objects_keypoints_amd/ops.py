@@ -232,8 +232,14 @@ class PackPlan:
     class _Entry:
         __slots__ = ("image", "n_img", "job", "src", "phase", "fresh", "used")
 
+    class _Copy:  # a group of strided copies into one destination buffer (unetpp_copy_jobs), redone with the images
+        __slots__ = ("dst", "jobs", "srcs", "srcsig", "phase", "fresh", "used", "elems")
+
     def __init__(self):
         self.entries = {}
+        self.copies = {}     # key -> _Copy
+        self._copy_tables = {}  # phase -> (device table, keys, max elements)
+        self.copy_launches = 0  # batched copy launches issued (tests)
         self._tables = {}    # phase -> (device table, host array, signatures, max floats)
         self._packed = set()  # phases whose images are current (only consulted while frozen)
         self.frozen = False
@@ -270,6 +276,9 @@ class PackPlan:
             stale = [k for k, e in self.entries.items() if self.pass_id - e.used > 16]
             for k in stale:
                 del self.entries[k]
+            for k in [k for k, c in self.copies.items() if self.pass_id - c.used > 16]:
+                del self.copies[k]
+        self._begin_copies(phase)   # (first: weight images of this pass may be packed FROM a copied buffer)
         sigs = tuple(k for k, e in self.entries.items() if e.phase == phase)
         if not sigs:
             return
@@ -290,6 +299,59 @@ class PackPlan:
             self._packed.add(phase)
         for e in ents:
             e.fresh = self.pass_id
+
+    def _begin_copies(self, phase: str) -> None:
+        keys = tuple(k for k, c in self.copies.items() if c.phase == phase)
+        if not keys:
+            return
+        cps = [self.copies[k] for k in keys]
+        tab = self._copy_tables.get(phase)
+        if tab is None or tab[1] != keys:
+            jobs = [j for c in cps for j in c.jobs]
+            arr = (_lib.CopyJob * len(jobs))(*jobs)
+            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(cps[0].dst.device)
+            if self.pinned and phase in self._copy_tables:
+                self._retired.append(self._copy_tables[phase])
+            tab = (dev, keys, max(c.elems for c in cps), len(jobs))
+            self._copy_tables[phase] = tab
+            self._packed.discard(phase)
+        if not (self.frozen and phase in self._packed):
+            check(_lib.lib().unetpp_copy_jobs(_ptr(tab[0]), tab[3], tab[2], _stream()), "unetpp_copy_jobs")
+            self.copy_launches += 1
+        for c in cps:
+            c.fresh = self.pass_id
+
+    def copy_for(self, key, phase: str, srcsig, make):
+        """A destination buffer filled by strided copies that ``begin(phase)`` redoes in ONE launch from the second pass on.
+        -> (dst, ready): ready = the buffer already holds this pass's contents.  The first time `key` is seen -- or when
+        `srcsig` (whatever identifies the sources: their addresses) changed -- ``make()`` -> (dst tensor, source tensors
+        kept alive, [(src tensor, src offset, dst offset, n_outer, n_inner, src_stride, dst_stride) in floats]) builds the
+        job list; the caller fills the buffer itself for that pass (ready = False)."""
+        c = self.copies.get(key)
+        if c is None or c.srcsig != srcsig or c.phase != phase:
+            dst, srcs, items = make()
+            c = PackPlan._Copy()
+            c.dst, c.srcs, c.srcsig, c.phase, c.fresh = dst, srcs, srcsig, phase, -1
+            c.jobs, c.elems = [], 1
+            for (src, s_off, d_off, n_outer, n_inner, s_stride, d_stride) in items:
+                j = _lib.CopyJob()
+                j.src, j.dst = src.data_ptr() + 4 * s_off, dst.data_ptr() + 4 * d_off
+                j.n_outer, j.n_inner, j.src_stride, j.dst_stride = n_outer, n_inner, s_stride, d_stride
+                if n_outer * n_inner >= 2 ** 31:
+                    raise ValueError("copy job too large")
+                c.jobs.append(j)
+                c.elems = max(c.elems, n_outer * n_inner)
+            self.copies[key] = c
+            old_tab = self._copy_tables.pop(phase, None)   # same keys, other jobs: the table is rebuilt by the next begin()
+            if old_tab is not None and self.pinned:
+                self._retired.append(old_tab)
+        c.used = self.pass_id
+        return c.dst, c.fresh == self.pass_id
+
+    def knows_copy(self, key, phase: str, srcsig) -> bool:
+        """begin(phase) will fill this buffer (callers that run BEFORE begin: the grouped input-gradient weights)"""
+        c = self.copies.get(key)
+        return c is not None and c.srcsig == srcsig and c.phase == phase
 
     def image_for(self, sig, n_img: int, weight: "WSrc", d: GemmDesc):
         """-> (image tensor, already packed for this pass)"""
@@ -318,6 +380,11 @@ _PLAN: Optional[PackPlan] = None
 def set_pack_plan(plan: Optional[PackPlan]) -> None:
     global _PLAN
     _PLAN = plan
+
+
+def current_plan() -> Optional[PackPlan]:
+    """the plan of the engine pass that is running, if any"""
+    return _PLAN if (_PLAN is not None and _PLAN.phase is not None) else None
 
 
 def gemm_pixel_blocks(n: int, h: int, w: int) -> int:
@@ -659,6 +726,33 @@ def focal_bce(pred: torch.Tensor, target: torch.Tensor, rows: int, gamma: float,
     check(lib.unetpp_focal_bce(_ptr(pred), _ptr(target), n, rows, float(gamma), _ptr(grad), _ptr(partial), _ptr(loss),
                                _stream()), "unetpp_focal_bce")
     return loss.reshape(()), grad
+
+
+def focal_bce_heads(preds, target: torch.Tensor, rows: int, gamma: float, want_grad: bool = True):
+    """The trainer's loop over the deep-supervision heads (criterion on every head, mean over heads) in one launch:
+    -> (losses [1 + heads]: the mean, then every head's FocalLoss_BCE_2d value; d mean / d pred per head or None).
+    Bit for bit what the loop computes with focal_bce and tensor arithmetic (tests/test_gpu_caller.py)."""
+    lib = _lib.lib()
+    if not 1 <= len(preds) <= _lib.MAX_HEADS:
+        raise ValueError("1 to %d heads" % _lib.MAX_HEADS)
+    _need(target, "target")
+    for p in preds:
+        _need(p, "pred")
+        if p.shape != target.shape:
+            raise ValueError("pred and target must have the same shape")
+    n = target.numel()
+    blocks = int(lib.unetpp_focal_bce_blocks(n))
+    partial = torch.empty(len(preds) * blocks, dtype=torch.float32, device=target.device)
+    grads = [torch.empty_like(p) for p in preds] if want_grad else None
+    loss = torch.empty(1 + len(preds), dtype=torch.float32, device=target.device)
+    hd = _lib.FocalHeads()
+    hd.n_heads = len(preds)
+    for i, p in enumerate(preds):
+        hd.pred[i] = p.data_ptr()
+        hd.grad[i] = grads[i].data_ptr() if want_grad else None
+    check(lib.unetpp_focal_bce_heads(C.byref(hd), _ptr(target), n, rows, float(gamma), _ptr(partial), _ptr(loss),
+                                     _stream()), "unetpp_focal_bce_heads")
+    return loss, grads
 
 
 def create_heatmap(points: torch.Tensor, height: int, width: int, radius: float = 3.0) -> torch.Tensor:
