@@ -576,6 +576,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
           }
       }
     }
+    // (Round 6: starting the sums with C = 0 in the unit's first 32 MFMAs instead of these 128 v_mov was built and
+    // measured -- profiles/r6/ab_wino_zero_in_mfma.txt.  As two C++ branches hipcc renames the group's accumulators and
+    // spills; as one asm statement per group it is 1.4 % SLOWER on a step, because the opaque 8-MFMA blocks take the
+    // staging code out from between the MFMAs, and the clearing it saves is worth 0.1-0.3 %: it sits in the epilogue.)
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
