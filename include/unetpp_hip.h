@@ -145,7 +145,8 @@ const char* unetpp_last_kernel_name(void);
  * (v9; replaces per-launch getenv).  `name` is the switch without its UNETPP_ prefix: BF16_NO_DMA, BF16_DMA_ALL,
  * BF16_DMA_MIN8, BF16_DMA_FORM, BF16_DMA_SMALL, BF16_DMA_STATS, BF16_DMA_POINTWISE, BF16_DMA_SPLIT, BF16_WGRAD_QUAD,
  * WINO_NO_LEAN, WINO_ONE_PER_CU, MEMSET_NODES, BF16_PW_PLAIN, PW_DIRECT (0: fp32 pointwise launches back on the LDS-staged
- * kernels), PW_NT (fp32 pointwise GEMM: 1 / 0 = non-temporal / plain stores whatever the output size).  set != 0: the switch takes `value`; set == 0: back to the
+ * kernels), PW_NT (fp32 pointwise GEMM: 1 / 0 = non-temporal / plain stores whatever the output size),
+ * HEAD_WGS_PER_CU (bf16 head backward: at most this many workgroups per CU take tiles, default 4; 0 = the whole grid).  set != 0: the switch takes `value`; set == 0: back to the
  * dispatcher's built-in default.  The environment variable UNETPP_<name>, if present when the library first looks a
  * switch up, is the initial setting.  Process-wide; results never depend on a switch beyond the summation order of the
  * kernel it selects.  UNETPP_EINVAL for an unknown name. */

@@ -6,8 +6,9 @@ import torch
 from unet_nested4tiny_objects_keypoints_amd import ops
 B = int(os.environ.get("B", "32")); REPS = int(os.environ.get("REPS", "5"))
 S = int(os.environ.get("SIZE", "256")); BF = os.environ.get("DTYPE", "f32") == "bf16"
-x = torch.randn(B, S, S, 32, device="cuda"); x = x.to(torch.bfloat16) if BF else x; w = torch.randn(4, 32, device="cuda") * 0.1; b = torch.zeros(4, device="cuda")
-o = torch.empty(B, 4, S, S, device="cuda"); go = torch.randn_like(o); dx = torch.empty_like(x)
+CH = int(os.environ.get("CH", "32")); NC = int(os.environ.get("NCLS", "4"))   # feature channels, classes (configs[4]: 64, 5)
+x = torch.randn(B, S, S, CH, device="cuda"); x = x.to(torch.bfloat16) if BF else x; w = torch.randn(NC, CH, device="cuda") * 0.1; b = torch.zeros(NC, device="cuda")
+o = torch.empty(B, NC, S, S, device="cuda"); go = torch.randn_like(o); dx = torch.empty_like(x)
 def t(fn):
     fn(); torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

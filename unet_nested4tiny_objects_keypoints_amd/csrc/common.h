@@ -158,6 +158,7 @@ enum Opt {
   OPT_BF16_PW_PLAIN,       // 0: plain-output bf16 pointwise launches on the two-per-CU instantiation (round-4 form)
   OPT_PW_DIRECT,           // 0: fp32 pointwise GEMMs back on gemm_fast_kernel<1> (tests compare the two kernels)
   OPT_PW_NT,               // fp32 pointwise GEMM: 1 / 0 = non-temporal / plain stores whatever the output size
+  OPT_HEAD_WGS_PER_CU,     // bf16 head backward: at most this many workgroups per CU take tiles (default 4; 0 = every workgroup of the grid, as until round 6)
   OPT_COUNT
 };
 bool opt_is_set(Opt o);

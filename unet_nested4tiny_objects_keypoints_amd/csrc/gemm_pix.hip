@@ -200,7 +200,7 @@ thread_local const char* g_last_kernel = "";
 const char* const kOptNames[OPT_COUNT] = {
     "BF16_NO_DMA", "BF16_DMA_ALL", "BF16_DMA_MIN8", "BF16_DMA_FORM", "BF16_DMA_SMALL", "BF16_DMA_STATS",
     "BF16_DMA_POINTWISE", "BF16_DMA_SPLIT", "BF16_WGRAD_QUAD", "WINO_NO_LEAN", "WINO_ONE_PER_CU", "MEMSET_NODES",
-    "BF16_PW_PLAIN", "PW_DIRECT", "PW_NT"};
+    "BF16_PW_PLAIN", "PW_DIRECT", "PW_NT", "HEAD_WGS_PER_CU"};
 struct OptSlot {
   std::atomic<long> value{0};
   std::atomic<bool> set{false};

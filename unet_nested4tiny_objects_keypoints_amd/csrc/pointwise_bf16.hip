@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kThreads) void head_bwd_bf16_kernel(const float* __
                                                                  unsigned pixels, unsigned HW, int n_cls, float keep_scale,
                                                                  uint32_t thr16, uint64_t seed, const uint8_t* __restrict__ mask, const uint64_t* __restrict__ seed_dev,
                                                                  bf16_t* __restrict__ dx, int accumulate, int gate_x,
-                                                                 float* __restrict__ partial) {
+                                                                 float* __restrict__ partial, unsigned active) {
   if (seed_dev != nullptr) seed += *seed_dev;  // graph-captured steps: the varying part of the seed lives in device memory
   // 256-pixel tiles (four items in flight per thread at 32 channels): dlogit = d_out * out * (1 - out) of the tile goes through LDS (the NCHW class planes are read
   // coalesced along the pixels), then every thread takes (pixel, channel octet) items: dx = keep * scale * (W^T dlogit)
@@ -279,9 +279,12 @@ __global__ __launch_bounds__(kThreads) void head_bwd_bf16_kernel(const float* __
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cg = tid & (CG - 1);
   const unsigned n_tiles = (pixels + TP - 1) / TP;
-  if (blockIdx.x >= n_tiles) {
+  // `active` workgroups walk the tiles (round 6).  A workgroup's fixed part -- 48 weight loads per thread, the shuffle and
+  // LDS reduction of its 48 + 6 sums, a 1.3 KB row -- used to be paid per tile or two (one workgroup per tile up to 4096:
+  // 2304 tiles at configs[4], 8192 at configs[3]); three workgroups per CU is what the registers allow to be resident.
+  if (blockIdx.x >= n_tiles || blockIdx.x >= active) {
     // The grid and the partial rows are sized from 64-pixel tiles (unetpp_head_bwd_blocks, shared with the fp32 kernel);
-    // below 4096 * TP pixels some blocks own no tile of this kernel: a zero row (the caller sums every row) and out,
+    // blocks that own no tile of this kernel: a zero row (the caller sums every row) and out,
     // before the weight registers, the shuffles and the LDS reduction
     float* dst = partial + static_cast<long>(blockIdx.x) * (n_cls * C + n_cls);
     for (int i = tid; i < n_cls * C + n_cls; i += kThreads) dst[i] = 0.f;
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(kThreads) void head_bwd_bf16_kernel(const float* __
     }
   }
   for (int i = tid; i < TP * kHeadMaxCls; i += kThreads) dl[i] = 0.f;  // classes past n_cls are never written again
-  for (unsigned tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (unsigned tile = blockIdx.x; tile < n_tiles; tile += active) {
     const unsigned p0 = tile * TP;
     __syncthreads();
     for (int it = tid; it < TP * n_cls; it += kThreads) {  // dlogit = d_out * out * (1 - out)
@@ -671,6 +674,23 @@ extern "C" int unetpp_head_bwd_bf16(const float* d_out_nchw, const float* out_nc
   const long tiles = (pixels + 63) / 64;
   const size_t lds = (kHeadTilePixels * kHeadMaxCls + 4 * (kHeadMaxCls * C + kHeadMaxCls)) * sizeof(float);  // dlogit tile + 4 wave rows
   const dim3 grid(static_cast<unsigned>(tiles < 4096 ? tiles : 4096));
+  // Workgroups that take tiles: at most HEAD_WGS_PER_CU per CU (default 4), and then as few as walk the same number of
+  // rounds (2304 tiles: 3 rounds of 768 rather than 1024 workgroups of which 256 carry a third tile).  tools/sweep_head_wgs.sh:
+  // configs[4] 87 -> 65-74 us per head, configs[3] 113 -> 102 us (dropout, accumulate and gate on; 0 = every workgroup).
+  const long per_cu = opt_value(OPT_HEAD_WGS_PER_CU, 4);
+  const int cus = device_cu_count();
+  if (cus <= 0) return UNETPP_ELAUNCH;
+  unsigned active = grid.x;
+  {
+    constexpr long kTilePixels = kHeadTilePixels;  // (every instantiation with C <= 64; wider heads use smaller tiles: more rounds, same rule)
+    const long n_tiles = (pixels + kTilePixels - 1) / kTilePixels;
+    const long most = per_cu * cus;
+    if (per_cu > 0 && most < n_tiles) {
+      const long rounds = (n_tiles + most - 1) / most;
+      active = static_cast<unsigned>((n_tiles + rounds - 1) / rounds);
+    }
+    if (active > grid.x) active = grid.x;
+  }
   const int drop = p_drop > 0.f ? (mask == nullptr ? 1 : 2) : 0;
   if (drop == 2 && (reinterpret_cast<uintptr_t>(mask) & 7) != 0) return UNETPP_EINVAL;  // mask octets are read as 8 bytes
 #define UNETPP_HEAD_BWD_BF(L, D)                                    \
@@ -683,7 +703,7 @@ extern "C" int unetpp_head_bwd_bf16(const float* d_out_nchw, const float* out_nc
   hipLaunchKernelGGL((head_bwd_bf16_kernel<L, D, PC>), grid, dim3(kThreads), lds, ST(stream), d_out_nchw, out_nchw,     \
                      static_cast<const bf16_t*>(x), weight, static_cast<unsigned>(pixels), static_cast<unsigned>(H * W), \
                      n_cls, 1.0f / (1.0f - p_drop), keep_threshold(p_drop), seed, mask, seed_dev, static_cast<bf16_t*>(dx),       \
-                     accumulate, gate_x, partial)
+                     accumulate, gate_x, partial, active)
 #define UNETPP_HEAD_BWD_BF_L(L)              \
   do {                                       \
     if (drop == 0) UNETPP_HEAD_BWD_BF(L, 0); \
