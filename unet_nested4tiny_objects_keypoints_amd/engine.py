@@ -32,6 +32,11 @@ USE_GROUPED_DGRAD = os.environ.get("UNETPP_NO_GROUPED_DGRAD") is None
 # A/B switch (measurements only): the bias rows / grouped weights by one launch each instead of the plan's copy launch
 USE_PLAN_COPIES = os.environ.get("UNETPP_NO_PLAN_COPIES") is None
 _A1_MATERIALIZE_BYTES = int(float(os.environ.get("UNETPP_BF16_A1_MAX_MB", "80")) * (1 << 20))
+# fp32 storage, the same choice (round 6): the fold costs the Winograd GEMM ~8 % of its matrix-pipe occupancy and the Winograd
+# weight gradient ~20 % (profiles/r6/pmc_summary_f32_*: 0.56 / 0.52 against 0.61 / 0.66 on plain views), a pass over a small
+# y1 costs less: headline 18.81 -> 18.74 ms at 40-80 MB (levels 2-4), 18.77 at 160, 18.84 at 300 (every level),
+# tools/sweep_f32_a1.sh on one box, alternating.  0 = never.
+_A1_MATERIALIZE_BYTES_F32 = int(float(os.environ.get("UNETPP_F32_A1_MAX_MB", "80")) * (1 << 20))
 
 
 # ----------------------------------------------------------------------------- weight re-layouts
@@ -178,7 +183,8 @@ def _pair_fwd(blk, ins: List[V], b, h, w, training, pool, adt=torch.float32) -> 
         # operands are bit-identical -- because a plain bf16 view lets conv2 and its weight gradient take the LDS-DMA /
         # quad kernels, and below a few tens of MB the extra pass costs less than the register-staged kernels lose
         r.y2 = new()
-        if adt == torch.bfloat16 and r.y1.numel() * 2 <= _A1_MATERIALIZE_BYTES:
+        if ((adt == torch.bfloat16 and r.y1.numel() * 2 <= _A1_MATERIALIZE_BYTES) or
+                (adt == torch.float32 and r.y1.numel() * 4 <= _A1_MATERIALIZE_BYTES_F32)):
             r.a1 = new()
             ops.affine_relu_pool(r.y1, r.bn1[2], r.bn1[3], True, r.a1, None, None)
             r.bn2 = _conv_bn_fwd([V(r.a1)], conv2, bn2, r.y2, b, h, w, training)
