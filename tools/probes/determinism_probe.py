@@ -10,6 +10,7 @@ back, from an idle device, and with a fresh PackPlan each time (table upload + f
 the first tensor (in forward order) that differs, per run.  Bounded: `runs` (default 40) runs per regime.
 """
 import copy
+import gc
 import os
 import sys
 import time
@@ -107,6 +108,9 @@ def main():
             bad_runs, first_bad = 0, {}
             for r in range(runs):
                 if regime.startswith("fresh-plan"):
+                    m = None
+                    gc.collect()                     # (a model that kept its saved activations is cyclic garbage: 7-14 GB per run
+                    torch.cuda.empty_cache()         # at the benchmarked geometries, which nothing collects under GPU memory pressure)
                     m = copy.deepcopy(base)          # a deep copy starts with an empty PackPlan
                     m._debug_keep_saved = True
                     if regime.endswith("second-pass"):
