@@ -260,7 +260,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
         const int y = p_ty0 + hy - 1, x = p_tx0 + hx - 1;
         // bitwise, and the index computed on both sides: a short-circuit here becomes a divergent branch that the
         // optimiser threads into the cursor code below, after which the whole cursor lives in vector registers
-        const bool inside = (it < NPIX * 2) & (static_cast<unsigned>(y) < static_cast<unsigned>(d.H)) &
+        // (only the last pass has items past the patch: for the others the test is a compile-time `true`, not a lane mask
+        // that lives in -- and is spilled from -- a scalar register pair across the unit loop)
+        const bool in_patch = ((q + 1) * kThreads <= NPIX * 2) ? true : (it < NPIX * 2);
+        const bool inside = in_patch & (static_cast<unsigned>(y) < static_cast<unsigned>(d.H)) &
                             (static_cast<unsigned>(x) < static_cast<unsigned>(d.W));
         const int linear = (row0 + y) * d.W + x;
         pix[q] = inside ? linear : -1;
