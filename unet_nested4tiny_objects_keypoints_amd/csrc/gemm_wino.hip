@@ -526,7 +526,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
 #pragma unroll                        // between the stores
           for (int bp = 0; bp < 2; ++bp)
 #pragma unroll
-            for (int nh = 0; nh < NH; ++nh) *reinterpret_cast<f32x4*>(obase + off[bp][nh]) = yv[bp][nh];
+            for (int nh = 0; nh < NH; ++nh) {
+              if constexpr (wino_exp::kNoOutStore) asm volatile("" ::"v"(yv[bp][nh]), "v"(off[bp][nh]));  // (ablation builds)
+              else *reinterpret_cast<f32x4*>(obase + off[bp][nh]) = yv[bp][nh];
+            }
           WINO_STAMP(10 + ap);  // 10, 11: epilogue rows
           continue;
         }
@@ -769,6 +772,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_wino_kernel(const FastArgs a
     // buffers and its staging stores (lgkmcnt(0)), its share of the next weight image (vmcnt(IN_ITEMS)).
     // (round 5: 19.765 -> 19.715 ms per step against the __syncthreads() form, profiles/r5/ab_wino_raw_barrier.txt)
     if constexpr (!wino_exp::kNoBarrier) {
+      if (wino_exp::kLaxWait && c_chunk == 0 && c_unit > 0)  // (ablation builds: first chunk behind an epilogue)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(IN_ITEMS + 4 + 4 * NH) : "memory");
+      else
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(IN_ITEMS) : "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");

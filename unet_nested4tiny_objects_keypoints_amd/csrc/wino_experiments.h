@@ -41,5 +41,17 @@ constexpr bool kNoEpilogue = true;
 constexpr bool kNoEpilogue = false;
 #endif
 
+#ifdef UNETPP_WINO_EXP_NO_OUT_STORE  // the epilogue runs (transform, bias, ReLU) but its plain 16-byte stores are not issued
+constexpr bool kNoOutStore = true;
+#else
+constexpr bool kNoOutStore = false;
+#endif
+
+#ifdef UNETPP_WINO_EXP_LAX_WAIT  // the chunk barrier behind an epilogue does not wait for the epilogue's stores (NOR for
+constexpr bool kLaxWait = true;  // the weight DMA issued after them: wrong results, an upper bound of what the wait costs)
+#else
+constexpr bool kLaxWait = false;
+#endif
+
 }  // namespace wino_exp
 }  // namespace unetpp
