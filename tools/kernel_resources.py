@@ -26,7 +26,10 @@ def report(path, defines=()):
            "-I", CSRC, "-c", path, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"] + ["-D" + d for d in defines]
     if os.path.basename(path) in SLP_OFF:
         cmd.insert(5, "-fno-slp-vectorize")
-    err = subprocess.run(cmd, capture_output=True, text=True).stderr
+    run = subprocess.run(cmd, capture_output=True, text=True)
+    if run.returncode != 0:   # a source that does not compile reports no kernels at all -- which must not read as "no spills"
+        raise RuntimeError("hipcc failed on %s:\n%s" % (path, "\n".join(l for l in run.stderr.splitlines() if "error" in l)[:2000]))
+    err = run.stderr
     rows, cur = [], None
     for ln in err.splitlines():
         m = re.search(r"Function Name: (\S+)", ln)
